@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py - IQ Msamples/s demodulated on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of HBM-resident synthetic input:
+scan kernel + demod kernel + record fetch (+ gather of records to rank 0 when N > 1) + the
+sequential host resolve on rank 0.  Workload = BASELINE.json configs[1]: 1 GiB of synthetic
+uint8 I/Q in 2 Msps file format (sigma = 3 integer noise, tests/synth.py), --no-fix, PER GPU
+(weak scaling: the stream is sharded into per-GPU buffer ranges, each rank's shard is 1 GiB).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is for the scan kernel (the only stage that reads
+every sample): algorithmic bytes = 2 per sample, duration = HIP events recorded around the kernel
+on its launch stream inside libmodes_gfx950.so.  `cpu_baseline` (N == 1 only) times the compiled
+reference (oracle/_ref) - or the C restatement if that binary is absent - on the host.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(iq, nbytes_sample):
+    """Reference single-threaded C path on the host cores, on the first nbytes_sample bytes of the
+    same workload.  Checker code (oracle/) is used here only as the thing being timed."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    sample = iq[:nbytes_sample].cpu().numpy()
+    sample[-480:] = 127
+    nsamp = nbytes_sample // 2
+    if orc.have_ref():
+        with tempfile.NamedTemporaryFile(suffix=".bin", dir="/tmp") as f:
+            sample.tofile(f.name)
+            env = dict(os.environ, LD_PRELOAD=orc.FIXED_TIME)
+            t0 = time.perf_counter()
+            out = subprocess.run([orc.REF_BIN, "--ifile", f.name, "--raw", "--no-fix"], stdout=subprocess.PIPE,
+                                 env=env, check=True).stdout
+            dt = time.perf_counter() - t0
+        kind, lines = "reference", out.count(b"\n")
+        what = "oracle/_ref/dump1090_ref --ifile <first %d MiB of the workload> --raw --no-fix" % (nbytes_sample >> 20)
+    else:
+        t0 = time.perf_counter()
+        msgs, _ = orc.run_stream(sample, **orc.FLAGSETS["nofix"])
+        dt = time.perf_counter() - t0
+        kind, lines = "port", len(msgs)
+        what = "oracle/liboracle.so orc_run_stream on the first %d MiB of the workload, --no-fix" % (nbytes_sample >> 20)
+    return {"value": round(nsamp / dt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
+            "sample": "%s; %.2f s wall, %d messages; 1 decode thread (host has %d cores)" % (
+                what, dt, lines, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mib", type=int, default=1024, help="MiB of I/Q per GPU (default: the 1 GiB workload)")
+    ap.add_argument("--cpu-mib", type=int, default=1024, help="MiB of the workload timed on the CPU baseline")
+    ap.add_argument("--run-chunks", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from dump1090_amd import Demodulator, HostResolver, block_count, shard_blocks, shard_byte_range
+    from dump1090_amd.distributed import gather_records
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (
+                args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # the global stream = world x (--mib) MiB; this rank demodulates its contiguous buffer range and
+    # holds exactly the bytes that range needs (its buffers + the 476-byte carry in front).
+    per_gpu = args.mib << 20
+    total = per_gpu * world
+    nblocks_total = block_count(total)
+    first_block, nblocks = shard_blocks(nblocks_total - 1, world, rank)     # the EOF buffer goes to the last rank
+    if rank == world - 1:
+        nblocks += 1
+    lo, hi = shard_byte_range(first_block, nblocks, total)
+
+    demod = Demodulator(device=local, fix=False, run_chunks=args.run_chunks)
+    iq = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
+    demod.synth_noise(iq, first_byte=lo, seed=20260922, sigma_q16=941)
+    if hi == total:
+        demod.fill(iq[-480:], 127)                  # oracle-safe tail
+    torch.cuda.synchronize(dev)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    scan_ms, demod_ms, n_msgs, n_pre = [], [], 0, 0
+    t0 = None
+    for step in range(args.warmup + args.steps):
+        if step == args.warmup:
+            sync_all()
+            t0 = time.perf_counter()
+        demod.detect(iq, stream_byte0=lo, first_block=first_block, nblocks=nblocks)
+        recs, cands, info = demod.fetch()
+        if world > 1:
+            recs, cands = gather_records(recs, cands, dst=0, device=dev)
+        if rank == 0:
+            res = HostResolver(fix=False)
+            m = res.count(recs, cands)
+            res.close()
+        if step >= args.warmup:
+            scan_ms.append(info["scan_ms"])
+            demod_ms.append(info["demod_ms"])
+            if rank == 0:
+                n_msgs += m
+            n_pre = info["n_preambles"]
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_step = total // 2
+    value = samples_per_step * args.steps / elapsed / 1e6
+    scan_avg_ms = float(np.mean(scan_ms))
+    achieved = (2.0 * (hi - lo) / 2) / (scan_avg_ms * 1e-3) / 1e9       # this rank's launch: 2 B per sample
+    line = {
+        "metric": "IQ Msamples/s demodulated", "value": round(value, 1), "unit": "Msamples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+        "config": {"workload": "%d MiB synthetic uint8 IQ @ 2 Msps format per GPU (sigma=3 integer noise, seed "
+                               "20260922), --no-fix, HBM-resident; BASELINE.json configs[1]" % args.mib,
+                   "bytes_per_gpu": per_gpu, "flags": "--raw --no-fix", "sharding": "buffers over %d rank(s)" % world,
+                   "step": "scan + demod kernels, record fetch%s, host resolve" % (
+                       ", RCCL gather to rank 0" if world > 1 else "")},
+        "msgs_per_s": round(n_msgs / elapsed, 2),
+        "preambles_per_step_rank0": int(n_pre),
+        "kernel_ms": {"scan": round(scan_avg_ms, 4), "demod_finalize": round(float(np.mean(demod_ms)), 4)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "scan_kernel", "algorithmic_bytes_per_launch": int(hi - lo)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(iq, min(args.cpu_mib << 20, (hi - lo) // 262144 * 262144))
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    demod.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

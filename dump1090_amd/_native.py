@@ -1,0 +1,173 @@
+"""ctypes bindings of the two product libraries (include/modes_gfx950.h, include/modes_host.h).
+
+No fallback: if libmodes_gfx950.so is missing or no HIP device is present, creating a
+GPU context raises ModesError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+GPU_LIB = os.path.join(PKG_DIR, "libmodes_gfx950.so")
+HOST_LIB = os.path.join(PKG_DIR, "libmodes_host.so")
+
+DATA_LEN = 262144
+CARRY_BYTES = 476
+BLOCK_STRIDE = 131072
+BLOCK_POSITIONS = 131070
+CARRY_SAMPLES = 238
+
+MODES_OK = 0
+ERRORS = {-1: "MODES_ERR_ARG", -2: "MODES_ERR_HIP", -3: "MODES_ERR_NOMEM", -4: "MODES_ERR_OVERFLOW",
+          -5: "MODES_ERR_STATE"}
+
+
+class ModesError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("%s: %s" % (ERRORS.get(code, code), text))
+        self.code = code
+
+
+class GpuConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("fix_errors", C.c_int32), ("aggressive", C.c_int32),
+                ("keep_candidates", C.c_int32), ("run_chunks", C.c_uint32), ("slot_cap", C.c_uint32),
+                ("max_records", C.c_uint32), ("scan_variant", C.c_uint32)]
+
+
+class Attempt(C.Structure):
+    _fields_ = [("msg", C.c_uint8 * 14), ("errors", C.c_uint8), ("gate_ok", C.c_uint8), ("nfix", C.c_uint8),
+                ("fixpos", C.c_uint8 * 2), ("pad", C.c_uint8 * 5), ("syndrome", C.c_uint32)]
+
+
+class Record(C.Structure):
+    _fields_ = [("block", C.c_uint32), ("j", C.c_uint32), ("att", Attempt * 2)]
+
+
+ATTEMPT_DTYPE = np.dtype([("msg", np.uint8, 14), ("errors", np.uint8), ("gate_ok", np.uint8), ("nfix", np.uint8),
+                          ("fixpos", np.uint8, 2), ("pad", np.uint8, 5), ("syndrome", np.uint32)])
+RECORD_DTYPE = np.dtype([("block", np.uint32), ("j", np.uint32), ("att", ATTEMPT_DTYPE, 2)])
+assert C.sizeof(Record) == 64 and RECORD_DTYPE.itemsize == 64
+
+
+class Span(C.Structure):
+    _fields_ = [("iq", C.c_void_p), ("nbytes", C.c_uint64), ("stream_byte0", C.c_uint64),
+                ("first_block", C.c_uint64), ("nblocks", C.c_uint64)]
+
+
+class GpuResult(C.Structure):
+    _fields_ = [("records", C.POINTER(Record)), ("n_records", C.c_uint64),
+                ("candidates", C.POINTER(C.c_uint64)), ("n_candidates", C.c_uint64),
+                ("n_forwarded", C.c_uint64), ("n_preambles", C.c_uint64),
+                ("scan_ms", C.c_float), ("demod_ms", C.c_float)]
+
+
+class HostConfig(C.Structure):
+    _fields_ = [("fix_errors", C.c_int32), ("aggressive", C.c_int32), ("check_crc", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+STAT_NAMES = ("valid_preamble", "out_of_phase", "demodulated", "goodcrc", "badcrc", "fixed", "single_bit_fix",
+              "two_bits_fix")
+
+
+class HostStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in STAT_NAMES]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in STAT_NAMES}
+
+
+class ModesMessage(C.Structure):
+    """struct modesMessage - dump1090.c:211-260, field for field."""
+    _fields_ = [("msg", C.c_ubyte * 14), ("msgbits", C.c_int), ("msgtype", C.c_int), ("crcok", C.c_int),
+                ("crc", C.c_uint32), ("errorbit", C.c_int), ("aa1", C.c_int), ("aa2", C.c_int), ("aa3", C.c_int),
+                ("phase_corrected", C.c_int), ("ca", C.c_int), ("iid", C.c_int), ("metype", C.c_int),
+                ("mesub", C.c_int), ("heading_is_valid", C.c_int), ("heading", C.c_int), ("aircraft_type", C.c_int),
+                ("fflag", C.c_int), ("tflag", C.c_int), ("raw_latitude", C.c_int), ("raw_longitude", C.c_int),
+                ("flight", C.c_char * 9), ("ew_dir", C.c_int), ("ew_velocity", C.c_int), ("ns_dir", C.c_int),
+                ("ns_velocity", C.c_int), ("vert_rate_source", C.c_int), ("vert_rate_sign", C.c_int),
+                ("vert_rate", C.c_int), ("velocity", C.c_int), ("movement", C.c_int), ("movement_valid", C.c_int),
+                ("ground_track", C.c_int), ("ground_track_valid", C.c_int), ("fs", C.c_int), ("dr", C.c_int),
+                ("um", C.c_int), ("identity", C.c_int), ("altitude", C.c_int), ("unit", C.c_int)]
+
+
+class Emitted(C.Structure):
+    _fields_ = [("mm", ModesMessage), ("block", C.c_uint32), ("j", C.c_uint32)]
+
+
+SINK_FN = C.CFUNCTYPE(None, C.POINTER(ModesMessage), C.c_uint32, C.c_uint32, C.c_void_p)
+
+# every symbol include/*.h declares (tests/test_abi.py checks the libraries export them)
+GPU_SYMBOLS = ("modes_gpu_create", "modes_gpu_destroy", "modes_gpu_last_error", "modes_gpu_compute_magnitude",
+               "modes_gpu_detect", "modes_gpu_fetch", "modes_gpu_demod_host", "modes_gpu_compute_power",
+               "modes_gpu_synth_noise", "modes_gpu_fill", "modes_gpu_abi_version")
+HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_resolve", "modes_host_resolve_to_array",
+                "modes_host_wants",
+                "modes_host_get_stats", "modes_host_decode", "modes_format_raw", "modes_format_onlyaddr",
+                "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
+                "modes_block_count")
+
+_gpu = None
+_host = None
+
+
+def gpu_lib():
+    """libmodes_gfx950.so (loading it needs the HIP runtime, not a GPU)."""
+    global _gpu
+    if _gpu is None:
+        if not os.path.exists(GPU_LIB):
+            raise ModesError(-2, "%s is not built (python -c 'import __graft_entry__ as g; g.build()')" % GPU_LIB)
+        L = C.CDLL(GPU_LIB)
+        L.modes_gpu_create.argtypes = [C.POINTER(GpuConfig), C.POINTER(C.c_void_p)]
+        L.modes_gpu_destroy.argtypes = [C.c_void_p]
+        L.modes_gpu_destroy.restype = None
+        L.modes_gpu_last_error.argtypes = [C.c_void_p]
+        L.modes_gpu_last_error.restype = C.c_char_p
+        L.modes_gpu_compute_magnitude.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.modes_gpu_compute_power.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.modes_gpu_detect.argtypes = [C.c_void_p, C.POINTER(Span), C.c_void_p]
+        L.modes_gpu_fetch.argtypes = [C.c_void_p, C.POINTER(GpuResult)]
+        L.modes_gpu_demod_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                           C.POINTER(GpuResult)]
+        L.modes_gpu_synth_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                            C.c_void_p]
+        L.modes_gpu_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint8, C.c_void_p]
+        _gpu = L
+    return _gpu
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise ModesError(-2, "%s is not built" % HOST_LIB)
+        L = C.CDLL(HOST_LIB)
+        L.modes_host_create.argtypes = [C.POINTER(HostConfig)]
+        L.modes_host_create.restype = C.c_void_p
+        L.modes_host_destroy.argtypes = [C.c_void_p]
+        L.modes_host_destroy.restype = None
+        L.modes_host_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, SINK_FN,
+                                         C.c_void_p]
+        L.modes_host_resolve.restype = C.c_uint64
+        L.modes_host_resolve_to_array.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                  C.POINTER(Emitted), C.c_uint64]
+        L.modes_host_resolve_to_array.restype = C.c_uint64
+        L.modes_host_wants.argtypes = [C.c_void_p, C.POINTER(ModesMessage)]
+        L.modes_host_get_stats.argtypes = [C.c_void_p, C.POINTER(HostStats)]
+        L.modes_host_get_stats.restype = None
+        L.modes_host_decode.argtypes = [C.c_void_p, C.POINTER(Attempt), C.POINTER(ModesMessage)]
+        L.modes_host_decode.restype = None
+        L.modes_format_raw.argtypes = [C.POINTER(ModesMessage), C.c_char_p]
+        L.modes_format_onlyaddr.argtypes = [C.POINTER(ModesMessage), C.c_char_p]
+        L.modes_format_stats.argtypes = [C.POINTER(HostStats), C.c_char_p]
+        L.modes_checksum.argtypes = [C.c_void_p, C.c_int]
+        L.modes_checksum.restype = C.c_uint32
+        L.modes_compute_crc.argtypes = [C.c_void_p, C.c_int]
+        L.modes_compute_crc.restype = C.c_uint32
+        L.modes_block_count.argtypes = [C.c_uint64]
+        L.modes_block_count.restype = C.c_uint64
+        _host = L
+    return _host

@@ -1,0 +1,184 @@
+// dump1090_amd - the C/C++ host of the reference's --ifile path on top of the two libraries:
+//
+//   read (--ifile <file>|-)  ->  libmodes_gfx950.so (scan + demod on the GPU, many buffers per call)
+//                            ->  libmodes_host.so   (in-order resolve, decodeModesMessage, sink)
+//                            ->  stdout (--raw / --onlyaddr / --stats)
+//
+// It keeps the reference's spellings and defaults for the flags of this path
+// (dump1090.c:2869-2897,2922; defaults :299-319) and processes EVERY buffer the reference's
+// reader publishes (the reference itself drops the last one most of the time: SURVEY.md 3.4).
+// Live radio, networking, interactive mode and the debug dumps are out of scope.
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <fcntl.h>
+#include <unistd.h>
+
+#include "../../include/modes_gfx950.h"
+#include "../../include/modes_host.h"
+
+namespace {
+
+struct Options {
+    std::string filename;
+    bool loop = false, raw = false, onlyaddr = false, stats = false;
+    int fix_errors = 1, check_crc = 1, aggressive = 0;
+    int device = 0;
+    uint64_t batch_blocks = 1024;          // 256 MiB of samples per GPU call
+};
+
+struct Sink {
+    const Options *opt;
+    modes_host *host;
+    std::string out;
+};
+
+void show_help() {
+    printf(
+        "--ifile <filename>       Read data from file (use '-' for stdin).\n"
+        "--loop                   With --ifile, read the same file in a loop.\n"
+        "--raw                    Show only messages hex values.\n"
+        "--no-fix                 Disable single-bits error correction using CRC.\n"
+        "--no-crc-check           Disable messages with broken CRC (discouraged).\n"
+        "--aggressive             More CPU for more messages (two bits fixes, ...).\n"
+        "--stats                  With --ifile print stats at exit. No other output.\n"
+        "--onlyaddr               Show only ICAO addresses (testing purposes).\n"
+        "--gpu <ordinal>          HIP device to run on (default: 0).\n"
+        "--batch-blocks <n>       256 KiB buffers per GPU call (default: 1024).\n"
+        "--help                   Show this help.\n");
+}
+
+// useModesMessage (dump1090.c:1802-1820) for the non-interactive, non-network case.
+void on_message(const struct modesMessage *mm, uint32_t, uint32_t, void *user) {
+    Sink *s = static_cast<Sink *>(user);
+    if (s->opt->stats || !modes_host_wants(s->host, mm)) return;
+    char line[64];
+    int n = s->opt->onlyaddr ? modes_format_onlyaddr(mm, line) : modes_format_raw(mm, line);
+    s->out.append(line, (size_t)n);
+}
+
+bool read_full(int fd, uint8_t *dst, size_t want, size_t *got) {
+    *got = 0;
+    while (*got < want) {
+        ssize_t n = read(fd, dst + *got, want - *got);
+        if (n < 0) { if (errno == EINTR) continue; return false; }
+        if (n == 0) break;
+        *got += (size_t)n;
+    }
+    return true;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    Options opt;
+    for (int j = 1; j < argc; j++) {
+        const bool more = j + 1 < argc;
+        const char *a = argv[j];
+        if (!strcmp(a, "--ifile") && more) opt.filename = argv[++j];
+        else if (!strcmp(a, "--loop")) opt.loop = true;
+        else if (!strcmp(a, "--no-fix")) opt.fix_errors = 0;
+        else if (!strcmp(a, "--no-crc-check")) opt.check_crc = 0;
+        else if (!strcmp(a, "--raw")) opt.raw = true;
+        else if (!strcmp(a, "--onlyaddr")) opt.onlyaddr = true;
+        else if (!strcmp(a, "--aggressive")) opt.aggressive++;
+        else if (!strcmp(a, "--stats")) opt.stats = true;
+        else if (!strcmp(a, "--gpu") && more) opt.device = atoi(argv[++j]);
+        else if (!strcmp(a, "--batch-blocks") && more) opt.batch_blocks = strtoull(argv[++j], nullptr, 10);
+        else if (!strcmp(a, "--help")) { show_help(); return 0; }
+        else {
+            fprintf(stderr, "Unknown or not enough arguments for option '%s'.\n\n", a);
+            show_help();
+            return 1;
+        }
+    }
+    if (opt.filename.empty()) {
+        fprintf(stderr, "dump1090_amd demodulates files only: give --ifile <file> (or '-').\n");
+        return 1;
+    }
+    if (!opt.raw && !opt.onlyaddr && !opt.stats) {
+        fprintf(stderr, "note: the verbose message dump is not implemented; printing --raw lines.\n");
+        opt.raw = true;
+    }
+    if (opt.batch_blocks == 0) opt.batch_blocks = 1;
+
+    int fd = 0;
+    if (opt.filename != "-" && (fd = open(opt.filename.c_str(), O_RDONLY)) == -1) {
+        perror("Opening data file");
+        return 1;
+    }
+
+    modes_gpu_config gcfg{};
+    gcfg.device = opt.device;
+    gcfg.fix_errors = opt.fix_errors;
+    gcfg.aggressive = opt.aggressive ? 1 : 0;
+    gcfg.keep_candidates = opt.stats ? 1 : 0;
+    modes_gpu *gpu = nullptr;
+    if (modes_gpu_create(&gcfg, &gpu) != MODES_OK) {
+        fprintf(stderr, "GPU init failed: %s\n", modes_gpu_last_error(nullptr));
+        return 1;
+    }
+    modes_host_config hcfg{opt.fix_errors, opt.aggressive ? 1 : 0, opt.check_crc, 0};
+    modes_host *host = modes_host_create(&hcfg);
+    Sink sink{&opt, host, {}};
+
+    // Batch b covers buffers [first, first+n): host bytes = 476-byte carry + n*262144 new bytes.
+    const size_t batch_bytes = (size_t)opt.batch_blocks * MODES_DATA_LEN;
+    std::vector<uint8_t> buf(MODES_CARRY_BYTES + batch_bytes);
+    uint64_t first_block = 0;
+    size_t carry = 0;                       // valid carry bytes at the front of buf (0 for the first batch)
+    bool eof = false;
+    int rc = 0;
+    while (!eof) {
+        size_t got = 0;
+        uint8_t *dst = buf.data() + carry;
+        if (!read_full(fd, dst, batch_bytes, &got)) { perror("read"); rc = 1; break; }
+        while (got < batch_bytes && opt.loop && fd != 0) {             // dump1090.c:488-494
+            if (lseek(fd, 0, SEEK_SET) == -1) break;
+            size_t more = 0;
+            if (!read_full(fd, dst + got, batch_bytes - got, &more)) { perror("read"); rc = 1; break; }
+            if (more == 0) break;                                      // empty file
+            got += more;
+        }
+        // The reader publishes one buffer per full 262144 bytes and one more at EOF
+        // (dump1090.c:484-510): a short batch ends the stream with floor(got/262144)+1 buffers.
+        uint64_t nblocks = got / MODES_DATA_LEN;
+        if (got < batch_bytes) { eof = true; nblocks += 1; }
+        const uint64_t byte0 = first_block * (uint64_t)MODES_DATA_LEN - carry;
+        modes_gpu_result res{};
+        if (modes_gpu_demod_host(gpu, buf.data(), carry + got, byte0, first_block, nblocks, &res) != MODES_OK) {
+            fprintf(stderr, "GPU demodulation failed: %s\n", modes_gpu_last_error(gpu));
+            rc = 1;
+            break;
+        }
+        modes_host_resolve(host, res.records, res.n_records, res.candidates, res.n_candidates, on_message, &sink);
+        if (!sink.out.empty()) {
+            fwrite(sink.out.data(), 1, sink.out.size(), stdout);
+            fflush(stdout);
+            sink.out.clear();
+        }
+        // carry the last 476 bytes into the next batch (dump1090.c:481)
+        if (!eof) {
+            memmove(buf.data(), buf.data() + carry + got - MODES_CARRY_BYTES, MODES_CARRY_BYTES);
+            carry = MODES_CARRY_BYTES;
+            first_block += nblocks;
+        }
+    }
+
+    if (rc == 0 && opt.stats) {                                        // dump1090.c:2993-3006
+        modes_host_stats st;
+        modes_host_get_stats(host, &st);
+        char text[512];
+        modes_format_stats(&st, text);
+        fputs(text, stdout);
+    }
+    modes_host_destroy(host);
+    modes_gpu_destroy(gpu);
+    if (fd > 0) close(fd);
+    return rc;
+}

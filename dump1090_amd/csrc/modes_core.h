@@ -1,0 +1,286 @@
+/* modes_core.h - arithmetic shared by the gfx950 kernels (modes_gfx950.hip) and
+ * the host resolve (modes_host.cpp).  Header-only, no HIP includes: every
+ * function is MODES_HD (= __host__ __device__ under hipcc, nothing under g++), so
+ * the exact code the kernels run can also be unit-tested on a CPU
+ * (tests/native/core_shim.cpp) - that shim is test scaffolding, not a fallback:
+ * the product's GPU entry points never route through host copies of these.
+ *
+ * Line numbers cite /root/reference/dump1090.c.
+ */
+#ifndef MODES_CORE_H
+#define MODES_CORE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MODES_HD  __host__ __device__ __forceinline__
+#define MODES_HDM __host__ __device__ __forceinline__      /* member functions */
+#else
+#define MODES_HD  static inline
+#define MODES_HDM inline
+#endif
+
+/* ------------------------------------------------------------------ CRC-24 */
+
+/* Mode S generator polynomial, x^24 + ... (the reference's table
+ * dump1090.c:683-698 is x^(111-i) mod this; tests/test_oracle.py). */
+#define MODES_CRC_POLY 0x1FFF409u
+
+/* modesMessageLenByType, dump1090.c:746-753. */
+MODES_HD int modes_len_by_df(int df) { return (df >= 16 && df <= 21) ? 112 : 56; }
+
+/* modesChecksum (dump1090.c:733-742): the table-XOR of the data bits XOR the
+ * received parity equals the remainder of the whole message (data + parity)
+ * modulo the generator, computed here bitwise, MSB first. */
+MODES_HD uint32_t modes_syndrome(const uint8_t *msg, int nbytes) {
+    uint32_t r = 0;
+    for (int b = 0; b < nbytes; b++) {
+        for (int t = 7; t >= 0; t--) {          /* plain (non-augmented) long division */
+            r = (r << 1) | ((uint32_t)(msg[b] >> t) & 1u);
+            if (r & 0x1000000u) r ^= MODES_CRC_POLY;
+        }
+    }
+    return r & 0xFFFFFFu;
+}
+
+/* Syndrome of a single flipped bit at frame position p of a 112-bit frame:
+ * x^(111-p) mod G.  A 56-bit message's bit k is frame position k+56
+ * (dump1090.c:874-880). */
+MODES_HD uint32_t modes_bit_syndrome(int p) {
+    uint32_t r = 1;
+    for (int e = 0; e < 111 - p; e++) {
+        r <<= 1;
+        if (r & 0x1000000u) r ^= MODES_CRC_POLY;
+    }
+    return r;
+}
+
+/* fixBitErrors' table lookup (dump1090.c:795-841 builds it, 854-880 queries it)
+ * without the table: the table holds the syndromes of all 1- and 2-bit error
+ * patterns over frame bits 5..111, all 5778 of them distinct, so "bsearch the
+ * syndrome, then require <= maxfix bits and every bit inside the message" is
+ * the same as searching only patterns that satisfy those two conditions.
+ * `esyn` = the 112 single-bit syndromes (modes_bit_syndrome).  Writes
+ * message-relative positions; returns the number of bits (0 = no repair). */
+MODES_HD int modes_find_fix(uint32_t syndrome, int bits, int maxfix, const uint32_t *esyn, uint8_t pos[2]) {
+    const int first = (bits == 112) ? 5 : 56;       /* frame bits usable by this length */
+    const int shift = 112 - bits;
+    pos[0] = pos[1] = 0xff;
+    if (maxfix < 1 || syndrome == 0) return 0;
+    for (int p = first; p < 112; p++)
+        if (esyn[p] == syndrome) { pos[0] = (uint8_t)(p - shift); return 1; }
+    if (maxfix < 2) return 0;
+    for (int p = first; p < 111; p++) {
+        uint32_t want = syndrome ^ esyn[p];
+        for (int q = p + 1; q < 112; q++)
+            if (esyn[q] == want) { pos[0] = (uint8_t)(p - shift); pos[1] = (uint8_t)(q - shift); return 2; }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------ magnitude / power */
+
+/* s = (I-127)^2 + (Q-127)^2, 0..32768.  The reference's magnitude
+ * (dump1090.c:1462-1467) is maglut[|I-127|*129 + |Q-127|] = round(360*sqrt(s)),
+ * a strictly increasing function of s, so >,<,== between samples can be decided
+ * on s. */
+MODES_HD uint32_t modes_power(uint32_t i_byte, uint32_t q_byte) {
+    int i = (int)i_byte - 127, q = (int)q_byte - 127;
+    return (uint32_t)(i * i + q * q);
+}
+MODES_HD uint32_t modes_lut_index(uint32_t i_byte, uint32_t q_byte) {
+    int i = (int)i_byte - 127, q = (int)q_byte - 127;
+    if (i < 0) i = -i;
+    if (q < 0) q = -q;
+    return (uint32_t)(i * 129 + q);
+}
+
+/* ---------------------------------------------------- preamble predicates */
+
+/* The full predicate of dump1090.c:1602-1650 on true magnitudes m[0..14]. */
+template <class M>
+MODES_HD bool modes_preamble_exact(const M &m) {
+    const int m0 = m(0), m1 = m(1), m2 = m(2), m3 = m(3), m4 = m(4), m5 = m(5), m6 = m(6), m7 = m(7),
+              m8 = m(8), m9 = m(9);
+    if (!(m0 > m1 && m1 < m2 && m2 > m3 && m3 < m0 && m4 < m0 && m5 < m0 && m6 < m0 && m7 > m8 && m8 < m9 &&
+          m9 > m6))
+        return false;
+    const int level = (m0 + m2 + m7 + m9) / 6;                               /* :1624 */
+    if (m4 >= level || m5 >= level) return false;                             /* :1625 */
+    return m(11) < level && m(12) < level && m(13) < level && m(14) < level;  /* :1639 */
+}
+
+/* ---- packed-u16 helpers: two samples per 32-bit register (v_pk_*_u16) ---- */
+#if defined(__clang__)   /* hipcc (device + host) and the clang-built test shim */
+
+typedef unsigned short modes_u16x2 __attribute__((ext_vector_type(2)));
+#define MODES_PK(x) __builtin_bit_cast(modes_u16x2, (uint32_t)(x))
+#define MODES_UN(x) __builtin_bit_cast(uint32_t, (modes_u16x2)(x))
+MODES_HD uint32_t pk_max(uint32_t a, uint32_t b) { return MODES_UN(__builtin_elementwise_max(MODES_PK(a), MODES_PK(b))); }
+MODES_HD uint32_t pk_min(uint32_t a, uint32_t b) { return MODES_UN(__builtin_elementwise_min(MODES_PK(a), MODES_PK(b))); }
+MODES_HD uint32_t pk_subs(uint32_t a, uint32_t b) { return MODES_UN(__builtin_elementwise_sub_sat(MODES_PK(a), MODES_PK(b))); }
+MODES_HD uint32_t pk_add(uint32_t a, uint32_t b) { return MODES_UN(MODES_PK(a) + MODES_PK(b)); }
+MODES_HD uint32_t pk_sub(uint32_t a, uint32_t b) { return MODES_UN(MODES_PK(a) - MODES_PK(b)); }
+MODES_HD uint32_t pk_mul(uint32_t a, uint32_t b) { return MODES_UN(MODES_PK(a) * MODES_PK(b)); }
+MODES_HD uint32_t pk_shr2(uint32_t a) { return MODES_UN(MODES_PK(a) >> (unsigned short)2); }
+MODES_HD uint32_t pk_shr1(uint32_t a) { return MODES_UN(MODES_PK(a) >> (unsigned short)1); }
+
+/* Four bytes I0 Q0 I1 Q1 (little-endian dword) -> packed (s0, s1). */
+MODES_HD uint32_t modes_power_pair(uint32_t w) {
+    const uint32_t k127 = 0x007F007Fu;
+    uint32_t ip = w & 0x00FF00FFu;              /* (I0, I1) - v_perm / v_and       */
+    uint32_t qp = (w >> 8) & 0x00FF00FFu;       /* (Q0, Q1)                        */
+    uint32_t ai = pk_sub(ip, k127), aq = pk_sub(qp, k127);   /* mod 2^16; squares are exact */
+    return pk_add(pk_mul(ai, ai), pk_mul(aq, aq));            /* v_pk_mul_lo + v_pk_mad      */
+}
+
+/* Scan of 8 consecutive preamble positions against a 24-sample window of
+ * powers.  E[t] = (s[2t], s[2t+1]) for window samples 0..23; position i
+ * (0..7) looks at window samples i..i+14.  Returns a mask with bit (i>>1) for
+ * even i and bit 16+(i>>1) for odd i set when position i MAY be a preamble:
+ *
+ *   - the ten ordering relations of dump1090.c:1602-1611, exactly (on s), as
+ *       s0 > max(s1,s3,s4,s5,s6), s2 > max(s1,s3), s7 > s8, s9 > max(s8,s6)
+ *   - a necessary condition for the level tests of dump1090.c:1624-1642:
+ *     a quiet sample x in {4,5,11..14} needs m_x < floor((m0+m2+m7+m9)/6) with
+ *     m = round(360 sqrt(s)), hence 360 sqrt(s_x) - 1/2 <= (360 SUM sqrt(s_k) + 2)/6 - 1,
+ *     i.e. sqrt(s_x) < SUM sqrt(s_k)/6 <= sqrt(SUM s_k)/3 (Cauchy-Schwarz), i.e.
+ *     9 s_x < SUM s_k.  With h = s >> 2 (so s <= 4h+3): 9 s_x < 4 SUM h + 12, which
+ *     implies s_x <= (SUM h + 4) >> 1.  That last form fits 16-bit packed math.
+ *
+ * Never rejects a position the reference accepts; the (few) false accepts are
+ * removed by modes_preamble_exact in the demod kernel.  ~90 VALU ops per call.
+ */
+MODES_HD uint32_t modes_scan8(const uint32_t E[12]) {
+    uint32_t O[11];                                   /* O[t] = (s[2t+1], s[2t+2])  */
+#pragma unroll
+    for (int t = 0; t < 11; t++) O[t] = (E[t] >> 16) | (E[t + 1] << 16);   /* v_alignbit */
+    uint32_t hit = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {                     /* positions i = 2q, 2q+1     */
+        /* X(k) = (s[i+k], s[i+1+k]) : even k -> E[q+k/2], odd k -> O[q+(k-1)/2]   */
+        const uint32_t x0 = E[q], x1 = O[q], x2 = E[q + 1], x3 = O[q + 1], x4 = E[q + 2], x5 = O[q + 2],
+                       x6 = E[q + 3], x7 = O[q + 3], x8 = E[q + 4], x9 = O[q + 4], x11 = O[q + 5],
+                       x12 = E[q + 6], x13 = O[q + 6], x14 = E[q + 7];
+        const uint32_t m13 = pk_max(x1, x3);
+        const uint32_t m45 = pk_max(x4, x5);
+        uint32_t r = pk_subs(x0, pk_max(pk_max(m13, m45), x6));      /* s0 > s1,s3,s4,s5,s6 */
+        r = pk_min(r, pk_subs(x2, m13));                             /* s2 > s1,s3          */
+        r = pk_min(r, pk_subs(x7, x8));                              /* s7 > s8             */
+        r = pk_min(r, pk_subs(x9, pk_max(x8, x6)));                  /* s9 > s8,s6          */
+        /* level bound */
+        const uint32_t sumh = pk_add(pk_add(pk_shr2(x0), pk_shr2(x2)), pk_add(pk_shr2(x7), pk_shr2(x9)));
+        const uint32_t lim1 = pk_shr1(pk_add(sumh, 0x00060006u));    /* ((sumh+4)>>1) + 1   */
+        const uint32_t quiet = pk_max(pk_max(m45, pk_max(x11, x12)), pk_max(x13, x14));
+        r = pk_min(r, pk_subs(lim1, quiet));                         /* quiet <= (sumh+4)>>1 */
+        hit |= pk_min(r, 0x00010001u) << q;
+    }
+    return hit;
+}
+/* position i of modes_scan8's mask */
+MODES_HD uint32_t modes_scan8_bit(int i) { return 1u << (((i & 1) << 4) + (i >> 1)); }
+#endif /* __clang__ */
+
+/* ----------------------------------------------------------- demodulation */
+
+/* Result of one demodulation attempt; same fields as modes_attempt. */
+struct modes_attempt_core {
+    uint8_t msg[14];
+    uint8_t errors;
+    uint8_t gate_ok;
+};
+
+/* scaleSample, dump1090.c:1473-1476. */
+MODES_HD uint32_t modes_scale(uint32_t v, uint32_t factor) {
+    uint32_t r = v * factor / 16384u;
+    return r > 65535u ? 65535u : r;
+}
+
+/* Bit slicing state machine of dump1090.c:1669-1689 fed one (lo, hi) pair at a
+ * time, packing as dump1090.c:1696-1706 does (a bit value of 2 is OR-ed in
+ * unmasked, then the byte is truncated to 8 bits). */
+struct modes_slicer {
+    uint32_t acc[14];
+    int prev;
+    int errors;
+    MODES_HDM void reset() {
+        for (int b = 0; b < 14; b++) acc[b] = 0;
+        prev = 0; errors = 0;
+    }
+    MODES_HDM void push(int k, int lo, int hi) {
+        int d = lo - hi;
+        if (d < 0) d = -d;
+        int bit;
+        if (k > 0 && d < 256) bit = prev;
+        else if (lo == hi) { bit = 2; if (k < 56) errors++; }
+        else bit = lo > hi;
+        prev = bit;
+        acc[k >> 3] |= (uint32_t)bit << (7 - (k & 7));
+    }
+    MODES_HDM void finish(uint8_t msg[14]) const {
+        for (int b = 0; b < 14; b++) msg[b] = (uint8_t)acc[b];
+    }
+};
+
+/* Both attempts at a preamble position.  `mag(t)` returns the reference's
+ * magnitude of the sample t places after the preamble start, t in [-1, 239]
+ * (t = -1 only when with_phase).  with_phase = (block-local j != 0),
+ * dump1090.c:1660.  The noise gate (dump1090.c:1713-1723) always uses the
+ * uncorrected samples but the message length of the attempt it gates. */
+template <class M>
+MODES_HD void modes_demod_both(const M &mag, bool with_phase, modes_attempt_core out[2]) {
+    modes_slicer sl;
+    int sum56 = 0, sum112 = 0;
+    /* attempt 0: samples as received */
+    sl.reset();
+    for (int k = 0; k < 112; k++) {
+        int lo = mag(16 + 2 * k), hi = mag(17 + 2 * k);
+        int d = lo > hi ? lo - hi : hi - lo;
+        sum112 += d;
+        if (k < 56) sum56 += d;
+        sl.push(k, lo, hi);
+    }
+    sl.finish(out[0].msg);
+    out[0].errors = (uint8_t)sl.errors;
+    out[0].gate_ok = modes_len_by_df(out[0].msg[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+    if (!out[0].gate_ok) { out[1] = out[0]; return; }     /* position ends here, dump1090.c:1723 */
+
+    /* attempt 1: applyPhaseCorrection, dump1090.c:1498-1558 */
+    if (!with_phase) { out[1] = out[0]; return; }
+    const uint32_t on_time = (uint32_t)mag(0) + mag(2) + mag(7) + mag(9);
+    const uint32_t early = ((uint32_t)mag(-1) + mag(6)) * 2u;
+    const uint32_t late = ((uint32_t)mag(3) + mag(10)) * 2u;
+    sl.reset();
+    if (early > late) {
+        /* Backward chain: the odd ("hi") sample of every pair is rescaled, starting
+         * from the last one; the factor for pair k-1 depends on the already rescaled
+         * pair k (lo_k > hi'_k ? down : up).  Record, per pair, what the slicer needs. */
+        const uint32_t x = 16384u * early / (early + on_time);
+        const uint32_t up = (16384u + x) & 0xFFFFu, dn = (16384u - x) & 0xFFFFu;
+        uint16_t hi2[112];
+        uint32_t h = modes_scale(mag(239), up);
+        hi2[111] = (uint16_t)h;
+        for (int k = 111; k >= 1; k--) {
+            uint32_t lo = mag(16 + 2 * k);
+            h = modes_scale(mag(15 + 2 * k), lo > h ? dn : up);
+            hi2[k - 1] = (uint16_t)h;
+        }
+        for (int k = 0; k < 112; k++) sl.push(k, mag(16 + 2 * k), hi2[k]);
+    } else {
+        /* Forward chain: the even ("lo") sample of every pair is rescaled; the factor
+         * for pair k+1 depends on the already rescaled pair k (lo'_k > hi_k ? up : down). */
+        const uint32_t x = 16384u * late / (late + on_time);
+        const uint32_t up = (16384u + x) & 0xFFFFu, dn = (16384u - x) & 0xFFFFu;
+        uint32_t l = modes_scale(mag(16), up);
+        for (int k = 0; k < 112; k++) {
+            uint32_t hi = mag(17 + 2 * k);
+            sl.push(k, (int)l, (int)hi);
+            if (k < 111) l = modes_scale(mag(18 + 2 * k), l > hi ? up : dn);
+        }
+    }
+    sl.finish(out[1].msg);
+    out[1].errors = (uint8_t)sl.errors;
+    out[1].gate_ok = modes_len_by_df(out[1].msg[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+}
+
+#endif /* MODES_CORE_H */

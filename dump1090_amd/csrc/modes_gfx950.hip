@@ -1,0 +1,786 @@
+// modes_gfx950.hip - gfx950 (MI355X / CDNA4) kernels and the C ABI of include/modes_gfx950.h.
+//
+// Data path (DESIGN.md has the full picture; line numbers cite /root/reference/dump1090.c):
+//
+//   u8 I/Q stream in HBM ──scan_kernel──► forwarded positions (per-run slots, u32)
+//        (2 B/sample, read once)              │
+//                                             ▼
+//                                  demod_kernel: exact preamble test (:1602-1650),
+//                                  bit slicing + noise gate (:1666-1726), phase-corrected
+//                                  retry (:1498-1558), syndrome + repair lookup (:733,:854)
+//                                             │
+//                                             ▼  64-byte modes_record list ──► host resolve
+//
+// scan_kernel is the only stage that touches every sample; it never materialises
+// magnitudes.  Each lane turns 16 bytes (8 I/Q pairs) into 8 packed-u16 powers
+// s = (I-127)^2+(Q-127)^2, shares them with its wavefront through a wave-private
+// 2 KiB LDS ring (no workgroup barrier anywhere), reads back a 24-sample window and
+// evaluates 8 preamble positions with v_pk_*_u16 arithmetic (modes_scan8).  Because
+// the reference's magnitude LUT is strictly monotone in s, the ten ordering tests
+// are exact on s; the six level tests are replaced by a necessary condition in s and
+// re-checked exactly (LUT) by demod_kernel on the ~0.1 % of positions forwarded.
+//
+// No MFMA (integer scan, HBM-bound), no CUDA compatibility layer, wave64 only.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/modes_gfx950.h"
+#include "modes_core.h"
+
+static_assert(sizeof(modes_attempt) == 28, "modes_attempt layout");
+static_assert(sizeof(modes_record) == 64, "modes_record layout");
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kChunkSamples = 512;          // one wavefront iteration: 64 lanes x 8 samples
+constexpr int kChunkBytes = 1024;
+constexpr int kScanWaves = 4;               // wavefronts per scan workgroup
+constexpr int kLookback = 16;               // positions of the previous chunk scanned with this one
+
+// ------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------
+
+struct DeviceTables {
+    const uint16_t *lut;     // 129*129 magnitudes, dump1090.c:359-364 (built on the host in double)
+    const uint32_t *esyn;    // 112 single-bit syndromes
+};
+
+// 16 stream bytes at byte offset `off` (may be negative / past the end: 127 there,
+// which is what the reference pads with, dump1090.c:344,506).
+// Slow path of load_iq16: byte-wise with bounds checks.  Out of line so the streaming
+// loop's code stays small; taken only by lanes that straddle the ends of the span.
+__device__ __attribute__((noinline)) uint4 load_iq16_edge(const uint8_t *iq, int64_t off, int64_t lo, int64_t hi) {
+    uint32_t w[4];
+    for (int d = 0; d < 4; d++) {
+        uint32_t v = 0;
+        for (int b = 0; b < 4; b++) {
+            int64_t o = off + 4 * d + b;
+            uint32_t byte = (o >= lo && o < hi) ? iq[o] : 127u;
+            v |= byte << (8 * b);
+        }
+        w[d] = v;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// `iq` is 16-byte aligned; the valid bytes are [lo, hi) relative to it.
+__device__ __forceinline__ uint4 load_iq16(const uint8_t *iq, int64_t off, int64_t lo, int64_t hi) {
+    if (off >= lo && off + 16 <= hi) return *reinterpret_cast<const uint4 *>(iq + off);
+    return load_iq16_edge(iq, off, lo, hi);
+}
+
+__device__ __forceinline__ uint4 power16(uint4 v) {
+    return make_uint4(modes_power_pair(v.x), modes_power_pair(v.y), modes_power_pair(v.z), modes_power_pair(v.w));
+}
+
+// Reference magnitude of buffer sample q (0 outside the stream).
+struct MagAt {
+    const uint8_t *iq;
+    int64_t lo, hi;
+    const uint16_t *lut;
+    int64_t p;
+    __device__ __forceinline__ int operator()(int t) const {
+        int64_t o = 2 * (p + t);
+        if (o < lo || o >= hi) return 0;
+        uint32_t ib = iq[o];
+        uint32_t qb = (o + 1 < hi) ? iq[o + 1] : 127u;
+        return lut[modes_lut_index(ib, qb)];
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// K1 (parity of computeMagnitudeVector, dump1090.c:1454-1469): u8 I/Q -> u16 magnitude.
+// LUT staged in LDS; 8 samples per lane per iteration (16 B in, 16 B out).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void magnitude_kernel(const uint8_t *__restrict__ iq, uint64_t nsamples,
+                                                        const uint16_t *__restrict__ lut, uint16_t *__restrict__ mag) {
+    __shared__ uint16_t s_lut[129 * 129 + 1];
+    for (int i = threadIdx.x; i < 129 * 129; i += blockDim.x) s_lut[i] = lut[i];
+    __syncthreads();
+    const uint64_t ngroups = (nsamples + 7) / 8;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 v = load_iq16(iq, (int64_t)(g * 16), 0, (int64_t)(nsamples * 2));
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint16_t m[8];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            m[2 * d] = s_lut[modes_lut_index(w[d] & 0xff, (w[d] >> 8) & 0xff)];
+            m[2 * d + 1] = s_lut[modes_lut_index((w[d] >> 16) & 0xff, w[d] >> 24)];
+        }
+        if (g * 8 + 8 <= nsamples) {
+            uint4 o = make_uint4(m[0] | (uint32_t)m[1] << 16, m[2] | (uint32_t)m[3] << 16, m[4] | (uint32_t)m[5] << 16,
+                                 m[6] | (uint32_t)m[7] << 16);
+            *reinterpret_cast<uint4 *>(mag + g * 8) = o;
+        } else {
+            for (int t = 0; t < 8 && g * 8 + t < nsamples; t++) mag[g * 8 + t] = m[t];
+        }
+    }
+}
+
+// Debug tap: the powers the scan kernel works on.
+__global__ __launch_bounds__(256) void power_kernel(const uint8_t *__restrict__ iq, uint64_t nsamples,
+                                                    uint16_t *__restrict__ out) {
+    const uint64_t ngroups = (nsamples + 7) / 8;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 s = power16(load_iq16(iq, (int64_t)(g * 16), 0, (int64_t)(nsamples * 2)));
+        uint32_t w[4] = {s.x, s.y, s.z, s.w};
+        for (int t = 0; t < 8 && g * 8 + t < nsamples; t++) out[g * 8 + t] = (uint16_t)(w[t >> 1] >> (16 * (t & 1)));
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// scan_kernel - the HBM-bound stage.
+//
+// Work decomposition: chunk c = buffer samples [512c, 512c+512) = 1 KiB = one coalesced
+// 16 B/lane load per wavefront.  A *run* is `run_chunks` consecutive chunks owned by ONE
+// wavefront; iteration c scans positions [512c-16, 512c+496) (their 15-sample windows
+// end inside chunk c), so a run scans [512*c0-16, 512*c1-16) and needs, besides its own
+// chunks, only the last 32 bytes of chunk c0-1.  Runs are independent: no inter-wave
+// synchronisation, no atomics; forwarded positions go to the run's private slot list in
+// ascending order, so the concatenation over runs is already sorted.
+// ------------------------------------------------------------------------------------
+struct ScanParams {
+    const uint8_t *iq;    // 16-byte aligned base
+    int64_t lo, hi;       // valid bytes [lo, hi) relative to iq (lo < 16: alignment slack)
+    uint64_t g0;          // framed coordinate of buffer sample 0
+    int64_t p_begin;      // positions [p_begin, p_end) are tested
+    int64_t p_end;
+    uint32_t nchunks;
+    uint32_t run_chunks;
+    uint32_t nruns;
+    uint32_t slot_cap;
+    uint32_t *slots;      // [nruns][slot_cap]
+    uint32_t *counts;     // [nruns]  (true count, may exceed slot_cap -> overflow flag)
+    uint32_t *flags;      // [0] = some run overflowed its slots
+};
+
+__global__ __launch_bounds__(kScanWaves * kWave) void scan_kernel(ScanParams P) {
+    // wave-private ring: 2 chunk slots x 256 dwords (512 powers each)
+    __shared__ __attribute__((aligned(16))) uint32_t ring_all[kScanWaves][512];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t run = blockIdx.x * kScanWaves + wave;
+    if (run >= P.nruns) return;
+    uint32_t *ring = ring_all[wave];
+
+    const int64_t c0 = (int64_t)run * P.run_chunks;
+    const int64_t c1 = (c0 + (int64_t)P.run_chunks < (int64_t)P.nchunks) ? c0 + (int64_t)P.run_chunks : (int64_t)P.nchunks;
+    const uint8_t *iq = P.iq;
+    const int64_t lo = P.lo, hi = P.hi;
+
+    // prologue: powers of the last 16 samples of chunk c0-1 (lanes 62, 63)
+    if (lane >= 62) {
+        uint4 s = power16(load_iq16(iq, (c0 - 1) * kChunkBytes + lane * 16, lo, hi));
+        *reinterpret_cast<uint4 *>(&ring[(((c0 - 1) & 1) * 256) + lane * 4]) = s;
+    }
+    // software prefetch, two chunks deep
+    uint4 cur = load_iq16(iq, c0 * kChunkBytes + lane * 16, lo, hi);
+    uint4 nxt = load_iq16(iq, (c0 + 1) * kChunkBytes + lane * 16, lo, hi);
+
+    uint32_t count = 0;
+    uint32_t *my_slots = P.slots + (uint64_t)run * P.slot_cap;
+
+    for (int64_t c = c0; c < c1; c++) {
+        const uint4 raw = cur;
+        cur = nxt;
+        nxt = load_iq16(iq, (c + 2) * kChunkBytes + lane * 16, lo, hi);
+
+        const uint4 s = power16(raw);
+        *reinterpret_cast<uint4 *>(&ring[((c & 1) * 256) + lane * 4]) = s;
+        // LDS operations of one wavefront execute in issue order: the reads below see the
+        // writes above without a barrier; only the compiler must not reorder them.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // window of 24 powers starting at position 512c - 16 + 8*lane (dword index mod 512)
+        const uint32_t d0 = (uint32_t)(((c & 1) * 256) + 512 - 8 + lane * 4) & 511u;
+        uint32_t E[12];
+        {
+            const uint4 a = *reinterpret_cast<const uint4 *>(&ring[d0]);
+            const uint4 b = *reinterpret_cast<const uint4 *>(&ring[(d0 + 4) & 511u]);
+            const uint4 d = *reinterpret_cast<const uint4 *>(&ring[(d0 + 8) & 511u]);
+            E[0] = a.x; E[1] = a.y; E[2] = a.z; E[3] = a.w;
+            E[4] = b.x; E[5] = b.y; E[6] = b.z; E[7] = b.w;
+            E[8] = d.x; E[9] = d.y; E[10] = d.z; E[11] = d.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        const uint32_t hit = modes_scan8(E);
+
+        // wavefront compaction, ascending position order
+        uint64_t lanes_hit = __ballot(hit != 0);
+        const int64_t pbase = c * kChunkSamples - kLookback;
+        while (lanes_hit) {
+            const int L = __builtin_ctzll(lanes_hit);
+            lanes_hit &= lanes_hit - 1;
+            const uint32_t m = __builtin_amdgcn_readlane(hit, L);
+            const int64_t p = pbase + 8 * L + lane;               // lanes 0..7 look at one position each
+            bool has = false;
+            if (lane < 8) {
+                has = (m & modes_scan8_bit(lane)) != 0 && p >= P.p_begin && p < P.p_end &&
+                      (((uint64_t)p + P.g0) & (MODES_BLOCK_STRIDE - 1)) < MODES_BLOCK_POSITIONS;   // j < 131070, :1593
+            }
+            const uint64_t hb = __ballot(has);
+            if (has) {
+                const uint32_t idx = count + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1));
+                if (idx < P.slot_cap) my_slots[idx] = (uint32_t)p;
+            }
+            count += (uint32_t)__builtin_popcountll(hb);
+        }
+    }
+    if (lane == 0) {
+        P.counts[run] = count;
+        if (count > P.slot_cap) atomicOr(&P.flags[0], 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// demod_kernel - one wavefront per run, one lane per forwarded position.
+// ------------------------------------------------------------------------------------
+struct DemodParams {
+    const uint8_t *iq;
+    int64_t lo, hi;
+    uint64_t g0;
+    uint32_t nruns;
+    uint32_t slot_cap;
+    const uint32_t *slots;
+    const uint32_t *counts;
+    DeviceTables tab;
+    int maxfix;                // 0 = --no-fix, 1 = default, 2 = --aggressive   (dump1090.c:1115)
+    uint32_t *cand_slots;      // [nruns][slot_cap] or nullptr
+    uint32_t *cand_counts;     // [nruns]
+    modes_record *records;
+    uint32_t *rec_counter;
+    uint32_t max_records;
+};
+
+__device__ __forceinline__ void finish_attempt(const modes_attempt_core &a, int maxfix, const uint32_t *esyn,
+                                               modes_attempt *out) {
+#pragma unroll
+    for (int b = 0; b < 14; b++) out->msg[b] = a.msg[b];
+    out->errors = a.errors;
+    out->gate_ok = a.gate_ok;
+    out->nfix = 0;
+    out->fixpos[0] = out->fixpos[1] = 0xff;
+#pragma unroll
+    for (int b = 0; b < 5; b++) out->pad[b] = 0;
+    out->syndrome = 0;
+    if (!a.gate_ok) return;
+    const int df = a.msg[0] >> 3;
+    const int bits = modes_len_by_df(df);
+    const uint32_t syn = modes_syndrome(a.msg, bits / 8);                    // modesChecksum, :1104
+    out->syndrome = syn;
+    if (syn != 0 && maxfix > 0 && (df == 11 || df == 17 || df == 18))        // :1112-1117
+        out->nfix = (uint8_t)modes_find_fix(syn, bits, maxfix, esyn, out->fixpos);
+}
+
+__global__ __launch_bounds__(256) void demod_kernel(DemodParams P) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t run = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (run >= P.nruns) return;
+    const uint32_t n = min(P.counts[run], P.slot_cap);
+    const uint32_t *my = P.slots + (uint64_t)run * P.slot_cap;
+    uint32_t ncand = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t e = base + lane;
+        const bool active = e < n;
+        const uint32_t p = active ? my[e] : 0u;
+        MagAt mag{P.iq, P.lo, P.hi, P.tab.lut, (int64_t)p};
+        const bool ok = active && modes_preamble_exact(mag);
+        const uint64_t okb = __ballot(ok);
+        if (ok && P.cand_slots)
+            P.cand_slots[(uint64_t)run * P.slot_cap + ncand + (uint32_t)__builtin_popcountll(okb & ((1ull << lane) - 1))] = p;
+        ncand += (uint32_t)__builtin_popcountll(okb);
+        if (ok) {
+            const uint64_t g = (uint64_t)p + P.g0;
+            const uint32_t j = (uint32_t)(g & (MODES_BLOCK_STRIDE - 1));
+            modes_attempt_core a[2];
+            modes_demod_both(mag, j != 0, a);
+            if (a[0].gate_ok) {
+                const uint32_t idx = atomicAdd(P.rec_counter, 1u);
+                if (idx < P.max_records) {
+                    modes_record rec;
+                    rec.block = (uint32_t)(g / MODES_BLOCK_STRIDE);
+                    rec.j = j;
+                    finish_attempt(a[0], P.maxfix, P.tab.esyn, &rec.att[0]);
+                    finish_attempt(a[1], P.maxfix, P.tab.esyn, &rec.att[1]);
+                    P.records[idx] = rec;
+                }
+            }
+        }
+    }
+    if (lane == 0) P.cand_counts[run] = ncand;
+}
+
+// ------------------------------------------------------------------------------------
+// finalize_kernel - one workgroup: totals + exclusive prefix of the per-run preamble
+// counts (for compaction of the candidate list when the host asked for it).
+// ------------------------------------------------------------------------------------
+struct ResultHeader {
+    uint64_t n_forwarded;
+    uint64_t n_preambles;
+    uint32_t n_records;
+    uint32_t overflow;
+};
+
+__global__ __launch_bounds__(1024) void finalize_kernel(const uint32_t *counts, const uint32_t *cand_counts, uint32_t nruns,
+                                                        const uint32_t *rec_counter, const uint32_t *flags,
+                                                        uint64_t *cand_offsets, ResultHeader *hdr) {
+    __shared__ uint64_t part_f[1024];
+    __shared__ uint64_t part_c[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nruns + 1023) / 1024;
+    const uint32_t lo = min(t * per, nruns), hi = min(lo + per, nruns);
+    uint64_t f = 0, c = 0;
+    for (uint32_t r = lo; r < hi; r++) { f += counts[r]; c += cand_counts[r]; }
+    part_f[t] = f;
+    part_c[t] = c;
+    __syncthreads();
+    for (uint32_t step = 1; step < 1024; step <<= 1) {       // Hillis-Steele inclusive scan
+        uint64_t af = 0, ac = 0;
+        if (t >= step) { af = part_f[t - step]; ac = part_c[t - step]; }
+        __syncthreads();
+        part_f[t] += af;
+        part_c[t] += ac;
+        __syncthreads();
+    }
+    if (cand_offsets) {
+        uint64_t off = part_c[t] - c;                        // exclusive prefix of this thread's first run
+        for (uint32_t r = lo; r < hi; r++) { cand_offsets[r] = off; off += cand_counts[r]; }
+    }
+    if (t == 1023) {
+        hdr->n_forwarded = part_f[1023];
+        hdr->n_preambles = part_c[1023];
+        hdr->n_records = *rec_counter;
+        hdr->overflow = flags[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_candidates_kernel(const uint32_t *cand_slots, const uint32_t *cand_counts,
+                                                                 const uint64_t *cand_offsets, uint32_t nruns,
+                                                                 uint32_t slot_cap, uint64_t g0, uint64_t *out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t run = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (run >= nruns) return;
+    const uint32_t n = cand_counts[run];
+    const uint64_t off = cand_offsets[run];
+    for (uint32_t e = lane; e < n; e += 64) out[off + e] = (uint64_t)cand_slots[(uint64_t)run * slot_cap + e] + g0;
+}
+
+// ------------------------------------------------------------------------------------
+// synthetic input (tests/synth.py:noise_bytes, integer for integer)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_noise_kernel(uint8_t *out, uint64_t first_byte, uint64_t nbytes, uint64_t seed,
+                                                          uint32_t sigma_q16) {
+    const uint64_t ngroups = (nbytes + 15) / 16;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            const uint64_t idx = first_byte + g * 16 + b;
+            const uint64_t h = mix64(seed + idx * 0x9E3779B97F4A7C15ull);
+            // sum of the 8 bytes of h
+            uint64_t t = (h & 0x00FF00FF00FF00FFull) + ((h >> 8) & 0x00FF00FF00FF00FFull);
+            t = (t & 0x0000FFFF0000FFFFull) + ((t >> 16) & 0x0000FFFF0000FFFFull);
+            const int32_t gsum = (int32_t)((t & 0xFFFFFFFFull) + (t >> 32));
+            int32_t v = 127 + (((gsum - 1020) * (int32_t)sigma_q16 + 58982) >> 16);
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            w[b >> 2] |= (uint32_t)v << (8 * (b & 3));
+        }
+        if (g * 16 + 16 <= nbytes) {
+            *reinterpret_cast<uint4 *>(out + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int b = 0; b < 16 && g * 16 + b < nbytes; b++) out[g * 16 + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(uint8_t *out, uint64_t nbytes, uint8_t value) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = value;
+}
+
+}  // namespace
+
+// ======================================================================================
+// host side of the ABI
+// ======================================================================================
+
+struct modes_gpu {
+    modes_gpu_config cfg{};
+    int maxfix = 1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    std::string err;
+
+    uint16_t *d_lut = nullptr;
+    uint32_t *d_esyn = nullptr;
+
+    // per-detect scratch (grown on demand)
+    uint32_t *d_slots = nullptr;      size_t slots_bytes = 0;
+    uint32_t *d_cand_slots = nullptr; size_t cand_slots_bytes = 0;
+    uint32_t *d_counts = nullptr;     size_t counts_elems = 0;       // counts | cand_counts
+    uint64_t *d_cand_offsets = nullptr;
+    uint64_t *d_cand_dense = nullptr; size_t cand_dense_elems = 0;
+    modes_record *d_records = nullptr;
+    uint32_t *d_small = nullptr;      // [0] rec_counter, [1] flags
+    ResultHeader *d_hdr = nullptr;
+
+    ResultHeader *h_hdr = nullptr;    // pinned
+    modes_record *h_records = nullptr;  // pinned, max_records
+    std::vector<uint64_t> h_cands;
+
+    uint8_t *d_stage = nullptr;       size_t stage_bytes = 0;
+
+    // geometry of the detect in flight
+    bool in_flight = false;
+    uint32_t nruns = 0, slot_cap = 0;
+    uint64_t g0 = 0;
+};
+
+static std::string g_create_error;
+
+static int fail(modes_gpu *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                               \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) return fail(ctx, MODES_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));  \
+    } while (0)
+
+template <class T>
+static int grow(modes_gpu *ctx, T **ptr, size_t *have, size_t want_bytes) {
+    if (*have >= want_bytes && *ptr) return MODES_OK;
+    if (*ptr) { (void)hipFree(*ptr); *ptr = nullptr; *have = 0; }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(ptr), want_bytes);
+    if (e != hipSuccess) return fail(ctx, MODES_ERR_NOMEM, "hipMalloc(%zu): %s", want_bytes, hipGetErrorString(e));
+    *have = want_bytes;
+    return MODES_OK;
+}
+
+static int grid_for(uint64_t items, int per_block) {
+    uint64_t b = (items + per_block - 1) / per_block;
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>(b, 256 * 8));
+}
+
+extern "C" {
+
+int modes_gpu_abi_version(void) { return MODES_GFX950_ABI; }
+
+const char *modes_gpu_last_error(const modes_gpu *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
+    if (!cfg || !out) return fail(nullptr, MODES_ERR_ARG, "modes_gpu_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, MODES_ERR_HIP, "no HIP device: libmodes_gfx950 has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, MODES_ERR_ARG, "device %d of %d", cfg->device, ndev);
+    modes_gpu *ctx = new (std::nothrow) modes_gpu;
+    if (!ctx) return fail(nullptr, MODES_ERR_NOMEM, "out of memory");
+    ctx->cfg = *cfg;
+    if (ctx->cfg.max_records == 0) ctx->cfg.max_records = 1u << 20;
+    ctx->maxfix = cfg->fix_errors ? (cfg->aggressive ? 2 : 1) : 0;
+    auto bail = [&](int rc) { g_create_error = ctx->err; modes_gpu_destroy(ctx); return rc; };
+#define CREATE_TRY(call)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) { fail(ctx, MODES_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); return bail(MODES_ERR_HIP); } \
+    } while (0)
+    CREATE_TRY(hipSetDevice(cfg->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    for (auto &e : ctx->ev) CREATE_TRY(hipEventCreate(&e));
+    // tables: the magnitude LUT exactly as the reference builds it (dump1090.c:359-364, double
+    // arithmetic on the host) and the 112 single-bit syndromes.
+    std::vector<uint16_t> lut(129 * 129);
+    for (int i = 0; i <= 128; i++)
+        for (int q = 0; q <= 128; q++) lut[i * 129 + q] = (uint16_t)std::round(std::sqrt((double)(i * i + q * q)) * 360.0);
+    uint32_t esyn[112];
+    for (int p = 0; p < 112; p++) esyn[p] = modes_bit_syndrome(p);
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_lut), lut.size() * 2));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_esyn), sizeof esyn));
+    CREATE_TRY(hipMemcpy(ctx->d_lut, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(ctx->d_esyn, esyn, sizeof esyn, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_records), (size_t)ctx->cfg.max_records * sizeof(modes_record)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_small), 16));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hdr), sizeof(ResultHeader)));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hdr), sizeof(ResultHeader), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_records), (size_t)ctx->cfg.max_records * sizeof(modes_record),
+                             hipHostMallocDefault));
+#undef CREATE_TRY
+    *out = ctx;
+    return MODES_OK;
+}
+
+void modes_gpu_destroy(modes_gpu *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    void *dev[] = {ctx->d_lut, ctx->d_esyn, ctx->d_slots, ctx->d_cand_slots, ctx->d_counts, ctx->d_cand_offsets,
+                   ctx->d_cand_dense, ctx->d_records, ctx->d_small, ctx->d_hdr, ctx->d_stage};
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    if (ctx->h_hdr) (void)hipHostFree(ctx->h_hdr);
+    if (ctx->h_records) (void)hipHostFree(ctx->h_records);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+static hipStream_t pick_stream(modes_gpu *ctx, void *stream) { return stream ? static_cast<hipStream_t>(stream) : ctx->own_stream; }
+
+int modes_gpu_compute_magnitude(modes_gpu *ctx, const void *d_iq, uint64_t nsamples, void *d_mag, void *stream) {
+    if (!ctx) return MODES_ERR_ARG;
+    if (!d_iq || !d_mag) return fail(ctx, MODES_ERR_ARG, "compute_magnitude: null pointer");
+    if (nsamples == 0) return MODES_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    hipLaunchKernelGGL(magnitude_kernel, dim3(grid_for((nsamples + 7) / 8, 256)), dim3(256), 0, pick_stream(ctx, stream),
+                       static_cast<const uint8_t *>(d_iq), nsamples, ctx->d_lut, static_cast<uint16_t *>(d_mag));
+    HIP_TRY(ctx, hipGetLastError());
+    return MODES_OK;
+}
+
+int modes_gpu_compute_power(modes_gpu *ctx, const void *d_iq, uint64_t nsamples, void *d_s, void *stream) {
+    if (!ctx) return MODES_ERR_ARG;
+    if (!d_iq || !d_s) return fail(ctx, MODES_ERR_ARG, "compute_power: null pointer");
+    if (nsamples == 0) return MODES_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    hipLaunchKernelGGL(power_kernel, dim3(grid_for((nsamples + 7) / 8, 256)), dim3(256), 0, pick_stream(ctx, stream),
+                       static_cast<const uint8_t *>(d_iq), nsamples, static_cast<uint16_t *>(d_s));
+    HIP_TRY(ctx, hipGetLastError());
+    return MODES_OK;
+}
+
+int modes_gpu_synth_noise(modes_gpu *ctx, void *d_out, uint64_t first_byte, uint64_t nbytes, uint64_t seed,
+                          uint32_t sigma_q16, void *stream) {
+    if (!ctx) return MODES_ERR_ARG;
+    if (!d_out) return fail(ctx, MODES_ERR_ARG, "synth_noise: null pointer");
+    if (nbytes == 0) return MODES_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    hipLaunchKernelGGL(synth_noise_kernel, dim3(grid_for((nbytes + 15) / 16, 256)), dim3(256), 0, pick_stream(ctx, stream),
+                       static_cast<uint8_t *>(d_out), first_byte, nbytes, seed, sigma_q16);
+    HIP_TRY(ctx, hipGetLastError());
+    return MODES_OK;
+}
+
+int modes_gpu_fill(modes_gpu *ctx, void *d_out, uint64_t nbytes, uint8_t value, void *stream) {
+    if (!ctx) return MODES_ERR_ARG;
+    if (!d_out) return fail(ctx, MODES_ERR_ARG, "fill: null pointer");
+    if (nbytes == 0) return MODES_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(nbytes, 256)), dim3(256), 0, pick_stream(ctx, stream),
+                       static_cast<uint8_t *>(d_out), nbytes, value);
+    HIP_TRY(ctx, hipGetLastError());
+    return MODES_OK;
+}
+
+int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
+    if (!ctx) return MODES_ERR_ARG;
+    if (!span || !span->iq) return fail(ctx, MODES_ERR_ARG, "detect: null span");
+    if (span->nblocks == 0) return fail(ctx, MODES_ERR_ARG, "detect: nblocks == 0");
+    if ((reinterpret_cast<uintptr_t>(span->iq) & 1) != 0) return fail(ctx, MODES_ERR_ARG, "detect: iq must be 2-byte aligned");
+    if (span->stream_byte0 & 1) return fail(ctx, MODES_ERR_ARG, "detect: stream_byte0 must be even");
+    if (span->nbytes > (1ull << 33)) return fail(ctx, MODES_ERR_ARG, "detect: at most 8 GiB per call");
+    // buffer `first_block` starts 476 bytes before stream byte 262144*first_block: the span must
+    // reach back that far (or start at the beginning of the stream, where the carry is 127s).
+    const uint64_t need0 = span->first_block * (uint64_t)MODES_DATA_LEN;
+    const uint64_t carry0 = need0 >= MODES_CARRY_BYTES ? need0 - MODES_CARRY_BYTES : 0;
+    if (span->stream_byte0 > carry0)
+        return fail(ctx, MODES_ERR_ARG, "detect: span starts at stream byte %llu, buffer %llu needs bytes from %llu",
+                    (unsigned long long)span->stream_byte0, (unsigned long long)span->first_block, (unsigned long long)carry0);
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    hipStream_t st = pick_stream(ctx, stream);
+
+    // The kernels address the stream from a 16-byte aligned base; a span that starts inside a
+    // 16-byte line (e.g. a 476-byte carry cut out of a bigger device buffer) gets `mis` bytes of
+    // slack in front, which read as "outside the span".
+    const uint64_t mis = reinterpret_cast<uintptr_t>(span->iq) & 15;
+    const uint8_t *base = static_cast<const uint8_t *>(span->iq) - mis;
+    const int64_t byte_lo = (int64_t)mis, byte_hi = (int64_t)(mis + span->nbytes);
+
+    // framed coordinates: g = 131072*k + j;  base sample p  <->  g = p + g0
+    const uint64_t g0 = span->stream_byte0 / 2 + MODES_CARRY_SAMPLES - mis / 2;
+    const uint64_t g_begin = span->first_block * (uint64_t)MODES_BLOCK_STRIDE;
+    const uint64_t g_end = (span->first_block + span->nblocks) * (uint64_t)MODES_BLOCK_STRIDE;
+    // positions before the span or past its last sample have magnitude 0 at m[0] and can never
+    // satisfy m[0] > m[1] (dump1090.c:1602), so only samples inside the span need scanning.
+    int64_t p_begin = (int64_t)g_begin - (int64_t)g0;
+    int64_t p_end = (int64_t)g_end - (int64_t)g0;
+    if (p_begin < byte_lo / 2) p_begin = byte_lo / 2;
+    if (p_end > (byte_hi + 1) / 2) p_end = (byte_hi + 1) / 2;
+    if (p_end < p_begin) p_end = p_begin;
+
+    const uint64_t nchunks = (uint64_t)(p_end + kLookback + kChunkSamples - 1) / kChunkSamples;
+    uint32_t R = ctx->cfg.run_chunks;
+    if (R == 0) R = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(64, nchunks / 8192));
+    const uint32_t nruns = (uint32_t)std::max<uint64_t>(1, (nchunks + R - 1) / R);
+    uint32_t cap = ctx->cfg.slot_cap;
+    if (cap == 0) cap = std::max<uint32_t>(64, R * 32);        // 1/16 of the run's positions
+    if (cap > R * (uint32_t)kChunkSamples) cap = R * kChunkSamples;
+
+    int rc;
+    size_t want = (size_t)nruns * cap * sizeof(uint32_t);
+    if ((rc = grow(ctx, &ctx->d_slots, &ctx->slots_bytes, want)) != MODES_OK) return rc;
+    if (ctx->cfg.keep_candidates && (rc = grow(ctx, &ctx->d_cand_slots, &ctx->cand_slots_bytes, want)) != MODES_OK) return rc;
+    if (ctx->counts_elems < nruns) {
+        if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+        if (ctx->d_cand_offsets) (void)hipFree(ctx->d_cand_offsets);
+        ctx->d_counts = nullptr; ctx->d_cand_offsets = nullptr; ctx->counts_elems = 0;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_counts), (size_t)nruns * 2 * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_cand_offsets), (size_t)nruns * sizeof(uint64_t)));
+        ctx->counts_elems = nruns;
+    }
+    uint32_t *d_counts = ctx->d_counts, *d_cand_counts = ctx->d_counts + nruns;
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_small, 0, 16, st));
+
+    ScanParams sp{};
+    sp.iq = base;
+    sp.lo = byte_lo;
+    sp.hi = byte_hi;
+    sp.g0 = g0;
+    sp.p_begin = p_begin;
+    sp.p_end = p_end;
+    sp.nchunks = (uint32_t)nchunks;
+    sp.run_chunks = R;
+    sp.nruns = nruns;
+    sp.slot_cap = cap;
+    sp.slots = ctx->d_slots;
+    sp.counts = d_counts;
+    sp.flags = ctx->d_small + 1;
+
+    DemodParams dp{};
+    dp.iq = sp.iq;
+    dp.lo = sp.lo;
+    dp.hi = sp.hi;
+    dp.g0 = g0;
+    dp.nruns = nruns;
+    dp.slot_cap = cap;
+    dp.slots = ctx->d_slots;
+    dp.counts = d_counts;
+    dp.tab = DeviceTables{ctx->d_lut, ctx->d_esyn};
+    dp.maxfix = ctx->maxfix;
+    dp.cand_slots = ctx->cfg.keep_candidates ? ctx->d_cand_slots : nullptr;
+    dp.cand_counts = d_cand_counts;
+    dp.records = ctx->d_records;
+    dp.rec_counter = ctx->d_small;
+    dp.max_records = ctx->cfg.max_records;
+
+    const dim3 grid((nruns + kScanWaves - 1) / kScanWaves);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+    hipLaunchKernelGGL(scan_kernel, grid, dim3(kScanWaves * kWave), 0, st, sp);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+    hipLaunchKernelGGL(demod_kernel, dim3((nruns + 3) / 4), dim3(256), 0, st, dp);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, d_counts, d_cand_counts, nruns, ctx->d_small,
+                       ctx->d_small + 1, ctx->cfg.keep_candidates ? ctx->d_cand_offsets : nullptr, ctx->d_hdr);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hdr, ctx->d_hdr, sizeof(ResultHeader), hipMemcpyDeviceToHost, st));
+
+    ctx->last_stream = st;
+    ctx->in_flight = true;
+    ctx->nruns = nruns;
+    ctx->slot_cap = cap;
+    ctx->g0 = g0;
+    return MODES_OK;
+}
+
+int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
+    if (!ctx) return MODES_ERR_ARG;
+    if (!res) return fail(ctx, MODES_ERR_ARG, "fetch: null result");
+    if (!ctx->in_flight) return fail(ctx, MODES_ERR_STATE, "fetch: no detect in flight");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    hipStream_t st = ctx->last_stream;
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    ctx->in_flight = false;
+    memset(res, 0, sizeof *res);
+    const ResultHeader hdr = *ctx->h_hdr;
+    if (hdr.overflow)
+        return fail(ctx, MODES_ERR_OVERFLOW, "scan forwarded more than slot_cap=%u positions in one run; raise slot_cap",
+                    ctx->slot_cap);
+    if (hdr.n_records > ctx->cfg.max_records)
+        return fail(ctx, MODES_ERR_OVERFLOW, "%u records exceed max_records=%u", hdr.n_records, ctx->cfg.max_records);
+    if (hdr.n_records) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_records, ctx->d_records, (size_t)hdr.n_records * sizeof(modes_record),
+                                    hipMemcpyDeviceToHost, st));
+    }
+    if (ctx->cfg.keep_candidates && hdr.n_preambles) {
+        if (ctx->cand_dense_elems < hdr.n_preambles) {
+            if (ctx->d_cand_dense) (void)hipFree(ctx->d_cand_dense);
+            ctx->d_cand_dense = nullptr; ctx->cand_dense_elems = 0;
+            const size_t want = (size_t)hdr.n_preambles + (hdr.n_preambles >> 2) + 1024;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_cand_dense), want * sizeof(uint64_t)));
+            ctx->cand_dense_elems = want;
+        }
+        hipLaunchKernelGGL(compact_candidates_kernel, dim3((ctx->nruns + 3) / 4), dim3(256), 0, st, ctx->d_cand_slots,
+                           ctx->d_counts + ctx->nruns, ctx->d_cand_offsets, ctx->nruns, ctx->slot_cap, ctx->g0,
+                           ctx->d_cand_dense);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->h_cands.resize(hdr.n_preambles);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cands.data(), ctx->d_cand_dense, (size_t)hdr.n_preambles * sizeof(uint64_t),
+                                    hipMemcpyDeviceToHost, st));
+    } else {
+        ctx->h_cands.clear();
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    // records were appended in completion order: put them in stream order
+    std::sort(ctx->h_records, ctx->h_records + hdr.n_records, [](const modes_record &a, const modes_record &b) {
+        return a.block != b.block ? a.block < b.block : a.j < b.j;
+    });
+    res->records = ctx->h_records;
+    res->n_records = hdr.n_records;
+    res->candidates = ctx->h_cands.empty() ? nullptr : ctx->h_cands.data();
+    res->n_candidates = ctx->h_cands.size();
+    res->n_forwarded = hdr.n_forwarded;
+    res->n_preambles = hdr.n_preambles;
+    (void)hipEventElapsedTime(&res->scan_ms, ctx->ev[0], ctx->ev[1]);
+    (void)hipEventElapsedTime(&res->demod_ms, ctx->ev[1], ctx->ev[2]);
+    return MODES_OK;
+}
+
+int modes_gpu_demod_host(modes_gpu *ctx, const uint8_t *iq, uint64_t nbytes, uint64_t stream_byte0, uint64_t first_block,
+                         uint64_t nblocks, modes_gpu_result *res) {
+    if (!ctx) return MODES_ERR_ARG;
+    if (!iq && nbytes) return fail(ctx, MODES_ERR_ARG, "demod_host: null iq");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    int rc;
+    const size_t want = (size_t)((nbytes + 15) & ~15ull) + 16;
+    if ((rc = grow(ctx, &ctx->d_stage, &ctx->stage_bytes, want)) != MODES_OK) return rc;
+    if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage, iq, nbytes, hipMemcpyHostToDevice, ctx->own_stream));
+    modes_gpu_span span{ctx->d_stage, nbytes, stream_byte0, first_block, nblocks};
+    if ((rc = modes_gpu_detect(ctx, &span, nullptr)) != MODES_OK) return rc;
+    return modes_gpu_fetch(ctx, res);
+}
+
+}  // extern "C"

@@ -1,0 +1,349 @@
+// modes_host.cpp - libmodes_host.so: the sequential host half of the hot path
+// (include/modes_host.h).  Consumes the GPU's modes_record list and reproduces, in
+// stream order, what detectModeS()/decodeModesMessage()/useModesMessage() do after the
+// demodulator has produced bits.  Pure C++17, no HIP.
+//
+// Line numbers cite /root/reference/dump1090.c.
+
+#include "../../include/modes_host.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "modes_core.h"
+
+namespace {
+
+constexpr uint32_t kIcaoSlots = 1024;                  // MODES_ICAO_CACHE_LEN, :65
+
+// ICAOCacheHashAddress, :898-905.
+inline uint32_t icao_slot(uint32_t a) {
+    a = ((a >> 16) ^ a) * 0x45d9f3bu;
+    a = ((a >> 16) ^ a) * 0x45d9f3bu;
+    a = ((a >> 16) ^ a);
+    return a & (kIcaoSlots - 1);
+}
+
+}  // namespace
+
+struct modes_host {
+    modes_host_config cfg{};
+    modes_host_stats st{};
+    // Recently-seen ICAO addresses (:896-925).  The reference stamps entries with time(NULL) and
+    // expires them after 60 s of WALL CLOCK; a file run on the GPU finishes in milliseconds, so
+    // within one run entries never expire - the same semantics the parity oracle gets from the
+    // constant-clock interposer (DESIGN.md "ICAO cache TTL").
+    uint32_t icao[kIcaoSlots] = {};
+    bool have_candidates = false;
+};
+
+extern "C" {
+
+uint32_t modes_checksum(const unsigned char *msg, int bits) { return modes_syndrome(msg, bits / 8); }
+
+// modesComputeCRC (:703-719) = parity of the data bits only = syndrome XOR received parity.
+uint32_t modes_compute_crc(const unsigned char *msg, int bits) {
+    const int n = bits / 8;
+    const uint32_t rx = ((uint32_t)msg[n - 3] << 16) | ((uint32_t)msg[n - 2] << 8) | msg[n - 1];
+    return modes_syndrome(msg, n) ^ rx;
+}
+
+int modes_message_len_by_type(int type) { return modes_len_by_df(type); }
+
+uint64_t modes_block_count(uint64_t nbytes) { return nbytes / MODES_DATA_LEN + 1; }
+
+modes_host *modes_host_create(const modes_host_config *cfg) {
+    if (!cfg) return nullptr;
+    modes_host *h = new (std::nothrow) modes_host;
+    if (h) h->cfg = *cfg;
+    return h;
+}
+
+void modes_host_destroy(modes_host *h) { delete h; }
+
+void modes_host_get_stats(const modes_host *h, modes_host_stats *out) {
+    *out = h->st;
+    if (!h->have_candidates) out->valid_preamble = -1;
+}
+
+int modes_host_wants(const modes_host *h, const struct modesMessage *mm) {
+    return h->cfg.check_crc == 0 || mm->crcok;                                    // :1803
+}
+
+static void icao_remember(modes_host *h, uint32_t addr) { h->icao[icao_slot(addr)] = addr; }           // :910
+static bool icao_known(const modes_host *h, uint32_t addr) { return addr != 0 && h->icao[icao_slot(addr)] == addr; }  // :919
+
+// decodeAC13Field, :988-1012.
+static int decode_ac13(const unsigned char *msg, int *unit) {
+    const int m_bit = msg[3] & (1 << 6), q_bit = msg[3] & (1 << 4);
+    if (!m_bit) {
+        *unit = MODES_UNIT_FEET;
+        if (q_bit) {
+            const int n = ((msg[2] & 31) << 6) | ((msg[3] & 0x80) >> 2) | ((msg[3] & 0x20) >> 1) | (msg[3] & 15);
+            return n * 25 - 1000;
+        }
+    } else {
+        *unit = MODES_UNIT_METERS;
+    }
+    return 0;
+}
+
+// decodeAC12Field, :1016-1030.
+static int decode_ac12(const unsigned char *msg, int *unit) {
+    if (msg[5] & 1) {
+        *unit = MODES_UNIT_FEET;
+        const int n = ((msg[5] >> 1) << 4) | ((msg[6] & 0xF0) >> 4);
+        return n * 25 - 1000;
+    }
+    return 0;
+}
+
+void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMessage *mm) {
+    static const char ais[] = "?ABCDEFGHIJKLMNOPQRSTUVWXYZ????? ???????????????0123456789??????";
+    // The reference leaves the fields a message type does not use uninitialised (mm is a stack
+    // variable, :1732); zero them so the struct is a function of the input.
+    memset(mm, 0, sizeof *mm);
+    memcpy(mm->msg, att->msg, MODES_LONG_MSG_BYTES);
+    unsigned char *msg = mm->msg;
+
+    mm->msgtype = msg[0] >> 3;                                                    // :1099
+    mm->msgbits = modes_len_by_df(mm->msgtype);                                   // :1100
+    mm->crc = att->syndrome;                                                      // :1104 (computed on the GPU)
+    mm->errorbit = -1;
+    mm->iid = 0;
+    mm->crcok = (mm->crc == 0);
+
+    // :1112-1128.  The lookup ran on the GPU with the context's maxfix; apply it here.
+    if (!mm->crcok && h->cfg.fix_errors && (mm->msgtype == 11 || mm->msgtype == 17 || mm->msgtype == 18)) {
+        const int maxfix = h->cfg.aggressive ? 2 : 1;
+        const int nfixed = att->nfix <= maxfix ? att->nfix : 0;
+        if (nfixed > 0) {
+            for (int i = 0; i < nfixed; i++) msg[att->fixpos[i] >> 3] ^= (unsigned char)(0x80u >> (att->fixpos[i] & 7));
+            mm->crc = modes_checksum(msg, mm->msgbits);
+            mm->crcok = (mm->crc == 0);
+            mm->errorbit = att->fixpos[0];
+            if (nfixed == 1) h->st.single_bit_fix++; else h->st.two_bits_fix++;  // :1122-1126
+        }
+    }
+
+    mm->ca = msg[0] & 7;                                                          // :1133
+    mm->aa1 = msg[1]; mm->aa2 = msg[2]; mm->aa3 = msg[3];                         // :1136
+    mm->metype = msg[4] >> 3;                                                     // :1141
+    mm->mesub = msg[4] & 7;
+    mm->fs = msg[0] & 7;                                                          // :1145
+    mm->dr = msg[1] >> 3 & 31;
+    mm->um = ((msg[1] & 7) << 3) | msg[2] >> 5;
+    {   // squawk, :1163-1179 (Gillham interleave C1 A1 C2 A2 C4 A4 0 B1 D1 B2 D2 B4 D4)
+        const int a = ((msg[3] & 0x80) >> 5) | ((msg[2] & 0x02) >> 0) | ((msg[2] & 0x08) >> 3);
+        const int b = ((msg[3] & 0x02) << 1) | ((msg[3] & 0x08) >> 2) | ((msg[3] & 0x20) >> 5);
+        const int c = ((msg[2] & 0x01) << 2) | ((msg[2] & 0x04) >> 1) | ((msg[2] & 0x10) >> 4);
+        const int d = ((msg[3] & 0x01) << 2) | ((msg[3] & 0x04) >> 1) | ((msg[3] & 0x10) >> 4);
+        mm->identity = a * 1000 + b * 100 + c * 10 + d;
+    }
+
+    if (mm->msgtype != 11 && mm->msgtype != 17 && mm->msgtype != 18) {            // :1183
+        // bruteForceAP, :942-983: address = AP field XOR parity of the data bits
+        mm->crcok = 0;
+        const int t = mm->msgtype;
+        if (t == 0 || t == 4 || t == 5 || t == 16 || t == 20 || t == 21 || t == 24) {
+            const int last = mm->msgbits / 8 - 1;
+            const uint32_t crc = modes_compute_crc(msg, mm->msgbits);
+            const uint32_t b0 = msg[last] ^ (crc & 0xff), b1 = msg[last - 1] ^ ((crc >> 8) & 0xff),
+                           b2 = msg[last - 2] ^ ((crc >> 16) & 0xff);
+            if (icao_known(h, b0 | (b1 << 8) | (b2 << 16))) {
+                mm->aa1 = (int)b2; mm->aa2 = (int)b1; mm->aa3 = (int)b0;
+                mm->crcok = 1;
+            }
+        }
+    } else {
+        const uint32_t addr = ((uint32_t)mm->aa1 << 16) | ((uint32_t)mm->aa2 << 8) | (uint32_t)mm->aa3;
+        if (mm->crcok && mm->errorbit == -1) icao_remember(h, addr);               // :1198
+        if (mm->msgtype == 11 && !mm->crcok && mm->crc < 80 && icao_known(h, addr)) {   // :1204
+            mm->iid = (int)mm->crc;
+            mm->crcok = 1;
+        }
+    }
+
+    if (mm->msgtype == 0 || mm->msgtype == 4 || mm->msgtype == 16 || mm->msgtype == 20)   // :1213
+        mm->altitude = decode_ac13(msg, &mm->unit);
+
+    if (mm->msgtype == 17 || mm->msgtype == 18) {                                 // :1221
+        if (mm->metype >= 1 && mm->metype <= 4) {                                 // identification
+            mm->aircraft_type = mm->metype - 1;
+            mm->flight[0] = ais[msg[5] >> 2];
+            mm->flight[1] = ais[((msg[5] & 3) << 4) | (msg[6] >> 4)];
+            mm->flight[2] = ais[((msg[6] & 15) << 2) | (msg[7] >> 6)];
+            mm->flight[3] = ais[msg[7] & 63];
+            mm->flight[4] = ais[msg[8] >> 2];
+            mm->flight[5] = ais[((msg[8] & 3) << 4) | (msg[9] >> 4)];
+            mm->flight[6] = ais[((msg[9] & 15) << 2) | (msg[10] >> 6)];
+            mm->flight[7] = ais[msg[10] & 63];
+            mm->flight[8] = '\0';
+        } else if (mm->metype >= 5 && mm->metype <= 8) {                          // surface position, :1236
+            mm->movement = ((msg[4] & 0x07) << 4) | (msg[5] >> 4);
+            mm->movement_valid = (mm->movement != 0);
+            mm->ground_track_valid = (msg[5] >> 3) & 1;
+            mm->ground_track = (((msg[5] & 0x07) << 4) | (msg[6] >> 4)) * 360 / 128;
+            mm->fflag = (msg[6] >> 2) & 1;
+            mm->tflag = (msg[6] >> 3) & 1;
+            mm->raw_latitude = ((msg[6] & 3) << 15) | (msg[7] << 7) | (msg[8] >> 1);
+            mm->raw_longitude = ((msg[8] & 1) << 16) | (msg[9] << 8) | msg[10];
+        } else if (mm->metype >= 9 && mm->metype <= 18) {                         // airborne position, :1261
+            mm->fflag = msg[6] & (1 << 2);
+            mm->tflag = msg[6] & (1 << 3);
+            mm->altitude = decode_ac12(msg, &mm->unit);
+            mm->raw_latitude = ((msg[6] & 3) << 15) | (msg[7] << 7) | (msg[8] >> 1);
+            mm->raw_longitude = ((msg[8] & 1) << 16) | (msg[9] << 8) | msg[10];
+        } else if (mm->metype == 19 && mm->mesub >= 1 && mm->mesub <= 4) {        // velocity, :1272
+            if (mm->mesub == 1 || mm->mesub == 2) {
+                mm->ew_dir = (msg[5] & 4) >> 2;
+                mm->ew_velocity = ((msg[5] & 3) << 8) | msg[6];
+                mm->ns_dir = (msg[7] & 0x80) >> 7;
+                mm->ns_velocity = ((msg[7] & 0x7f) << 3) | ((msg[8] & 0xe0) >> 5);
+                mm->vert_rate_source = (msg[8] & 0x10) >> 4;
+                mm->vert_rate_sign = (msg[8] & 0x8) >> 3;
+                mm->vert_rate = ((msg[8] & 7) << 6) | ((msg[9] & 0xfc) >> 2);
+                mm->velocity = (int)std::sqrt((double)(mm->ns_velocity * mm->ns_velocity + mm->ew_velocity * mm->ew_velocity));
+                if (mm->velocity) {
+                    int ewv = mm->ew_velocity, nsv = mm->ns_velocity;
+                    if (mm->ew_dir) ewv = -ewv;
+                    if (mm->ns_dir) nsv = -nsv;
+                    const double heading = std::atan2((double)ewv, (double)nsv);
+                    mm->heading = (int)(heading * 360 / (M_PI * 2));
+                    if (mm->heading < 0) mm->heading += 360;
+                } else {
+                    mm->heading = 0;
+                }
+            } else {
+                mm->heading_is_valid = msg[5] & (1 << 2);
+                mm->heading = (int)((360.0 / 128) * (((msg[5] & 3) << 5) | (msg[6] >> 3)));
+            }
+        }
+    }
+    mm->phase_corrected = 0;                                                      // :1309
+}
+
+// The loop body of detectModeS after the bits exist (:1708-1791), driven by records instead of
+// by sample offsets.  State that the reference keeps in locals of one detectModeS() call - the
+// skip distance `j += ...` (:1770) and use_correction (:1568) - resets at every buffer, so it
+// resets here whenever `block` changes.
+uint64_t modes_host_resolve(modes_host *h, const modes_record *recs, uint64_t nrecs, const uint64_t *cands, uint64_t ncand,
+                            modes_sink_fn sink, void *user) {
+    uint64_t calls = 0;
+    uint64_t ri = 0, ci = 0;
+    uint32_t cur_block = 0xffffffffu;
+    uint32_t skip_to = 0;                 // first block-local offset the scan visits again
+    if (cands) h->have_candidates = true;
+
+    auto next_is_candidate_only = [&]() -> bool {
+        if (!cands || ci >= ncand) return false;
+        if (ri >= nrecs) return true;
+        const uint64_t grec = (uint64_t)recs[ri].block * MODES_BLOCK_STRIDE + recs[ri].j;
+        return cands[ci] < grec;
+    };
+
+    while (ri < nrecs || (cands && ci < ncand)) {
+        if (next_is_candidate_only()) {
+            // a preamble whose first noise gate failed: counted (:1651), then `continue` (:1723-1726)
+            const uint32_t blk = (uint32_t)(cands[ci] / MODES_BLOCK_STRIDE), j = (uint32_t)(cands[ci] % MODES_BLOCK_STRIDE);
+            ci++;
+            if (blk != cur_block) { cur_block = blk; skip_to = 0; }
+            if (j >= skip_to) h->st.valid_preamble++;
+            continue;
+        }
+        const modes_record &r = recs[ri++];
+        if (cands && ci < ncand && cands[ci] == (uint64_t)r.block * MODES_BLOCK_STRIDE + r.j) ci++;
+        if (r.block != cur_block) { cur_block = r.block; skip_to = 0; }
+        if (r.j < skip_to) continue;                                             // inside a decoded frame, :1770
+        h->st.valid_preamble++;                                                   // :1651
+
+        for (int pass = 0; pass < 2; pass++) {
+            const modes_attempt &a = r.att[pass];
+            if (pass == 1 && r.j != 0) h->st.out_of_phase++;                      // :1660-1663
+            if (!a.gate_ok) break;                                                // :1723-1726 (no retry)
+            bool good = false;
+            if (a.errors == 0 || (h->cfg.aggressive && a.errors < 3)) {           // :1731
+                struct modesMessage mm;
+                modes_host_decode(h, &a, &mm);
+                if (mm.crcok || pass == 1) {                                      // :1738-1753
+                    if (a.errors == 0) h->st.demodulated++;
+                    if (mm.errorbit == -1) {
+                        if (mm.crcok) h->st.goodcrc++; else h->st.badcrc++;
+                    } else {
+                        h->st.badcrc++;
+                        h->st.fixed++;
+                        if (mm.errorbit < MODES_LONG_MSG_BITS) h->st.single_bit_fix++; else h->st.two_bits_fix++;
+                    }
+                }
+                if (mm.crcok) {                                                   // :1769-1774
+                    // msglen comes from the demodulated (pre-repair) DF, like the local `msglen` of :1709
+                    skip_to = r.j + (8 + (uint32_t)modes_len_by_df(a.msg[0] >> 3)) * 2 + 1;
+                    good = true;
+                    if (pass == 1) mm.phase_corrected = 1;
+                }
+                if (sink) sink(&mm, r.block, r.j, user);                          // :1777
+                calls++;
+            }
+            if (good) break;                                                      // :1786-1791
+        }
+    }
+    return calls;
+}
+
+namespace {
+struct ArraySink {
+    modes_host *h;
+    modes_emitted *out;
+    uint64_t cap, n;
+};
+void array_sink(const struct modesMessage *mm, uint32_t block, uint32_t j, void *user) {
+    ArraySink *s = static_cast<ArraySink *>(user);
+    if (!modes_host_wants(s->h, mm)) return;
+    if (s->n < s->cap) {
+        s->out[s->n].mm = *mm;
+        s->out[s->n].block = block;
+        s->out[s->n].j = j;
+    }
+    s->n++;
+}
+}  // namespace
+
+uint64_t modes_host_resolve_to_array(modes_host *h, const modes_record *recs, uint64_t nrecs, const uint64_t *cands,
+                                     uint64_t ncand, modes_emitted *out, uint64_t cap) {
+    ArraySink s{h, out, out ? cap : 0, 0};
+    modes_host_resolve(h, recs, nrecs, cands, ncand, array_sink, &s);
+    return s.n;
+}
+
+int modes_format_raw(const struct modesMessage *mm, char *buf) {                  // :1324-1326
+    static const char hex[] = "0123456789abcdef";
+    int n = 0;
+    buf[n++] = '*';
+    for (int b = 0; b < mm->msgbits / 8; b++) {
+        buf[n++] = hex[mm->msg[b] >> 4];
+        buf[n++] = hex[mm->msg[b] & 15];
+    }
+    buf[n++] = ';';
+    buf[n++] = '\n';
+    buf[n] = 0;
+    return n;
+}
+
+int modes_format_onlyaddr(const struct modesMessage *mm, char *buf) {             // :1319
+    return snprintf(buf, 16, "%02x%02x%02x\n", mm->aa1, mm->aa2, mm->aa3);
+}
+
+int modes_format_stats(const modes_host_stats *st, char *buf) {                   // :2994-3005
+    return snprintf(buf, 512,
+                    "%lld valid preambles\n%lld demodulated again after phase correction\n"
+                    "%lld demodulated with zero errors\n%lld with good crc\n%lld with bad crc\n"
+                    "%lld errors corrected\n%lld single bit errors\n%lld two bits errors\n"
+                    "%lld total usable messages\n",
+                    (long long)st->valid_preamble, (long long)st->out_of_phase, (long long)st->demodulated,
+                    (long long)st->goodcrc, (long long)st->badcrc, (long long)st->fixed, (long long)st->single_bit_fix,
+                    (long long)st->two_bits_fix, (long long)(st->goodcrc + st->fixed));
+}
+
+}  // extern "C"

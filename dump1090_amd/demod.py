@@ -1,0 +1,277 @@
+"""Host-side mirror of the reference's two hot-path calls, on top of the C ABI.
+
+    reference (dump1090.c)                      here
+    ------------------------------------------  -------------------------------------------
+    computeMagnitudeVector()          :1454     Demodulator.compute_magnitude_vector(iq)
+    detectModeS(m, mlen)              :1563     Demodulator.detect(iq, ...) + .fetch()   (GPU)
+      ... decodeModesMessage(&mm,msg) :1735       HostResolver.resolve(records)           (CPU, in order)
+      ... useModesMessage(&mm)        :1777       -> list[Message] (what the sink would show)
+    main loop over buffers            :2969     Demodulator.demodulate(stream)
+
+torch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+
+
+def block_count(nbytes: int) -> int:
+    """Buffers the reference's reader publishes for an nbytes stream (dump1090.c:484-510)."""
+    return nbytes // N.DATA_LEN + 1
+
+
+def shard_blocks(nblocks: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous partition of buffers [0, nblocks) over `world` ranks -> (first_block, count)."""
+    base, extra = divmod(nblocks, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def shard_byte_range(first_block: int, nblocks: int, stream_nbytes: int) -> tuple[int, int]:
+    """Stream bytes a rank needs for its buffers: [start - 476, end), clipped to the stream
+    (the 476-byte carry of dump1090.c:481 is the only overlap between shards)."""
+    lo = max(0, first_block * N.DATA_LEN - N.CARRY_BYTES)
+    hi = min(stream_nbytes, (first_block + nblocks) * N.DATA_LEN)
+    return lo, max(lo, hi)
+
+
+@dataclass
+class Message:
+    """One message the reference's sink would display (fields of struct modesMessage)."""
+    msg: bytes
+    msgbits: int
+    msgtype: int
+    crcok: int
+    crc: int
+    errorbit: int
+    aa1: int
+    aa2: int
+    aa3: int
+    phase_corrected: int
+    iid: int
+    block: int
+    j: int
+    fields: dict
+
+    def raw_line(self) -> str:
+        return "*" + self.msg[: self.msgbits // 8].hex() + ";\n"         # dump1090.c:1324-1326
+
+    def addr_line(self) -> str:
+        return "%02x%02x%02x\n" % (self.aa1, self.aa2, self.aa3)          # dump1090.c:1319
+
+
+_EXTRA_FIELDS = [f for f, _ in N.ModesMessage._fields_ if f not in (
+    "msg", "msgbits", "msgtype", "crcok", "crc", "errorbit", "aa1", "aa2", "aa3", "phase_corrected", "iid")]
+
+
+def _to_message(e: N.Emitted) -> Message:
+    mm = e.mm
+    extra = {}
+    for f in _EXTRA_FIELDS:
+        v = getattr(mm, f)
+        extra[f] = v.decode("ascii", "replace") if isinstance(v, bytes) else int(v)
+    return Message(bytes(mm.msg), mm.msgbits, mm.msgtype, mm.crcok, mm.crc, mm.errorbit, mm.aa1, mm.aa2, mm.aa3,
+                   mm.phase_corrected, mm.iid, e.block, e.j, extra)
+
+
+class HostResolver:
+    """The sequential half: records -> messages (libmodes_host.so).  No GPU needed."""
+
+    def __init__(self, fix: bool = True, aggressive: bool = False, check_crc: bool = True):
+        self._lib = N.host_lib()
+        cfg = N.HostConfig(int(fix), int(aggressive), int(check_crc), 0)
+        self._h = self._lib.modes_host_create(C.byref(cfg))
+        if not self._h:
+            raise N.ModesError(-3, "modes_host_create failed")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.modes_host_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def resolve(self, records: np.ndarray, candidates: np.ndarray | None = None) -> list[Message]:
+        """Records (RECORD_DTYPE, ascending (block, j)) -> messages that pass the display filter."""
+        records = np.ascontiguousarray(records, dtype=N.RECORD_DTYPE)
+        cptr, ncand = None, 0
+        if candidates is not None:
+            candidates = np.ascontiguousarray(candidates, dtype=np.uint64)
+            cptr, ncand = candidates.ctypes.data, candidates.size
+        cap = 2 * records.size + 16                       # at most two sink calls per record
+        out = (N.Emitted * cap)()
+        n = self._lib.modes_host_resolve_to_array(self._h, records.ctypes.data, records.size, cptr, ncand, out, cap)
+        assert n <= cap
+        return [_to_message(out[i]) for i in range(n)]
+
+    def count(self, records: np.ndarray, candidates: np.ndarray | None = None) -> int:
+        """Like resolve() but only counts the messages (no Python objects; used by the bench)."""
+        records = np.ascontiguousarray(records, dtype=N.RECORD_DTYPE)
+        cptr, ncand = None, 0
+        if candidates is not None:
+            candidates = np.ascontiguousarray(candidates, dtype=np.uint64)
+            cptr, ncand = candidates.ctypes.data, candidates.size
+        return int(self._lib.modes_host_resolve_to_array(self._h, records.ctypes.data, records.size, cptr, ncand,
+                                                         None, 0))
+
+    def stats(self) -> dict:
+        st = N.HostStats()
+        self._lib.modes_host_get_stats(self._h, C.byref(st))
+        return st.as_dict()
+
+    def stats_text(self) -> str:
+        st = N.HostStats()
+        self._lib.modes_host_get_stats(self._h, C.byref(st))
+        buf = C.create_string_buffer(512)
+        self._lib.modes_format_stats(C.byref(st), buf)
+        return buf.value.decode()
+
+
+def raw_text(msgs) -> str:
+    return "".join(m.raw_line() for m in msgs)
+
+
+def onlyaddr_text(msgs) -> str:
+    return "".join(m.addr_line() for m in msgs)
+
+
+class Demodulator:
+    """GPU scan + demod + host resolve for one device.  Raises if the HIP library or a GPU is missing."""
+
+    def __init__(self, device: int = 0, fix: bool = True, aggressive: bool = False, check_crc: bool = True,
+                 keep_candidates: bool = False, run_chunks: int = 0, slot_cap: int = 0, max_records: int = 0):
+        self._lib = N.gpu_lib()
+        self.flags = dict(fix=fix, aggressive=aggressive, check_crc=check_crc)
+        self.device = device
+        cfg = N.GpuConfig(device, int(fix), int(aggressive), int(keep_candidates), run_chunks, slot_cap, max_records, 0)
+        h = C.c_void_p()
+        rc = self._lib.modes_gpu_create(C.byref(cfg), C.byref(h))
+        if rc != N.MODES_OK:
+            raise N.ModesError(rc, self._lib.modes_gpu_last_error(None).decode())
+        self._h = h
+        self.keep_candidates = keep_candidates
+        self.last = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.modes_gpu_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != N.MODES_OK:
+            raise N.ModesError(rc, self._lib.modes_gpu_last_error(self._h).decode())
+
+    @staticmethod
+    def _stream_ptr(stream):
+        if stream is None:
+            return None
+        return C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+
+    # ---- computeMagnitudeVector, dump1090.c:1454 -------------------------------------------
+    def compute_magnitude_vector(self, iq, stream=None):
+        """uint8 CUDA tensor of interleaved I/Q -> uint16 CUDA tensor of magnitudes."""
+        import torch
+        assert iq.is_cuda and iq.dtype == torch.uint8 and iq.is_contiguous()
+        n = iq.numel() // 2
+        out = torch.empty(n, dtype=torch.uint16, device=iq.device)
+        st = stream if stream is not None else torch.cuda.current_stream(iq.device)
+        self._check(self._lib.modes_gpu_compute_magnitude(self._h, iq.data_ptr(), n, out.data_ptr(),
+                                                          self._stream_ptr(st)))
+        return out
+
+    def compute_power(self, iq, stream=None):
+        import torch
+        assert iq.is_cuda and iq.dtype == torch.uint8 and iq.is_contiguous()
+        n = iq.numel() // 2
+        out = torch.empty(n, dtype=torch.uint16, device=iq.device)
+        st = stream if stream is not None else torch.cuda.current_stream(iq.device)
+        self._check(self._lib.modes_gpu_compute_power(self._h, iq.data_ptr(), n, out.data_ptr(), self._stream_ptr(st)))
+        return out
+
+    # ---- detectModeS (stateless part), dump1090.c:1563 -----------------------------------
+    def detect(self, iq, stream_byte0: int = 0, first_block: int = 0, nblocks: int | None = None, stream=None):
+        """Launch scan + demod for buffers [first_block, first_block+nblocks) of a stream whose bytes
+        [stream_byte0, stream_byte0+len(iq)) sit in the CUDA uint8 tensor `iq`.  Asynchronous."""
+        import torch
+        assert iq.is_cuda and iq.dtype == torch.uint8 and iq.is_contiguous()
+        if nblocks is None:
+            nblocks = block_count(stream_byte0 + iq.numel()) - first_block
+        span = N.Span(iq.data_ptr(), iq.numel(), stream_byte0, first_block, nblocks)
+        st = stream if stream is not None else torch.cuda.current_stream(iq.device)
+        self._keepalive = iq
+        self._check(self._lib.modes_gpu_detect(self._h, C.byref(span), self._stream_ptr(st)))
+
+    def fetch(self):
+        """Wait for detect(); -> (records ndarray, candidates ndarray | None, info dict)."""
+        res = N.GpuResult()
+        self._check(self._lib.modes_gpu_fetch(self._h, C.byref(res)))
+        return self._unpack(res)
+
+    def _unpack(self, res):
+        n = int(res.n_records)
+        if n:
+            recs = np.frombuffer(C.string_at(res.records, n * 64), dtype=N.RECORD_DTYPE).copy()
+        else:
+            recs = np.zeros(0, dtype=N.RECORD_DTYPE)
+        cands = None
+        if self.keep_candidates:
+            nc = int(res.n_candidates)
+            cands = (np.frombuffer(C.string_at(res.candidates, nc * 8), dtype=np.uint64).copy() if nc
+                     else np.zeros(0, dtype=np.uint64))
+        self.last = dict(n_records=n, n_forwarded=int(res.n_forwarded), n_preambles=int(res.n_preambles),
+                         scan_ms=float(res.scan_ms), demod_ms=float(res.demod_ms))
+        return recs, cands, dict(self.last)
+
+    def records_from_host(self, data: np.ndarray, stream_byte0: int = 0, first_block: int = 0,
+                          nblocks: int | None = None):
+        """modes_gpu_demod_host: stage a host buffer, detect, fetch (what the C host calls)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        if nblocks is None:
+            nblocks = block_count(stream_byte0 + data.size) - first_block
+        res = N.GpuResult()
+        self._check(self._lib.modes_gpu_demod_host(self._h, data.ctypes.data, data.size, stream_byte0, first_block,
+                                                   nblocks, C.byref(res)))
+        return self._unpack(res)
+
+    # ---- the whole path -----------------------------------------------------------------------
+    def demodulate(self, data, resolver: HostResolver | None = None):
+        """Whole stream (numpy uint8 on the host, or a CUDA uint8 tensor) -> list[Message]."""
+        own = resolver is None
+        if own:
+            resolver = HostResolver(**self.flags)
+        try:
+            if isinstance(data, np.ndarray):
+                recs, cands, _ = self.records_from_host(data)
+            else:
+                self.detect(data)
+                recs, cands, _ = self.fetch()
+            msgs = resolver.resolve(recs, cands)
+            self.last["stats"] = resolver.stats()
+            self.last["stats_text"] = resolver.stats_text()
+            return msgs
+        finally:
+            if own:
+                resolver.close()
+
+    # ---- synthetic input ----------------------------------------------------------------------
+    def synth_noise(self, out, first_byte: int, seed: int, sigma_q16: int = 941, stream=None):
+        """Fill a CUDA uint8 tensor with tests/synth.py:noise_bytes(seed, first_byte, len(out))."""
+        import torch
+        assert out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous()
+        st = stream if stream is not None else torch.cuda.current_stream(out.device)
+        self._check(self._lib.modes_gpu_synth_noise(self._h, out.data_ptr(), first_byte, out.numel(), seed, sigma_q16,
+                                                    self._stream_ptr(st)))
+        return out
+
+    def fill(self, out, value: int = 127, stream=None):
+        import torch
+        st = stream if stream is not None else torch.cuda.current_stream(out.device)
+        self._check(self._lib.modes_gpu_fill(self._h, out.data_ptr(), out.numel(), value, self._stream_ptr(st)))
+        return out

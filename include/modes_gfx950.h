@@ -1,0 +1,153 @@
+/* modes_gfx950.h - C ABI of libmodes_gfx950.so, the MI355X (gfx950) replacement for
+ * dump1090's IQ -> candidate-record hot path.
+ *
+ * The reference has no plugin interface: the path is entered by two calls the
+ * main thread makes once per 256 KiB buffer,
+ *
+ *     computeMagnitudeVector();                          dump1090.c:2974 -> :1454
+ *     detectModeS(Modes.magnitude, Modes.data_len/2);    dump1090.c:2986 -> :1563
+ *
+ * and left through useModesMessage(&mm) (dump1090.c:1777).  This header is what a
+ * C host binds instead (INTEGRATION.md shows the patch): the two stateless stages
+ * run on the GPU over MANY buffers at once and come back as fixed-size records,
+ * one per preamble position that survives the first noise gate; the stateful,
+ * in-order remainder of detectModeS()/decodeModesMessage() (skip window, retry,
+ * ICAO whitelist; dump1090.c:1731-1791, 1181-1210) stays on the host in
+ * modes_host.h and consumes those records.
+ *
+ * Plain C: pointers, sizes, POD structs.  No C++ / torch types.  Every function
+ * returns 0 or a negative MODES_ERR_*; modes_gpu_last_error() has the text.  A
+ * context is used from one host thread at a time (like the reference's main
+ * thread).  There is NO CPU fallback: without a HIP device create() fails.
+ */
+#ifndef MODES_GFX950_H
+#define MODES_GFX950_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MODES_OK            0
+#define MODES_ERR_ARG      (-1)   /* bad argument / span geometry                     */
+#define MODES_ERR_HIP      (-2)   /* HIP runtime error (text has hipGetErrorString)   */
+#define MODES_ERR_NOMEM    (-3)
+#define MODES_ERR_OVERFLOW (-4)   /* more records than max_records                    */
+#define MODES_ERR_STATE    (-5)   /* fetch without a detect in flight, ...            */
+
+/* Buffer geometry of the reference (dump1090.c:54,61,331): buffer k holds stream
+ * bytes [262144k - 476, 262144(k+1)), 127 outside the stream; 131310 magnitudes;
+ * detectModeS tests local offsets j in [0,131070).  "Framed coordinate"
+ * g = 131072*k + j  <->  file sample g - 238. */
+#define MODES_DATA_LEN        262144u
+#define MODES_CARRY_BYTES     476u
+#define MODES_BLOCK_STRIDE    131072u     /* samples between buffer starts            */
+#define MODES_BLOCK_POSITIONS 131070u     /* tested j per buffer (dump1090.c:1593)    */
+#define MODES_CARRY_SAMPLES   238u
+
+typedef struct modes_gpu modes_gpu;       /* opaque context                           */
+
+typedef struct {
+    int32_t  device;           /* HIP device ordinal                                  */
+    int32_t  fix_errors;       /* Modes.fix_errors (dump1090.c:167; default 1)        */
+    int32_t  aggressive;       /* Modes.aggressive (dump1090.c:179; default 0)        */
+    int32_t  keep_candidates;  /* also return every preamble position (for --stats)   */
+    uint32_t run_chunks;       /* tuning: 512-sample chunks per wavefront run, 0=auto */
+    uint32_t slot_cap;         /* tuning: forwarded positions per run, 0=auto         */
+    uint32_t max_records;      /* record-list capacity, 0 = 1<<20                     */
+    uint32_t scan_variant;     /* 0 = production scan kernel; others: see DESIGN.md   */
+} modes_gpu_config;
+
+/* One demodulation attempt at a preamble position: dump1090.c:1666-1726 (bit
+ * slicing, packing, noise gate) plus the syndrome / repair lookup of
+ * dump1090.c:1104,1112-1117,854-880.  Pure function of the magnitudes. */
+typedef struct {
+    uint8_t  msg[14];      /* packed bits as demodulated (before any repair)          */
+    uint8_t  errors;       /* dump1090.c:1682 counter                                 */
+    uint8_t  gate_ok;      /* 1 if mean |lo-hi| >= 2550 (dump1090.c:1723)             */
+    uint8_t  nfix;         /* bits fixBitErrors would flip: 0, 1 or 2                 */
+    uint8_t  fixpos[2];    /* their message-relative positions, 0xff if unused        */
+    uint8_t  pad[5];
+    uint32_t syndrome;     /* modesChecksum() of msg (dump1090.c:733); 0 if !gate_ok  */
+} modes_attempt;
+
+/* att[0]: samples as received.  att[1]: after applyPhaseCorrection
+ * (dump1090.c:1498-1558; identical to att[0] when j == 0, dump1090.c:1660).
+ * Emitted only for positions whose att[0].gate_ok == 1 (a failed first gate ends
+ * the position in the reference: dump1090.c:1723-1726). */
+typedef struct {
+    uint32_t      block;   /* buffer index k                                          */
+    uint32_t      j;       /* buffer-local offset                                     */
+    modes_attempt att[2];
+} modes_record;            /* 64 bytes                                                */
+
+/* A device-resident piece of the sample stream and the buffers to demodulate. */
+typedef struct {
+    const void *iq;            /* DEVICE pointer (2-byte aligned): interleaved u8 I,Q  */
+    uint64_t    nbytes;        /* valid bytes at iq; bytes outside read as 127        */
+    uint64_t    stream_byte0;  /* offset of iq[0] in the whole stream (even)          */
+    uint64_t    first_block;   /* first buffer index to demodulate                    */
+    uint64_t    nblocks;       /* number of buffers                                   */
+} modes_gpu_span;
+
+typedef struct {
+    const modes_record *records;       /* host memory owned by the context, ascending */
+    uint64_t            n_records;     /*   (block, j); valid until next detect       */
+    const uint64_t     *candidates;    /* framed g of every preamble position,        */
+    uint64_t            n_candidates;  /*   ascending (keep_candidates only)          */
+    uint64_t            n_forwarded;   /* positions the s-domain scan forwarded       */
+    uint64_t            n_preambles;   /* positions where dump1090.c:1602-1650 holds  */
+    float               scan_ms;       /* HIP-event time of the scan kernel           */
+    float               demod_ms;      /* HIP-event time of the demod kernel          */
+} modes_gpu_result;
+
+int  modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out);
+void modes_gpu_destroy(modes_gpu *ctx);
+/* Text of the last error on ctx (or of the last failed create when ctx == NULL). */
+const char *modes_gpu_last_error(const modes_gpu *ctx);
+
+/* Replaces computeMagnitudeVector() (dump1090.c:1454-1469): nsamples interleaved
+ * I/Q byte pairs at d_iq -> nsamples u16 magnitudes at d_mag (both DEVICE).
+ * stream: hipStream_t to launch on (NULL = the context's stream). */
+int modes_gpu_compute_magnitude(modes_gpu *ctx, const void *d_iq, uint64_t nsamples,
+                                void *d_mag, void *stream);
+
+/* Replaces computeMagnitudeVector()+detectModeS() up to (not including) the
+ * stateful decode, for span->nblocks buffers: launches the scan and demod
+ * kernels asynchronously on `stream` (NULL = the context's stream). */
+int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream);
+
+/* Waits for the last modes_gpu_detect(), copies the records back, orders them. */
+int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res);
+
+/* Host-buffer convenience used by the C host: stages `nbytes` stream bytes that
+ * start at stream offset `stream_byte0` into the context's device buffer, then
+ * detect + fetch for buffers [first_block, first_block+nblocks). */
+int modes_gpu_demod_host(modes_gpu *ctx, const uint8_t *iq, uint64_t nbytes,
+                         uint64_t stream_byte0, uint64_t first_block, uint64_t nblocks,
+                         modes_gpu_result *res);
+
+/* Debug / test taps of the scan kernel's inputs: s = (I-127)^2 + (Q-127)^2 per
+ * sample (u16) for nsamples at d_iq.  Ordering compares on s equal ordering
+ * compares on the magnitude (the LUT is strictly monotone in s). */
+int modes_gpu_compute_power(modes_gpu *ctx, const void *d_iq, uint64_t nsamples,
+                            void *d_s, void *stream);
+
+/* Synthetic-input generator (bench / tests): the integer noise of
+ * tests/synth.py:noise_bytes, bytes [first_byte, first_byte+nbytes) -> d_out. */
+int modes_gpu_synth_noise(modes_gpu *ctx, void *d_out, uint64_t first_byte, uint64_t nbytes,
+                          uint64_t seed, uint32_t sigma_q16, void *stream);
+
+/* Fills d_out[0..nbytes) with `value` (127 = no signal) - tail padding helper. */
+int modes_gpu_fill(modes_gpu *ctx, void *d_out, uint64_t nbytes, uint8_t value, void *stream);
+
+/* ABI version of this header. */
+#define MODES_GFX950_ABI 1
+int modes_gpu_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,170 @@
+/* modes_host.h - C ABI of libmodes_host.so: the host half of the hot path.
+ *
+ * What stays sequential in the reference stays on the CPU here: the skip-after-
+ * good-message rule, the retry-with-phase-correction state machine
+ * (dump1090.c:1568,1597,1723-1726,1731-1792), decodeModesMessage()'s CRC / repair /
+ * ICAO-whitelist decisions (dump1090.c:1091-1310, 896-983) and the sink
+ * useModesMessage() (dump1090.c:1802-1820).  Input: the modes_record list produced
+ * by libmodes_gfx950.so (modes_gfx950.h).  Output: `struct modesMessage` - same
+ * field names and types as dump1090.c:211-260 - handed to a callback in stream
+ * order, exactly where the reference calls useModesMessage(&mm).
+ *
+ * Pure host code: loads and runs without a GPU.
+ */
+#ifndef MODES_HOST_H
+#define MODES_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "modes_gfx950.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MODES_LONG_MSG_BITS   112
+#define MODES_SHORT_MSG_BITS  56
+#define MODES_LONG_MSG_BYTES  (112 / 8)
+#define MODES_SHORT_MSG_BYTES (56 / 8)
+#define MODES_UNIT_FEET   0
+#define MODES_UNIT_METERS 1
+
+/* dump1090.c:211-260, field for field. */
+struct modesMessage {
+    /* Generic fields */
+    unsigned char msg[MODES_LONG_MSG_BYTES]; /* Binary message. */
+    int msgbits;                /* Number of bits in message */
+    int msgtype;                /* Downlink format # */
+    int crcok;                  /* True if CRC was valid */
+    uint32_t crc;               /* Message CRC */
+    int errorbit;               /* Bit corrected. -1 if no bit corrected. */
+    int aa1, aa2, aa3;          /* ICAO Address bytes 1 2 and 3 */
+    int phase_corrected;        /* True if phase correction was applied. */
+
+    /* DF 11 */
+    int ca;                     /* Responder capabilities. */
+    int iid;                    /* Interrogator Identifier (IID). */
+
+    /* DF 17, 18 */
+    int metype;                 /* Extended squitter message type. */
+    int mesub;                  /* Extended squitter message subtype. */
+    int heading_is_valid;
+    int heading;
+    int aircraft_type;
+    int fflag;                  /* 1 = Odd, 0 = Even CPR message. */
+    int tflag;                  /* UTC synchronized? */
+    int raw_latitude;           /* Non decoded latitude */
+    int raw_longitude;          /* Non decoded longitude */
+    char flight[9];             /* 8 chars flight number. */
+    int ew_dir;                 /* 0 = East, 1 = West. */
+    int ew_velocity;            /* E/W velocity. */
+    int ns_dir;                 /* 0 = North, 1 = South. */
+    int ns_velocity;            /* N/S velocity. */
+    int vert_rate_source;       /* Vertical rate source. */
+    int vert_rate_sign;         /* Vertical rate sign. */
+    int vert_rate;              /* Vertical rate. */
+    int velocity;               /* Computed from EW and NS velocity. */
+
+    /* DF 17, 18: Surface position (metype 5-8). */
+    int movement;
+    int movement_valid;
+    int ground_track;
+    int ground_track_valid;
+
+    /* DF4, DF5, DF20, DF21 */
+    int fs;                     /* Flight status for DF4,5,20,21 */
+    int dr;                     /* Request extraction of downlink request. */
+    int um;                     /* Request extraction of downlink request. */
+    int identity;               /* 13 bits identity (Squawk). */
+
+    /* Fields used by multiple message types. */
+    int altitude, unit;
+};
+
+/* The flags of the reference's global `Modes` the path reads
+ * (dump1090.c:167,168,179; defaults dump1090.c:305,306,315). */
+typedef struct {
+    int32_t fix_errors;
+    int32_t aggressive;
+    int32_t check_crc;
+    int32_t reserved;
+} modes_host_config;
+
+/* dump1090.c:186-195 (the counters --stats prints, dump1090.c:2993-3006).
+ * valid_preamble needs the full candidate list (keep_candidates); it is -1 when
+ * the resolve ran on records only. */
+typedef struct {
+    int64_t valid_preamble;
+    int64_t out_of_phase;
+    int64_t demodulated;
+    int64_t goodcrc;
+    int64_t badcrc;
+    int64_t fixed;
+    int64_t single_bit_fix;
+    int64_t two_bits_fix;
+} modes_host_stats;
+
+/* Where the reference calls useModesMessage(&mm) (dump1090.c:1777).  Called for
+ * every attempt that reaches the decoder; `mm` lives on the caller's stack, do
+ * not retain it (same contract as dump1090.c:1732).  block/j locate the frame. */
+typedef void (*modes_sink_fn)(const struct modesMessage *mm, uint32_t block, uint32_t j, void *user);
+
+typedef struct modes_host modes_host;   /* resolve state: config, ICAO cache, stats */
+
+modes_host *modes_host_create(const modes_host_config *cfg);
+void        modes_host_destroy(modes_host *h);
+
+/* Sequential in-order resolve of one batch of records (ascending (block, j), as
+ * modes_gpu_fetch returns them).  `candidates` (framed g, ascending) is optional:
+ * when given, positions without a record (first noise gate failed) still count
+ * as valid preambles outside a skip window, which --stats needs.  The sink is
+ * called regardless of crcok, like dump1090.c:1777; use modes_host_wants() for
+ * the reference's display filter.  Returns number of sink calls. */
+uint64_t modes_host_resolve(modes_host *h, const modes_record *recs, uint64_t nrecs,
+                            const uint64_t *candidates, uint64_t ncand,
+                            modes_sink_fn sink, void *user);
+
+/* Same resolve, but instead of a callback the messages that pass the display
+ * filter (modes_host_wants) are stored, in order, in out[0..cap).  Returns the
+ * number of such messages (may exceed cap; only cap are stored). */
+typedef struct {
+    struct modesMessage mm;
+    uint32_t block;
+    uint32_t j;
+} modes_emitted;
+uint64_t modes_host_resolve_to_array(modes_host *h, const modes_record *recs, uint64_t nrecs,
+                                     const uint64_t *candidates, uint64_t ncand,
+                                     modes_emitted *out, uint64_t cap);
+
+/* dump1090.c:1803: would useModesMessage() display/forward this message? */
+int modes_host_wants(const modes_host *h, const struct modesMessage *mm);
+
+void modes_host_get_stats(const modes_host *h, modes_host_stats *out);
+
+/* decodeModesMessage() (dump1090.c:1091-1310) on a demodulated frame, with the
+ * repair decision already made on the GPU (att->nfix / fixpos).  Updates the
+ * ICAO whitelist and the repair counters exactly like the reference. */
+void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMessage *mm);
+
+/* Formatting of the sink's two machine-readable modes.  buf >= 40 bytes.
+ *   raw:      "*<hex>;\n"   (dump1090.c:1324-1326)
+ *   onlyaddr: "%02x%02x%02x\n" (dump1090.c:1319)
+ * Return the number of characters written. */
+int modes_format_raw(const struct modesMessage *mm, char *buf);
+int modes_format_onlyaddr(const struct modesMessage *mm, char *buf);
+/* The 9-line --stats summary (dump1090.c:2994-3005); buf >= 512 bytes. */
+int modes_format_stats(const modes_host_stats *st, char *buf);
+
+/* CRC helpers shared with the device code (dump1090.c:703-753). */
+uint32_t modes_checksum(const unsigned char *msg, int bits);      /* modesChecksum      */
+uint32_t modes_compute_crc(const unsigned char *msg, int bits);   /* modesComputeCRC    */
+int      modes_message_len_by_type(int type);                     /* modesMessageLenByType */
+
+/* Number of buffers the reference's reader publishes for a stream of nbytes
+ * (dump1090.c:484-510): nbytes/262144 + 1. */
+uint64_t modes_block_count(uint64_t nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

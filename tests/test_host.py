@@ -1,0 +1,104 @@
+"""CPU tests of the host half (libmodes_host.so via dump1090_amd.HostResolver): fed with the
+oracle's stateless records it must print exactly what the reference prints."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from dump1090_amd import HostResolver, _native as N, block_count, onlyaddr_text, raw_text, shard_blocks, shard_byte_range
+from helpers import maxfix_of, oracle_records
+
+CASES = ["modes1", "uniform", "coarse", "edges", "edges_smear", "frames", "smear", "lowsnr"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_resolve_reproduces_reference_listing(golden, streams, case):
+    data = streams[case]
+    for fs, flags in orc.FLAGSETS.items():
+        recs, cands = oracle_records(data, maxfix_of(flags))
+        r = HostResolver(**flags)
+        msgs = r.resolve(recs, cands)
+        assert raw_text(msgs) == golden[case]["raw"][fs]["text"], (case, fs)
+        if fs in golden[case]["stats"]:
+            assert r.stats_text() == golden[case]["stats"][fs]["text"], (case, fs)
+        if fs == "default":
+            assert onlyaddr_text(msgs) == golden[case]["onlyaddr"]["default"]["text"]
+        r.close()
+
+
+def test_resolve_without_candidates_gives_same_messages(streams):
+    data = streams["smear"]
+    flags = orc.FLAGSETS["aggressive_nocrc"]
+    recs, cands = oracle_records(data, 2)
+    a, b = HostResolver(**flags), HostResolver(**flags)
+    assert raw_text(a.resolve(recs, cands)) == raw_text(b.resolve(recs, None))
+    sa, sb = a.stats(), b.stats()
+    assert sb["valid_preamble"] == -1
+    sa.pop("valid_preamble"), sb.pop("valid_preamble")
+    assert sa == sb
+
+
+def test_resolve_in_batches_keeps_icao_state(streams, golden):
+    """Feeding the records buffer by buffer (as the C host does per GPU batch) changes nothing."""
+    data = streams["modes1"]
+    recs, cands = oracle_records(data, 1)
+    r = HostResolver()
+    msgs = []
+    for k in range(block_count(data.size)):
+        sel = recs["block"] == k
+        csel = (cands // N.BLOCK_STRIDE) == k
+        msgs += r.resolve(recs[sel], cands[csel])
+    assert raw_text(msgs) == golden["modes1"]["raw"]["default"]["text"]
+    assert r.stats_text() == golden["modes1"]["stats"]["default"]["text"]
+
+
+def test_message_fields_against_oracle(streams):
+    data = streams["frames"]
+    want, _ = orc.run_stream(data, **orc.FLAGSETS["default"])
+    recs, cands = oracle_records(data, 1)
+    got = HostResolver().resolve(recs, cands)
+    assert len(got) == len(want) > 50
+    for g, w in zip(got, want):
+        assert (g.msg, g.msgbits, g.msgtype, g.crcok, g.crc, g.errorbit, g.aa1, g.aa2, g.aa3, g.phase_corrected,
+                g.iid, g.block, g.j) == (bytes(w.msg), w.msgbits, w.msgtype, w.crcok, w.crc, w.errorbit, w.aa1, w.aa2,
+                                         w.aa3, w.phase_corrected, w.iid, w.block, w.j)
+
+
+def test_crc_helpers():
+    L = N.host_lib()
+    rng = np.random.default_rng(3)
+    for bits in (56, 112):
+        for _ in range(200):
+            msg = rng.integers(0, 256, 14, dtype=np.uint8)
+            assert L.modes_checksum(msg.ctypes.data, bits) == orc.lib().orc_checksum(msg.ctypes.data, bits)
+            orc.lib().orc_compute_crc.restype = C.c_uint32
+            orc.lib().orc_compute_crc.argtypes = [C.c_void_p, C.c_int]
+            assert L.modes_compute_crc(msg.ctypes.data, bits) == orc.lib().orc_compute_crc(msg.ctypes.data, bits)
+    assert [L.modes_message_len_by_type(t) for t in (0, 4, 11, 16, 17, 21, 22, 24)] == [56, 56, 56, 112, 112, 112, 56, 56]
+    assert L.modes_block_count(0) == 1 and L.modes_block_count(262144) == 2 and L.modes_block_count(262145) == 2
+
+
+def test_sharding_helpers():
+    for nblocks in (1, 7, 8, 9, 4097):
+        for world in (1, 2, 3, 8):
+            parts = [shard_blocks(nblocks, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and sum(n for _, n in parts) == nblocks
+            for (f0, n0), (f1, _) in zip(parts, parts[1:]):
+                assert f0 + n0 == f1
+    assert shard_byte_range(0, 2, 10 ** 9) == (0, 2 * 262144)
+    assert shard_byte_range(2, 2, 10 ** 9) == (2 * 262144 - 476, 4 * 262144)
+    assert shard_byte_range(3, 1, 3 * 262144 + 10) == (3 * 262144 - 476, 3 * 262144 + 10)
+
+
+def test_cli_fails_loudly_without_gpu():
+    """No CPU fallback: on a machine without a HIP device the CLI must refuse, not emulate."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = os.path.join(N.PKG_DIR, "bin", "dump1090_amd")
+    fixture = os.path.join(os.path.dirname(__file__), "golden", "modes1.bin")
+    p = subprocess.run([exe, "--ifile", fixture, "--raw"], capture_output=True)
+    assert p.returncode == 1 and p.stdout == b"" and b"no HIP device" in p.stderr
