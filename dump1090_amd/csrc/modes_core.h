@@ -283,4 +283,124 @@ MODES_HD void modes_demod_both(const M &mag, bool with_phase, modes_attempt_core
     out[1].gate_ok = modes_len_by_df(out[1].msg[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
 }
 
+/* ------------------------------------------------------------------------
+ * Data-parallel formulation of the same demodulation (used by the gfx950 demod
+ * kernel: one wavefront per preamble, lane L owns bit pairs k = L and L + 64).
+ *
+ * Everything sequential in dump1090.c:1669-1689 and 1498-1558 is a first-order
+ * boolean recurrence  r_k = G_k | (P_k & r_(k-1))  with G & P == 0, which is the
+ * carry chain of an addition: with a = G|P and b = G, the carry out of bit k of
+ * a + b is r_k.  Masks are 128-bit, bit k = bit pair k (0..111).
+ *
+ *  - bit slicing: a "weak" pair (k>0, |lo-hi| < 256) repeats the previous bit:
+ *      bit_k = weak_k ? bit_(k-1) : (lo_k > hi_k)      G = strong & ~weak, P = weak
+ *  - phase correction, early > late (dump1090.c:1512-1534, walks k = 111 -> 0 and
+ *    rescales hi): c_k = lo_k > hi'_k, hi'_(k-1) = scale(hi_(k-1), c_k ? dn : up)
+ *      c_(k-1) = Up_(k-1) | (Dn_(k-1) & c_k)   with Up_k = lo_k > scale(hi_k, up),
+ *      Dn_k = lo_k > scale(hi_k, dn), Up subset of Dn    (same chain, bit-reversed)
+ *  - phase correction, late >= early (dump1090.c:1535-1556, walks k = 0 -> 111 and
+ *    rescales lo): c_k = lo'_k > hi_k, lo'_(k+1) = scale(lo_(k+1), c_k ? up : dn)
+ *      c_k = Dn_k | (Up_k & c_(k-1))   with Up_k = scale(lo_k, up) > hi_k, Dn subset of Up
+ * ------------------------------------------------------------------------ */
+struct modes_m128 {
+    uint64_t lo, hi;          /* bits 0..63, 64..127 */
+};
+MODES_HD modes_m128 m128_make(uint64_t lo, uint64_t hi) { modes_m128 r; r.lo = lo; r.hi = hi; return r; }
+MODES_HD modes_m128 m128_and(modes_m128 a, modes_m128 b) { return m128_make(a.lo & b.lo, a.hi & b.hi); }
+MODES_HD modes_m128 m128_or(modes_m128 a, modes_m128 b) { return m128_make(a.lo | b.lo, a.hi | b.hi); }
+MODES_HD modes_m128 m128_xor(modes_m128 a, modes_m128 b) { return m128_make(a.lo ^ b.lo, a.hi ^ b.hi); }
+MODES_HD modes_m128 m128_andn(modes_m128 a, modes_m128 b) { return m128_make(a.lo & ~b.lo, a.hi & ~b.hi); }   /* a & ~b */
+MODES_HD modes_m128 m128_add(modes_m128 a, modes_m128 b) {
+    modes_m128 r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u);
+    return r;
+}
+MODES_HD modes_m128 m128_shr1(modes_m128 a) { return m128_make((a.lo >> 1) | (a.hi << 63), a.hi >> 1); }
+MODES_HD uint64_t m128_rev64(uint64_t x) {
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    return (x >> 32) | (x << 32);
+}
+/* bit k <-> bit 111-k, for masks that only use bits 0..111 */
+MODES_HD modes_m128 m128_rev112(modes_m128 a) {
+    const uint64_t rl = m128_rev64(a.lo), rh = m128_rev64(a.hi);      /* bit k -> 127-k: {hi=rl, lo=rh} */
+    return m128_make((rh >> 16) | (rl << 48), rl >> 16);              /* then >> 16: 127-k -> 111-k     */
+}
+/* r_k = G_k | (P_k & r_(k-1)), r_(-1) = 0.  Requires G & P == 0 and bits >= 112 clear. */
+MODES_HD modes_m128 modes_chain(modes_m128 G, modes_m128 P) {
+    const modes_m128 sum = m128_add(m128_or(G, P), G);
+    return m128_shr1(m128_xor(sum, P));
+}
+/* same recurrence running from bit 111 down to bit 0 */
+MODES_HD modes_m128 modes_chain_down(modes_m128 G, modes_m128 P) {
+    return m128_rev112(modes_chain(m128_rev112(G), m128_rev112(P)));
+}
+
+/* Per-pair quantities of one slicing pass (elementwise; lane L computes k = L, L+64). */
+MODES_HD void modes_pair_flags(int k, int lo, int hi, bool *weak, bool *strong, int *delta) {
+    const int d = lo > hi ? lo - hi : hi - lo;
+    *delta = d;
+    *weak = k > 0 && d < 256;                      /* dump1090.c:1675 */
+    *strong = lo > hi;                             /* dump1090.c:1683 */
+}
+
+/* From the masks of one slicing pass to the packed message, dump1090.c:1669-1706.
+ * `first_equal` = (lo_0 == hi_0): the reference stores the value 2 for that pair and for the
+ * weak pairs that repeat it; packing ORs `2 << (7 - t)` into byte k/8 (t = k%8), i.e. sets the
+ * bit of pair k-1 unless t == 0, where it falls off the byte (dump1090.c:1696-1706). */
+MODES_HD void modes_pack_message(modes_m128 weak, modes_m128 strong, bool first_equal, uint8_t msg[14], uint8_t *errors) {
+    modes_m128 bits = modes_chain(m128_andn(strong, weak), weak);
+    bits.hi &= 0x0000FFFFFFFFFFFFull;
+    *errors = first_equal ? 1 : 0;                 /* only pair 0 can take the lo==hi branch (:1677-1682) */
+    if (first_equal) {
+        /* pairs 0..r hold the value 2, r = length of the weak run that follows pair 0 */
+        const modes_m128 w1 = m128_shr1(weak);     /* bit i = weak_(i+1) */
+        int r = 0;
+        {
+            const uint64_t inv_lo = ~w1.lo;
+            if (inv_lo) r = __builtin_ctzll(inv_lo);
+            else {
+                const uint64_t inv_hi = ~w1.hi;
+                r = 64 + (inv_hi ? __builtin_ctzll(inv_hi) : 64);
+            }
+            if (r > 111) r = 111;
+        }
+        /* ones at bits 0..r-1 = the positions k-1 for k = 1..r */
+        modes_m128 twos;
+        if (r == 0) twos = m128_make(0, 0);
+        else if (r < 64) twos = m128_make((1ull << r) - 1, 0);
+        else if (r == 64) twos = m128_make(~0ull, 0);
+        else twos = m128_make(~0ull, (1ull << (r - 64)) - 1);
+        /* k % 8 == 0 falls off its byte: drop positions p = k-1 with p % 8 == 7 */
+        const modes_m128 keep = m128_make(0x7F7F7F7F7F7F7F7Full, 0x7F7F7F7F7F7F7F7Full);
+        bits = m128_or(bits, m128_and(twos, keep));
+    }
+    for (int b = 0; b < 14; b++) {
+        const uint32_t v = (uint32_t)((b < 8 ? bits.lo >> (8 * b) : bits.hi >> (8 * (b - 8))) & 0xFF);
+        /* pair 8b+t is bit t of v and bit 7-t of the byte */
+        uint32_t rev = ((v & 0xF0) >> 4) | ((v & 0x0F) << 4);
+        rev = ((rev & 0xCC) >> 2) | ((rev & 0x33) << 2);
+        rev = ((rev & 0xAA) >> 1) | ((rev & 0x55) << 1);
+        msg[b] = (uint8_t)rev;
+    }
+}
+
+/* Scale factors of applyPhaseCorrection (dump1090.c:1502-1516 / 1538-1539).
+ * m_1 = m[-1], m0..m10 as named.  Returns true for the early > late branch. */
+MODES_HD bool modes_phase_factors(uint32_t m_1, uint32_t m0, uint32_t m2, uint32_t m3, uint32_t m6, uint32_t m7,
+                                  uint32_t m9, uint32_t m10, uint32_t *up, uint32_t *dn) {
+    const uint32_t on_time = m0 + m2 + m7 + m9;
+    const uint32_t early = (m_1 + m6) * 2u, late = (m3 + m10) * 2u;
+    const bool backward = early > late;
+    const uint32_t e = backward ? early : late;
+    const uint32_t x = 16384u * e / (e + on_time);
+    *up = (16384u + x) & 0xFFFFu;
+    *dn = (16384u - x) & 0xFFFFu;
+    return backward;
+}
+
 #endif /* MODES_CORE_H */

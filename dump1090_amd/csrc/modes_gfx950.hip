@@ -59,26 +59,23 @@ struct DeviceTables {
 
 // 16 stream bytes at byte offset `off` (may be negative / past the end: 127 there,
 // which is what the reference pads with, dump1090.c:344,506).
-// Slow path of load_iq16: byte-wise with bounds checks.  Out of line so the streaming
-// loop's code stays small; taken only by lanes that straddle the ends of the span.
-__device__ __attribute__((noinline)) uint4 load_iq16_edge(const uint8_t *iq, int64_t off, int64_t lo, int64_t hi) {
-    uint32_t w[4];
-    for (int d = 0; d < 4; d++) {
-        uint32_t v = 0;
-        for (int b = 0; b < 4; b++) {
-            int64_t o = off + 4 * d + b;
-            uint32_t byte = (o >= lo && o < hi) ? iq[o] : 127u;
-            v |= byte << (8 * b);
-        }
-        w[d] = v;
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// `iq` is 16-byte aligned; the valid bytes are [lo, hi) relative to it.
+// 16 stream bytes at byte offset `off` relative to the 16-byte aligned base `iq`; the valid bytes
+// are [lo, hi), everything else reads as 127 - what the reference pads with (dump1090.c:344,506).
+// The byte-wise path is a rolled loop (small code) taken only by lanes that straddle an end of
+// the span.
 __device__ __forceinline__ uint4 load_iq16(const uint8_t *iq, int64_t off, int64_t lo, int64_t hi) {
     if (off >= lo && off + 16 <= hi) return *reinterpret_cast<const uint4 *>(iq + off);
-    return load_iq16_edge(iq, off, lo, hi);
+    uint64_t a = 0x7f7f7f7f7f7f7f7full, b = 0x7f7f7f7f7f7f7f7full;
+#pragma nounroll
+    for (int t = 0; t < 16; t++) {
+        const int64_t o = off + t;
+        if (o >= lo && o < hi) {
+            const int sh = (t & 7) * 8;
+            const uint64_t v = (uint64_t)iq[o] << sh, keep = ~(0xffull << sh);
+            if (t < 8) a = (a & keep) | v; else b = (b & keep) | v;
+        }
+    }
+    return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
 }
 
 __device__ __forceinline__ uint4 power16(uint4 v) {
@@ -268,62 +265,218 @@ struct DemodParams {
     uint32_t max_records;
 };
 
-__device__ __forceinline__ void finish_attempt(const modes_attempt_core &a, int maxfix, const uint32_t *esyn,
-                                               modes_attempt *out) {
+// Guarded loads at the ends of the span: bytes outside [lo, hi) read as 127 (no signal).
+__device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t *iq, int64_t o, int64_t lo, int64_t hi) {
+    if (o >= lo && o + 4 <= hi) return *reinterpret_cast<const uint32_t *>(iq + o);
+    uint32_t v = 0x7f7f7f7fu;
+#pragma nounroll
+    for (int b = 0; b < 4; b++)
+        if (o + b >= lo && o + b < hi) v = (v & ~(0xffu << (8 * b))) | ((uint32_t)iq[o + b] << (8 * b));
+    return v;
+}
+__device__ __forceinline__ uint32_t load_sample_guarded(const uint8_t *iq, int64_t sample, int64_t lo, int64_t hi) {
+    const int64_t o = 2 * sample;
+    if (o >= lo && o + 2 <= hi) return *reinterpret_cast<const uint16_t *>(iq + o);
+    uint32_t v = 0x7f7fu;
+    if (o >= lo && o < hi) v = (v & 0xff00u) | iq[o];
+    if (o + 1 >= lo && o + 1 < hi) v = (v & 0x00ffu) | ((uint32_t)iq[o + 1] << 8);
+    return v;
+}
+// magnitude of a sample packed as I | Q << 8 (low 16 bits)
+__device__ __forceinline__ int mag_of(const uint16_t *s_lut, uint32_t iq16) {
+    return s_lut[modes_lut_index(iq16 & 0xff, (iq16 >> 8) & 0xff)];
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
-    for (int b = 0; b < 14; b++) out->msg[b] = a.msg[b];
-    out->errors = a.errors;
-    out->gate_ok = a.gate_ok;
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Ballot of a per-pair flag: lane L contributes pair L (f1) and pair L+64 (f2, lanes < 48).
+__device__ __forceinline__ modes_m128 pair_ballot(bool f1, bool f2) {
+    return m128_make(__ballot(f1), __ballot(f2) & 0x0000FFFFFFFFFFFFull);
+}
+__device__ __forceinline__ bool m128_bit(modes_m128 m, int k) {      // k may be per-lane
+    return (((k < 64) ? (m.lo >> (k & 63)) : (m.hi >> (k & 63))) & 1ull) != 0;
+}
+
+// Syndrome / repair lookup for one attempt (lane 0 only; rare: needs a passed noise gate).
+__device__ __forceinline__ void finish_attempt(const uint8_t msg[14], uint8_t errors, bool gate_ok, int maxfix,
+                                               const uint32_t *esyn, modes_attempt *out) {
+#pragma unroll
+    for (int b = 0; b < 14; b++) out->msg[b] = msg[b];
+    out->errors = errors;
+    out->gate_ok = gate_ok ? 1 : 0;
     out->nfix = 0;
     out->fixpos[0] = out->fixpos[1] = 0xff;
 #pragma unroll
     for (int b = 0; b < 5; b++) out->pad[b] = 0;
     out->syndrome = 0;
-    if (!a.gate_ok) return;
-    const int df = a.msg[0] >> 3;
+    if (!gate_ok) return;
+    const int df = msg[0] >> 3;
     const int bits = modes_len_by_df(df);
-    const uint32_t syn = modes_syndrome(a.msg, bits / 8);                    // modesChecksum, :1104
+    const uint32_t syn = modes_syndrome(msg, bits / 8);                      // modesChecksum, :1104
     out->syndrome = syn;
     if (syn != 0 && maxfix > 0 && (df == 11 || df == 17 || df == 18))        // :1112-1117
         out->nfix = (uint8_t)modes_find_fix(syn, bits, maxfix, esyn, out->fixpos);
 }
 
+// One slicing pass for the whole wavefront: lane L holds pairs k1 = L and k2 = L + 64.
+// Returns the packed message (wave-uniform) and, on request, the two delta sums.
+__device__ __forceinline__ void slice_pass(int lane, int lo1, int hi1, int lo2, int hi2, uint8_t msg[14], uint8_t *errors,
+                                           int *sum56, int *sum112) {
+    bool w1, s1, w2, s2;
+    int d1, d2;
+    modes_pair_flags(lane, lo1, hi1, &w1, &s1, &d1);
+    modes_pair_flags(lane + 64, lo2, hi2, &w2, &s2, &d2);
+    const bool two = lane < 48;
+    const modes_m128 weak = pair_ballot(w1, two && w2);
+    const modes_m128 strong = pair_ballot(s1, two && s2);
+    const bool first_equal = (__ballot(lo1 == hi1) & 1ull) != 0;             // pair 0 lives in lane 0
+    modes_pack_message(weak, strong, first_equal, msg, errors);
+    if (sum56) {
+        // both sums in one reduction: sum112 < 2^23, sum56 < 2^22
+        const int all = d1 + (two ? d2 : 0);
+        const int first = (lane < 56) ? d1 : 0;
+        *sum112 = wave_sum(all);
+        *sum56 = wave_sum(first);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// demod_kernel - persistent workgroups, one wavefront per run.
+//   stage 1: one lane per forwarded position: exact preamble predicate (dump1090.c:1602-1650)
+//            on LUT magnitudes; survivors compacted, in order, into a wave-private LDS list.
+//   stage 2: the wavefront demodulates the survivors one at a time, all 64 lanes cooperating
+//            (coalesced sample loads; the sequential parts of the reference become carry chains,
+//            see modes_core.h).  Positions whose first noise gate passes become records.
+// ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void demod_kernel(DemodParams P) {
+    __shared__ uint16_t s_lut[129 * 129 + 1];
+    __shared__ uint32_t s_list[4][64];
+    for (int i = threadIdx.x; i < 129 * 129; i += blockDim.x) s_lut[i] = P.tab.lut[i];
+    __syncthreads();
+
     const int lane = threadIdx.x & 63;
-    const uint32_t run = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (run >= P.nruns) return;
-    const uint32_t n = min(P.counts[run], P.slot_cap);
-    const uint32_t *my = P.slots + (uint64_t)run * P.slot_cap;
-    uint32_t ncand = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t e = base + lane;
-        const bool active = e < n;
-        const uint32_t p = active ? my[e] : 0u;
-        MagAt mag{P.iq, P.lo, P.hi, P.tab.lut, (int64_t)p};
-        const bool ok = active && modes_preamble_exact(mag);
-        const uint64_t okb = __ballot(ok);
-        if (ok && P.cand_slots)
-            P.cand_slots[(uint64_t)run * P.slot_cap + ncand + (uint32_t)__builtin_popcountll(okb & ((1ull << lane) - 1))] = p;
-        ncand += (uint32_t)__builtin_popcountll(okb);
-        if (ok) {
-            const uint64_t g = (uint64_t)p + P.g0;
-            const uint32_t j = (uint32_t)(g & (MODES_BLOCK_STRIDE - 1));
-            modes_attempt_core a[2];
-            modes_demod_both(mag, j != 0, a);
-            if (a[0].gate_ok) {
-                const uint32_t idx = atomicAdd(P.rec_counter, 1u);
-                if (idx < P.max_records) {
-                    modes_record rec;
-                    rec.block = (uint32_t)(g / MODES_BLOCK_STRIDE);
-                    rec.j = j;
-                    finish_attempt(a[0], P.maxfix, P.tab.esyn, &rec.att[0]);
-                    finish_attempt(a[1], P.maxfix, P.tab.esyn, &rec.att[1]);
-                    P.records[idx] = rec;
+    const int wave = threadIdx.x >> 6;
+    const uint8_t *iq = P.iq;
+    const int64_t lo = P.lo, hi = P.hi;
+
+    for (uint32_t run = blockIdx.x * 4 + wave; run < P.nruns; run += gridDim.x * 4) {
+        const uint32_t n = min(P.counts[run], P.slot_cap);
+        const uint32_t *my = P.slots + (uint64_t)run * P.slot_cap;
+        uint32_t ncand = 0;
+        for (uint32_t base = 0; base < n; base += 64) {
+            // ---------------- stage 1 ----------------
+            const uint32_t e = base + lane;
+            const bool active = e < n;
+            const uint32_t p = active ? my[e] : 0u;
+            bool ok = false;
+            if (active) {
+                const int64_t even = (int64_t)(p & ~1u);
+                int mm[16];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t w = load_dword_guarded(iq, 2 * even + 4 * i, lo, hi);
+                    mm[2 * i] = mag_of(s_lut, w & 0xffffu);
+                    mm[2 * i + 1] = mag_of(s_lut, w >> 16);
+                }
+                const bool odd = (p & 1u) != 0;
+                int m[15];
+#pragma unroll
+                for (int t = 0; t < 15; t++) m[t] = odd ? mm[t + 1] : mm[t];
+                struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
+                ok = modes_preamble_exact(Win{m});
+            }
+            const uint64_t okb = __ballot(ok);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(okb & ((1ull << lane) - 1));
+            if (ok) {
+                s_list[wave][rank] = p;
+                if (P.cand_slots) P.cand_slots[(uint64_t)run * P.slot_cap + ncand + rank] = p;
+            }
+            const uint32_t nlist = (uint32_t)__builtin_popcountll(okb);
+            ncand += nlist;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ---------------- stage 2 ----------------
+            for (uint32_t c = 0; c < nlist; c++) {
+                const int64_t pc = (int64_t)s_list[wave][c];                 // wave-uniform
+                const uint64_t g = (uint64_t)pc + P.g0;
+                const uint32_t j = (uint32_t)(g & (MODES_BLOCK_STRIDE - 1));
+                const bool two = lane < 48;
+                // lane L: pairs k1 = L, k2 = L+64 -> samples 16+2k, 17+2k; lanes 0..11 also m[-1..10]
+                const int lo1 = mag_of(s_lut, load_sample_guarded(iq, pc + 16 + 2 * lane, lo, hi));
+                const int hi1 = mag_of(s_lut, load_sample_guarded(iq, pc + 17 + 2 * lane, lo, hi));
+                const int lo2 = two ? mag_of(s_lut, load_sample_guarded(iq, pc + 144 + 2 * lane, lo, hi)) : 0;
+                const int hi2 = two ? mag_of(s_lut, load_sample_guarded(iq, pc + 145 + 2 * lane, lo, hi)) : 0;
+                const int pre = (lane < 12) ? mag_of(s_lut, load_sample_guarded(iq, pc - 1 + lane, lo, hi)) : 0;
+
+                uint8_t msg0[14], err0;
+                int sum56, sum112;
+                slice_pass(lane, lo1, hi1, lo2, hi2, msg0, &err0, &sum56, &sum112);
+                const bool gate0 = modes_len_by_df(msg0[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+                if (!gate0) continue;                                        // dump1090.c:1723-1726: position ends
+
+                uint8_t msg1[14], err1 = err0;
+#pragma unroll
+                for (int b = 0; b < 14; b++) msg1[b] = msg0[b];
+                bool gate1 = gate0;
+                if (j != 0) {                                                // dump1090.c:1660
+                    uint32_t up, dn;
+                    const bool backward = modes_phase_factors(
+                        (uint32_t)__builtin_amdgcn_readlane(pre, 0), (uint32_t)__builtin_amdgcn_readlane(pre, 1),
+                        (uint32_t)__builtin_amdgcn_readlane(pre, 3), (uint32_t)__builtin_amdgcn_readlane(pre, 4),
+                        (uint32_t)__builtin_amdgcn_readlane(pre, 7), (uint32_t)__builtin_amdgcn_readlane(pre, 8),
+                        (uint32_t)__builtin_amdgcn_readlane(pre, 10), (uint32_t)__builtin_amdgcn_readlane(pre, 11), &up, &dn);
+                    int nlo1 = lo1, nhi1 = hi1, nlo2 = lo2, nhi2 = hi2;
+                    if (backward) {
+                        // hi of every pair is rescaled, walking from pair 111 down (dump1090.c:1519-1534)
+                        const int hu1 = (int)modes_scale((uint32_t)hi1, up), hd1 = (int)modes_scale((uint32_t)hi1, dn);
+                        const int hu2 = (int)modes_scale((uint32_t)hi2, up), hd2 = (int)modes_scale((uint32_t)hi2, dn);
+                        const modes_m128 Up = pair_ballot(lo1 > hu1, two && lo2 > hu2);
+                        modes_m128 Dn = pair_ballot(lo1 > hd1, two && lo2 > hd2);
+                        modes_m128 Pm = m128_andn(Dn, Up);
+                        Pm.hi &= ~(1ull << 47);                              // pair 111 starts the chain: c_111 = Up_111
+                        const modes_m128 cm = modes_chain_down(Up, Pm);
+                        nhi1 = m128_bit(cm, lane + 1) ? hd1 : hu1;           // pair k uses c_(k+1)
+                        nhi2 = (lane == 47) ? hu2 : (m128_bit(cm, lane + 65) ? hd2 : hu2);
+                    } else {
+                        // lo of every pair is rescaled, walking from pair 0 up (dump1090.c:1542-1556)
+                        const int lu1 = (int)modes_scale((uint32_t)lo1, up), ld1 = (int)modes_scale((uint32_t)lo1, dn);
+                        const int lu2 = (int)modes_scale((uint32_t)lo2, up), ld2 = (int)modes_scale((uint32_t)lo2, dn);
+                        const modes_m128 Up = pair_ballot(lu1 > hi1, two && lu2 > hi2);
+                        const modes_m128 Dn = pair_ballot(ld1 > hi1, two && ld2 > hi2);
+                        modes_m128 Gm = Dn, Pm = m128_andn(Up, Dn);
+                        Gm.lo = (Gm.lo & ~1ull) | (Up.lo & 1ull);            // pair 0 starts the chain: c_0 = Up_0
+                        Pm.lo &= ~1ull;
+                        const modes_m128 cm = modes_chain(Gm, Pm);
+                        nlo1 = (lane == 0) ? lu1 : (m128_bit(cm, lane - 1) ? lu1 : ld1);   // pair k uses c_(k-1)
+                        nlo2 = m128_bit(cm, lane + 63) ? lu2 : ld2;
+                    }
+                    slice_pass(lane, nlo1, nhi1, nlo2, nhi2, msg1, &err1, nullptr, nullptr);
+                    // the gate of the retry: uncorrected deltas, the retry's own length (dump1090.c:1708-1723)
+                    gate1 = modes_len_by_df(msg1[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+                }
+                if (lane == 0) {
+                    const uint32_t idx = atomicAdd(P.rec_counter, 1u);
+                    if (idx < P.max_records) {
+                        modes_record rec;
+                        rec.block = (uint32_t)(g / MODES_BLOCK_STRIDE);
+                        rec.j = j;
+                        finish_attempt(msg0, err0, true, P.maxfix, P.tab.esyn, &rec.att[0]);
+                        finish_attempt(msg1, err1, gate1, P.maxfix, P.tab.esyn, &rec.att[1]);
+                        P.records[idx] = rec;
+                    }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
+        if (lane == 0) P.cand_counts[run] = ncand;
     }
-    if (lane == 0) P.cand_counts[run] = ncand;
 }
 
 // ------------------------------------------------------------------------------------
@@ -558,7 +711,9 @@ void modes_gpu_destroy(modes_gpu *ctx) {
     delete ctx;
 }
 
-static hipStream_t pick_stream(modes_gpu *ctx, void *stream) { return stream ? static_cast<hipStream_t>(stream) : ctx->own_stream; }
+// `stream` is a hipStream_t; NULL is HIP's default stream (which is also what torch's default
+// stream is), NOT the context's private stream - work must stay ordered with the caller's.
+static hipStream_t pick_stream(modes_gpu *, void *stream) { return static_cast<hipStream_t>(stream); }
 
 int modes_gpu_compute_magnitude(modes_gpu *ctx, const void *d_iq, uint64_t nsamples, void *d_mag, void *stream) {
     if (!ctx) return MODES_ERR_ARG;
@@ -701,7 +856,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     hipLaunchKernelGGL(scan_kernel, grid, dim3(kScanWaves * kWave), 0, st, sp);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    hipLaunchKernelGGL(demod_kernel, dim3((nruns + 3) / 4), dim3(256), 0, st, dp);
+    hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((nruns + 3) / 4, 1024u)), dim3(256), 0, st, dp);
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, d_counts, d_cand_counts, nruns, ctx->d_small,
                        ctx->d_small + 1, ctx->cfg.keep_candidates ? ctx->d_cand_offsets : nullptr, ctx->d_hdr);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
@@ -779,7 +934,7 @@ int modes_gpu_demod_host(modes_gpu *ctx, const uint8_t *iq, uint64_t nbytes, uin
     if ((rc = grow(ctx, &ctx->d_stage, &ctx->stage_bytes, want)) != MODES_OK) return rc;
     if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage, iq, nbytes, hipMemcpyHostToDevice, ctx->own_stream));
     modes_gpu_span span{ctx->d_stage, nbytes, stream_byte0, first_block, nblocks};
-    if ((rc = modes_gpu_detect(ctx, &span, nullptr)) != MODES_OK) return rc;
+    if ((rc = modes_gpu_detect(ctx, &span, ctx->own_stream)) != MODES_OK) return rc;
     return modes_gpu_fetch(ctx, res);
 }
 

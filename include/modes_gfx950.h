@@ -110,13 +110,13 @@ const char *modes_gpu_last_error(const modes_gpu *ctx);
 
 /* Replaces computeMagnitudeVector() (dump1090.c:1454-1469): nsamples interleaved
  * I/Q byte pairs at d_iq -> nsamples u16 magnitudes at d_mag (both DEVICE).
- * stream: hipStream_t to launch on (NULL = the context's stream). */
+ * stream: the hipStream_t to launch on (NULL = HIP's default stream). */
 int modes_gpu_compute_magnitude(modes_gpu *ctx, const void *d_iq, uint64_t nsamples,
                                 void *d_mag, void *stream);
 
 /* Replaces computeMagnitudeVector()+detectModeS() up to (not including) the
  * stateful decode, for span->nblocks buffers: launches the scan and demod
- * kernels asynchronously on `stream` (NULL = the context's stream). */
+ * kernels asynchronously on `stream` (a hipStream_t; NULL = HIP's default stream). */
 int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream);
 
 /* Waits for the last modes_gpu_detect(), copies the records back, orders them. */

@@ -52,6 +52,79 @@ void shim_demod_both(const uint16_t *win, int with_phase, uint8_t *out) {
     memcpy(out, a, sizeof a);
 }
 
+// The data-parallel formulation the gfx950 demod kernel uses (carry chains, modes_core.h), with the
+// 64 lanes emulated by loops: lane L owns pairs L and L+64, "ballots" become mask-building loops.
+// Mirrors demod_kernel's stage 2 statement by statement.
+namespace {
+struct Lanes {
+    int lo[112], hi[112];
+};
+modes_m128 ballot_pairs(const bool *f) {
+    modes_m128 m = m128_make(0, 0);
+    for (int k = 0; k < 112; k++)
+        if (f[k]) { if (k < 64) m.lo |= 1ull << k; else m.hi |= 1ull << (k - 64); }
+    return m;
+}
+bool bit_of(modes_m128 m, int k) { return ((k < 64 ? m.lo >> k : m.hi >> (k - 64)) & 1ull) != 0; }
+void slice_pass_emul(const Lanes &v, uint8_t msg[14], uint8_t *errors, int *sum56, int *sum112) {
+    bool w[112], s[112];
+    int s56 = 0, s112 = 0;
+    for (int k = 0; k < 112; k++) {
+        int d;
+        modes_pair_flags(k, v.lo[k], v.hi[k], &w[k], &s[k], &d);
+        s112 += d;
+        if (k < 56) s56 += d;
+    }
+    modes_pack_message(ballot_pairs(w), ballot_pairs(s), v.lo[0] == v.hi[0], msg, errors);
+    if (sum56) { *sum56 = s56; *sum112 = s112; }
+}
+}  // namespace
+
+void shim_demod_parallel(const uint16_t *win, int with_phase, uint8_t *out) {
+    MagPtr mag{win};
+    Lanes v;
+    for (int k = 0; k < 112; k++) { v.lo[k] = mag(16 + 2 * k); v.hi[k] = mag(17 + 2 * k); }
+    modes_attempt_core a[2];
+    memset(a, 0, sizeof a);
+    int sum56, sum112;
+    slice_pass_emul(v, a[0].msg, &a[0].errors, &sum56, &sum112);
+    a[0].gate_ok = modes_len_by_df(a[0].msg[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+    a[1] = a[0];
+    if (a[0].gate_ok && with_phase) {
+        uint32_t up, dn;
+        const bool backward = modes_phase_factors(mag(-1), mag(0), mag(2), mag(3), mag(6), mag(7), mag(9), mag(10), &up, &dn);
+        Lanes n = v;
+        bool U[112], D[112];
+        if (backward) {
+            int hu[112], hd[112];
+            for (int k = 0; k < 112; k++) {
+                hu[k] = (int)modes_scale((uint32_t)v.hi[k], up); hd[k] = (int)modes_scale((uint32_t)v.hi[k], dn);
+                U[k] = v.lo[k] > hu[k]; D[k] = v.lo[k] > hd[k];
+            }
+            const modes_m128 Up = ballot_pairs(U);
+            modes_m128 Pm = m128_andn(ballot_pairs(D), Up);
+            Pm.hi &= ~(1ull << 47);
+            const modes_m128 cm = modes_chain_down(Up, Pm);
+            for (int k = 0; k < 112; k++) n.hi[k] = (k == 111) ? hu[k] : (bit_of(cm, k + 1) ? hd[k] : hu[k]);
+        } else {
+            int lu[112], ld[112];
+            for (int k = 0; k < 112; k++) {
+                lu[k] = (int)modes_scale((uint32_t)v.lo[k], up); ld[k] = (int)modes_scale((uint32_t)v.lo[k], dn);
+                U[k] = lu[k] > v.hi[k]; D[k] = ld[k] > v.hi[k];
+            }
+            const modes_m128 Up = ballot_pairs(U), Dn = ballot_pairs(D);
+            modes_m128 Gm = Dn, Pm = m128_andn(Up, Dn);
+            Gm.lo = (Gm.lo & ~1ull) | (Up.lo & 1ull);
+            Pm.lo &= ~1ull;
+            const modes_m128 cm = modes_chain(Gm, Pm);
+            for (int k = 0; k < 112; k++) n.lo[k] = (k == 0) ? lu[k] : (bit_of(cm, k - 1) ? lu[k] : ld[k]);
+        }
+        slice_pass_emul(n, a[1].msg, &a[1].errors, nullptr, nullptr);
+        a[1].gate_ok = modes_len_by_df(a[1].msg[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+    }
+    memcpy(out, a, sizeof a);
+}
+
 int shim_preamble_exact(const uint16_t *m15) {
     struct M { const uint16_t *m; int operator()(int t) const { return m[t]; } };
     return modes_preamble_exact(M{m15}) ? 1 : 0;

@@ -17,6 +17,7 @@ def shim():
     L.shim_scan_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     L.shim_power.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     L.shim_demod_both.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.shim_demod_parallel.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.shim_preamble_exact.argtypes = [C.c_void_p]
     L.shim_syndrome.argtypes = [C.c_void_p, C.c_int]
     L.shim_syndrome.restype = C.c_uint32
@@ -98,6 +99,31 @@ def test_preamble_exact_matches_oracle(shim, streams):
     assert got.sum() > 100 and (~got).sum() > 10
 
 
+def test_chain_primitives(shim):
+    """modes_chain / modes_chain_down / m128_rev112 against a bit-by-bit loop (via random demod windows:
+    every window exercises the slicing chain; the phase branch exercises the other two)."""
+    rng = np.random.default_rng(11)
+    for trial in range(4000):
+        style = trial % 4
+        if style == 0:
+            win = rng.integers(0, 65536, 241).astype(np.uint16)
+        elif style == 1:                        # many weak pairs and equal neighbours
+            win = (rng.integers(0, 6, 241) * 200 + 3000).astype(np.uint16)
+        elif style == 2:                        # strong frame-like alternation with leak
+            b = rng.integers(0, 2, 241)
+            win = (b * 30000 + rng.integers(0, 9000, 241)).astype(np.uint16)
+        else:                                   # first pair equal -> the value-2 packing quirk
+            win = (rng.integers(0, 4, 241) * 150 + 20000).astype(np.uint16)
+            win[17] = win[18]
+        a = np.zeros(32, dtype=np.uint8)
+        b2 = np.zeros(32, dtype=np.uint8)
+        shim.shim_demod_both(win.ctypes.data, 1, a.ctypes.data)
+        shim.shim_demod_parallel(win.ctypes.data, 1, b2.ctypes.data)
+        assert np.array_equal(a[:16], b2[:16]), (trial, "attempt 0")
+        if a[15]:
+            assert np.array_equal(a[16:], b2[16:]), (trial, "attempt 1")
+
+
 @pytest.mark.parametrize("case", ["modes1", "coarse", "smear", "lowsnr", "edges_smear"])
 def test_demod_both_matches_oracle_records(shim, streams, case):
     data = streams[case]
@@ -114,6 +140,11 @@ def test_demod_both_matches_oracle_records(shim, streams, case):
             win[1:] = mag[j:j + 240]
             out = np.zeros(32, dtype=np.uint8)
             shim.shim_demod_both(win.ctypes.data, int(j != 0), out.ctypes.data)
+            par = np.zeros(32, dtype=np.uint8)
+            shim.shim_demod_parallel(win.ctypes.data, int(j != 0), par.ctypes.data)
+            assert np.array_equal(out[:16], par[:16]), (case, k, j, "parallel attempt 0")
+            if out[15]:
+                assert np.array_equal(out[16:], par[16:]), (case, k, j, "parallel attempt 1")
             a0, a1 = out[:16], out[16:]
             assert bytes(a0[:14]) == bytes(w["att"][0]["msg"]) and a0[14] == w["att"][0]["errors"] \
                 and a0[15] == w["att"][0]["gate_ok"], (case, k, j)
