@@ -148,6 +148,14 @@ __global__ __launch_bounds__(256) void power_kernel(const uint8_t *__restrict__ 
 // synchronisation, no atomics; forwarded positions go to the run's private slot list in
 // ascending order, so the concatenation over runs is already sorted.
 // ------------------------------------------------------------------------------------
+// Totals of one detect call, accumulated on the device (zeroed by a memset node before the scan).
+struct ResultHeader {
+    unsigned long long n_forwarded;   // positions forwarded by the scan (atomics, one per demod workgroup)
+    unsigned long long n_preambles;   // positions where the full predicate holds
+    uint32_t n_records;               // record-list append counter
+    uint32_t overflow;                // some run overflowed its slots
+};
+
 struct ScanParams {
     const uint8_t *iq;    // 16-byte aligned base
     int64_t lo, hi;       // valid bytes [lo, hi) relative to iq (lo < 16: alignment slack)
@@ -160,7 +168,7 @@ struct ScanParams {
     uint32_t slot_cap;
     uint32_t *slots;      // [nruns][slot_cap]
     uint32_t *counts;     // [nruns]  (true count, may exceed slot_cap -> overflow flag)
-    uint32_t *flags;      // [0] = some run overflowed its slots
+    ResultHeader *hdr;
 };
 
 __global__ __launch_bounds__(kScanWaves * kWave) void scan_kernel(ScanParams P) {
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_kernel(ScanParams P) 
     }
     if (lane == 0) {
         P.counts[run] = count;
-        if (count > P.slot_cap) atomicOr(&P.flags[0], 1u);
+        if (count > P.slot_cap) atomicOr(&P.hdr->overflow, 1u);
     }
 }
 
@@ -261,26 +269,35 @@ struct DemodParams {
     uint32_t *cand_slots;      // [nruns][slot_cap] or nullptr
     uint32_t *cand_counts;     // [nruns]
     modes_record *records;
-    uint32_t *rec_counter;
+    ResultHeader *hdr;
     uint32_t max_records;
 };
 
-// Guarded loads at the ends of the span: bytes outside [lo, hi) read as 127 (no signal).
-__device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t *iq, int64_t o, int64_t lo, int64_t hi) {
-    if (o >= lo && o + 4 <= hi) return *reinterpret_cast<const uint32_t *>(iq + o);
+// Sample / dword loads for the demod kernel.  GUARD = false: plain loads (the caller has checked,
+// wave-uniformly, that every byte it will touch lies inside the span) - no branches, so the loads
+// of one iteration pipeline.  GUARD = true: bytes outside [lo, hi) read as 127 (no signal); used
+// only by wavefronts that work next to an end of the span.
+template <bool GUARD>
+__device__ __forceinline__ uint32_t load_dword(const uint8_t *iq, int64_t o, int64_t lo, int64_t hi) {
+    if (!GUARD || (o >= lo && o + 4 <= hi)) return *reinterpret_cast<const uint32_t *>(iq + o);
     uint32_t v = 0x7f7f7f7fu;
 #pragma nounroll
     for (int b = 0; b < 4; b++)
         if (o + b >= lo && o + b < hi) v = (v & ~(0xffu << (8 * b))) | ((uint32_t)iq[o + b] << (8 * b));
     return v;
 }
-__device__ __forceinline__ uint32_t load_sample_guarded(const uint8_t *iq, int64_t sample, int64_t lo, int64_t hi) {
+template <bool GUARD>
+__device__ __forceinline__ uint32_t load_sample(const uint8_t *iq, int64_t sample, int64_t lo, int64_t hi) {
     const int64_t o = 2 * sample;
-    if (o >= lo && o + 2 <= hi) return *reinterpret_cast<const uint16_t *>(iq + o);
+    if (!GUARD || (o >= lo && o + 2 <= hi)) return *reinterpret_cast<const uint16_t *>(iq + o);
     uint32_t v = 0x7f7fu;
     if (o >= lo && o < hi) v = (v & 0xff00u) | iq[o];
     if (o + 1 >= lo && o + 1 < hi) v = (v & 0x00ffu) | ((uint32_t)iq[o + 1] << 8);
     return v;
+}
+// true when samples [first, last] are entirely inside the span
+__device__ __forceinline__ bool samples_inside(int64_t first, int64_t last, int64_t lo, int64_t hi) {
+    return 2 * first >= lo && 2 * last + 2 <= hi;
 }
 // magnitude of a sample packed as I | Q << 8 (low 16 bits)
 __device__ __forceinline__ int mag_of(const uint16_t *s_lut, uint32_t iq16) {
@@ -344,51 +361,160 @@ __device__ __forceinline__ void slice_pass(int lane, int lo1, int hi1, int lo2, 
     }
 }
 
+// Full demodulation of one preamble by the whole wavefront (both attempts) -> record.
+// sum56 / sum112: the delta sums of dump1090.c:1713-1717 (already computed by the pre-gate).
+// Exact preamble predicate (dump1090.c:1602-1650) at buffer sample p, magnitudes from the LDS LUT.
+template <bool GUARD>
+__device__ __forceinline__ bool preamble_at(const uint8_t *iq, int64_t lo, int64_t hi, const uint16_t *s_lut, uint32_t p) {
+    const int64_t even = (int64_t)(p & ~1u);
+    int mm[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t w = load_dword<GUARD>(iq, 2 * even + 4 * i, lo, hi);
+        mm[2 * i] = mag_of(s_lut, w & 0xffffu);
+        mm[2 * i + 1] = mag_of(s_lut, w >> 16);
+    }
+    const bool odd = (p & 1u) != 0;
+    int m[15];
+#pragma unroll
+    for (int t = 0; t < 15; t++) m[t] = odd ? mm[t + 1] : mm[t];
+    struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
+    return modes_preamble_exact(Win{m});
+}
+
+// Sums of |lo-hi| over pairs gl, gl+16, ... of the preamble at pc (one 16-lane group).
+template <bool GUARD>
+__device__ __forceinline__ void gate_sums(const uint8_t *iq, int64_t lo, int64_t hi, const uint16_t *s_lut, int64_t pc, int gl,
+                                          int *d56, int *d112) {
+    int s56 = 0, s112 = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const int k = gl + 16 * i;
+        const int a = mag_of(s_lut, load_sample<GUARD>(iq, pc + 16 + 2 * k, lo, hi));
+        const int b = mag_of(s_lut, load_sample<GUARD>(iq, pc + 17 + 2 * k, lo, hi));
+        const int d = a > b ? a - b : b - a;
+        s112 += d;
+        if (k < 56) s56 += d;
+    }
+    *d56 = s56;
+    *d112 = s112;
+}
+
+template <bool GUARD>
+__device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t *s_lut, int lane, int64_t pc, int sum56,
+                                           int sum112) {
+    const uint8_t *iq = P.iq;
+    const int64_t lo = P.lo, hi = P.hi;
+    const uint64_t g = (uint64_t)pc + P.g0;
+    const uint32_t j = (uint32_t)(g & (MODES_BLOCK_STRIDE - 1));
+    const bool two = lane < 48;
+    // lane L: pairs k1 = L, k2 = L+64 -> samples 16+2k, 17+2k; lanes 0..11 also m[-1..10]
+    const int lo1 = mag_of(s_lut, load_sample<GUARD>(iq, pc + 16 + 2 * lane, lo, hi));
+    const int hi1 = mag_of(s_lut, load_sample<GUARD>(iq, pc + 17 + 2 * lane, lo, hi));
+    const int lo2 = two ? mag_of(s_lut, load_sample<GUARD>(iq, pc + 144 + 2 * lane, lo, hi)) : 0;
+    const int hi2 = two ? mag_of(s_lut, load_sample<GUARD>(iq, pc + 145 + 2 * lane, lo, hi)) : 0;
+    const int pre = (lane < 12) ? mag_of(s_lut, load_sample<GUARD>(iq, pc - 1 + lane, lo, hi)) : 0;
+
+    uint8_t msg0[14], err0;
+    slice_pass(lane, lo1, hi1, lo2, hi2, msg0, &err0, nullptr, nullptr);
+    const bool gate0 = modes_len_by_df(msg0[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+    if (!gate0) return;                                                      // dump1090.c:1723-1726: position ends
+
+    uint8_t msg1[14], err1 = err0;
+#pragma unroll
+    for (int b = 0; b < 14; b++) msg1[b] = msg0[b];
+    bool gate1 = gate0;
+    if (j != 0) {                                                            // dump1090.c:1660
+        uint32_t up, dn;
+        const bool backward = modes_phase_factors(
+            (uint32_t)__builtin_amdgcn_readlane(pre, 0), (uint32_t)__builtin_amdgcn_readlane(pre, 1),
+            (uint32_t)__builtin_amdgcn_readlane(pre, 3), (uint32_t)__builtin_amdgcn_readlane(pre, 4),
+            (uint32_t)__builtin_amdgcn_readlane(pre, 7), (uint32_t)__builtin_amdgcn_readlane(pre, 8),
+            (uint32_t)__builtin_amdgcn_readlane(pre, 10), (uint32_t)__builtin_amdgcn_readlane(pre, 11), &up, &dn);
+        int nlo1 = lo1, nhi1 = hi1, nlo2 = lo2, nhi2 = hi2;
+        if (backward) {
+            // hi of every pair is rescaled, walking from pair 111 down (dump1090.c:1519-1534)
+            const int hu1 = (int)modes_scale((uint32_t)hi1, up), hd1 = (int)modes_scale((uint32_t)hi1, dn);
+            const int hu2 = (int)modes_scale((uint32_t)hi2, up), hd2 = (int)modes_scale((uint32_t)hi2, dn);
+            const modes_m128 Up = pair_ballot(lo1 > hu1, two && lo2 > hu2);
+            const modes_m128 Dn = pair_ballot(lo1 > hd1, two && lo2 > hd2);
+            modes_m128 Pm = m128_andn(Dn, Up);
+            Pm.hi &= ~(1ull << 47);                                          // pair 111 starts the chain: c_111 = Up_111
+            const modes_m128 cm = modes_chain_down(Up, Pm);
+            nhi1 = m128_bit(cm, lane + 1) ? hd1 : hu1;                       // pair k uses c_(k+1)
+            nhi2 = (lane == 47) ? hu2 : (m128_bit(cm, lane + 65) ? hd2 : hu2);
+        } else {
+            // lo of every pair is rescaled, walking from pair 0 up (dump1090.c:1542-1556)
+            const int lu1 = (int)modes_scale((uint32_t)lo1, up), ld1 = (int)modes_scale((uint32_t)lo1, dn);
+            const int lu2 = (int)modes_scale((uint32_t)lo2, up), ld2 = (int)modes_scale((uint32_t)lo2, dn);
+            const modes_m128 Up = pair_ballot(lu1 > hi1, two && lu2 > hi2);
+            const modes_m128 Dn = pair_ballot(ld1 > hi1, two && ld2 > hi2);
+            modes_m128 Gm = Dn, Pm = m128_andn(Up, Dn);
+            Gm.lo = (Gm.lo & ~1ull) | (Up.lo & 1ull);                        // pair 0 starts the chain: c_0 = Up_0
+            Pm.lo &= ~1ull;
+            const modes_m128 cm = modes_chain(Gm, Pm);
+            nlo1 = (lane == 0) ? lu1 : (m128_bit(cm, lane - 1) ? lu1 : ld1);   // pair k uses c_(k-1)
+            nlo2 = m128_bit(cm, lane + 63) ? lu2 : ld2;
+        }
+        slice_pass(lane, nlo1, nhi1, nlo2, nhi2, msg1, &err1, nullptr, nullptr);
+        // the gate of the retry: uncorrected deltas, the retry's own length (dump1090.c:1708-1723)
+        gate1 = modes_len_by_df(msg1[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+    }
+    if (lane == 0) {
+        const uint32_t idx = atomicAdd(&P.hdr->n_records, 1u);
+        if (idx < P.max_records) {
+            modes_record rec;
+            rec.block = (uint32_t)(g / MODES_BLOCK_STRIDE);
+            rec.j = j;
+            finish_attempt(msg0, err0, true, P.maxfix, P.tab.esyn, &rec.att[0]);
+            finish_attempt(msg1, err1, gate1, P.maxfix, P.tab.esyn, &rec.att[1]);
+            P.records[idx] = rec;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // demod_kernel - persistent workgroups, one wavefront per run.
 //   stage 1: one lane per forwarded position: exact preamble predicate (dump1090.c:1602-1650)
 //            on LUT magnitudes; survivors compacted, in order, into a wave-private LDS list.
-//   stage 2: the wavefront demodulates the survivors one at a time, all 64 lanes cooperating
+//   stage 2: noise-gate pre-test (dump1090.c:1713-1723), four preambles per iteration, 16 lanes
+//            each: sum of |lo-hi| over the 56 and the 112 bit pairs.  A position whose sums fail
+//            the gate for BOTH message lengths ends here (that is nearly every preamble found in
+//            noise), whatever its bits are.
+//   stage 3: the wavefront demodulates the survivors one at a time, all 64 lanes cooperating
 //            (coalesced sample loads; the sequential parts of the reference become carry chains,
 //            see modes_core.h).  Positions whose first noise gate passes become records.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void demod_kernel(DemodParams P) {
     __shared__ uint16_t s_lut[129 * 129 + 1];
     __shared__ uint32_t s_list[4][64];
+    __shared__ unsigned long long s_tot[2];
     for (int i = threadIdx.x; i < 129 * 129; i += blockDim.x) s_lut[i] = P.tab.lut[i];
+    if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint8_t *iq = P.iq;
     const int64_t lo = P.lo, hi = P.hi;
+    unsigned long long tot_fwd = 0, tot_cand = 0;
 
     for (uint32_t run = blockIdx.x * 4 + wave; run < P.nruns; run += gridDim.x * 4) {
-        const uint32_t n = min(P.counts[run], P.slot_cap);
+        const uint32_t count = P.counts[run];
+        const uint32_t n = min(count, P.slot_cap);
         const uint32_t *my = P.slots + (uint64_t)run * P.slot_cap;
         uint32_t ncand = 0;
+        tot_fwd += count;
         for (uint32_t base = 0; base < n; base += 64) {
             // ---------------- stage 1 ----------------
             const uint32_t e = base + lane;
             const bool active = e < n;
             const uint32_t p = active ? my[e] : 0u;
-            bool ok = false;
-            if (active) {
-                const int64_t even = (int64_t)(p & ~1u);
-                int mm[16];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint32_t w = load_dword_guarded(iq, 2 * even + 4 * i, lo, hi);
-                    mm[2 * i] = mag_of(s_lut, w & 0xffffu);
-                    mm[2 * i + 1] = mag_of(s_lut, w >> 16);
-                }
-                const bool odd = (p & 1u) != 0;
-                int m[15];
-#pragma unroll
-                for (int t = 0; t < 15; t++) m[t] = odd ? mm[t + 1] : mm[t];
-                struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
-                ok = modes_preamble_exact(Win{m});
-            }
+            // fast path when every lane's 16-sample window is inside the span (wave-uniform test)
+            const bool in1 = !active || samples_inside((int64_t)(p & ~1u), (int64_t)(p & ~1u) + 15, lo, hi);
+            bool ok;
+            if (__all(in1)) ok = active && preamble_at<false>(iq, lo, hi, s_lut, p);
+            else            ok = active && preamble_at<true>(iq, lo, hi, s_lut, p);
             const uint64_t okb = __ballot(ok);
             const uint32_t rank = (uint32_t)__builtin_popcountll(okb & ((1ull << lane) - 1));
             if (ok) {
@@ -401,126 +527,75 @@ __global__ __launch_bounds__(256) void demod_kernel(DemodParams P) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-            // ---------------- stage 2 ----------------
-            for (uint32_t c = 0; c < nlist; c++) {
-                const int64_t pc = (int64_t)s_list[wave][c];                 // wave-uniform
-                const uint64_t g = (uint64_t)pc + P.g0;
-                const uint32_t j = (uint32_t)(g & (MODES_BLOCK_STRIDE - 1));
-                const bool two = lane < 48;
-                // lane L: pairs k1 = L, k2 = L+64 -> samples 16+2k, 17+2k; lanes 0..11 also m[-1..10]
-                const int lo1 = mag_of(s_lut, load_sample_guarded(iq, pc + 16 + 2 * lane, lo, hi));
-                const int hi1 = mag_of(s_lut, load_sample_guarded(iq, pc + 17 + 2 * lane, lo, hi));
-                const int lo2 = two ? mag_of(s_lut, load_sample_guarded(iq, pc + 144 + 2 * lane, lo, hi)) : 0;
-                const int hi2 = two ? mag_of(s_lut, load_sample_guarded(iq, pc + 145 + 2 * lane, lo, hi)) : 0;
-                const int pre = (lane < 12) ? mag_of(s_lut, load_sample_guarded(iq, pc - 1 + lane, lo, hi)) : 0;
-
-                uint8_t msg0[14], err0;
-                int sum56, sum112;
-                slice_pass(lane, lo1, hi1, lo2, hi2, msg0, &err0, &sum56, &sum112);
-                const bool gate0 = modes_len_by_df(msg0[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
-                if (!gate0) continue;                                        // dump1090.c:1723-1726: position ends
-
-                uint8_t msg1[14], err1 = err0;
-#pragma unroll
-                for (int b = 0; b < 14; b++) msg1[b] = msg0[b];
-                bool gate1 = gate0;
-                if (j != 0) {                                                // dump1090.c:1660
-                    uint32_t up, dn;
-                    const bool backward = modes_phase_factors(
-                        (uint32_t)__builtin_amdgcn_readlane(pre, 0), (uint32_t)__builtin_amdgcn_readlane(pre, 1),
-                        (uint32_t)__builtin_amdgcn_readlane(pre, 3), (uint32_t)__builtin_amdgcn_readlane(pre, 4),
-                        (uint32_t)__builtin_amdgcn_readlane(pre, 7), (uint32_t)__builtin_amdgcn_readlane(pre, 8),
-                        (uint32_t)__builtin_amdgcn_readlane(pre, 10), (uint32_t)__builtin_amdgcn_readlane(pre, 11), &up, &dn);
-                    int nlo1 = lo1, nhi1 = hi1, nlo2 = lo2, nhi2 = hi2;
-                    if (backward) {
-                        // hi of every pair is rescaled, walking from pair 111 down (dump1090.c:1519-1534)
-                        const int hu1 = (int)modes_scale((uint32_t)hi1, up), hd1 = (int)modes_scale((uint32_t)hi1, dn);
-                        const int hu2 = (int)modes_scale((uint32_t)hi2, up), hd2 = (int)modes_scale((uint32_t)hi2, dn);
-                        const modes_m128 Up = pair_ballot(lo1 > hu1, two && lo2 > hu2);
-                        modes_m128 Dn = pair_ballot(lo1 > hd1, two && lo2 > hd2);
-                        modes_m128 Pm = m128_andn(Dn, Up);
-                        Pm.hi &= ~(1ull << 47);                              // pair 111 starts the chain: c_111 = Up_111
-                        const modes_m128 cm = modes_chain_down(Up, Pm);
-                        nhi1 = m128_bit(cm, lane + 1) ? hd1 : hu1;           // pair k uses c_(k+1)
-                        nhi2 = (lane == 47) ? hu2 : (m128_bit(cm, lane + 65) ? hd2 : hu2);
-                    } else {
-                        // lo of every pair is rescaled, walking from pair 0 up (dump1090.c:1542-1556)
-                        const int lu1 = (int)modes_scale((uint32_t)lo1, up), ld1 = (int)modes_scale((uint32_t)lo1, dn);
-                        const int lu2 = (int)modes_scale((uint32_t)lo2, up), ld2 = (int)modes_scale((uint32_t)lo2, dn);
-                        const modes_m128 Up = pair_ballot(lu1 > hi1, two && lu2 > hi2);
-                        const modes_m128 Dn = pair_ballot(ld1 > hi1, two && ld2 > hi2);
-                        modes_m128 Gm = Dn, Pm = m128_andn(Up, Dn);
-                        Gm.lo = (Gm.lo & ~1ull) | (Up.lo & 1ull);            // pair 0 starts the chain: c_0 = Up_0
-                        Pm.lo &= ~1ull;
-                        const modes_m128 cm = modes_chain(Gm, Pm);
-                        nlo1 = (lane == 0) ? lu1 : (m128_bit(cm, lane - 1) ? lu1 : ld1);   // pair k uses c_(k-1)
-                        nlo2 = m128_bit(cm, lane + 63) ? lu2 : ld2;
-                    }
-                    slice_pass(lane, nlo1, nhi1, nlo2, nhi2, msg1, &err1, nullptr, nullptr);
-                    // the gate of the retry: uncorrected deltas, the retry's own length (dump1090.c:1708-1723)
-                    gate1 = modes_len_by_df(msg1[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+            // ---------------- stage 2 + 3 ----------------
+            const int grp = lane >> 4, gl = lane & 15;
+            for (uint32_t c0 = 0; c0 < nlist; c0 += 4) {
+                const uint32_t c = c0 + (uint32_t)grp;
+                const bool gact = c < nlist;
+                const int64_t pc = gact ? (int64_t)s_list[wave][c] : 0;
+                int d56 = 0, d112 = 0;
+                const bool in2 = !gact || samples_inside(pc - 1, pc + 239, lo, hi);
+                const bool fast = __all(in2);
+                if (gact) {
+                    if (fast) gate_sums<false>(iq, lo, hi, s_lut, pc, gl, &d56, &d112);
+                    else      gate_sums<true>(iq, lo, hi, s_lut, pc, gl, &d56, &d112);
                 }
-                if (lane == 0) {
-                    const uint32_t idx = atomicAdd(P.rec_counter, 1u);
-                    if (idx < P.max_records) {
-                        modes_record rec;
-                        rec.block = (uint32_t)(g / MODES_BLOCK_STRIDE);
-                        rec.j = j;
-                        finish_attempt(msg0, err0, true, P.maxfix, P.tab.esyn, &rec.att[0]);
-                        finish_attempt(msg1, err1, gate1, P.maxfix, P.tab.esyn, &rec.att[1]);
-                        P.records[idx] = rec;
-                    }
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) {                     // reduce within each 16-lane group
+                    d56 += __shfl_xor(d56, off, 64);
+                    d112 += __shfl_xor(d112, off, 64);
+                }
+                const bool may_pass = gact && (d112 / 56 >= 2550 || d56 / 28 >= 2550);
+                uint64_t todo = __ballot(may_pass && gl == 0);
+                while (todo) {
+                    const int leader = __builtin_ctzll(todo);                // lane 0, 16, 32 or 48
+                    todo &= todo - 1;
+                    const int64_t pcs = (int64_t)s_list[wave][c0 + (uint32_t)(leader >> 4)];
+                    const int s56 = __builtin_amdgcn_readlane(d56, leader), s112 = __builtin_amdgcn_readlane(d112, leader);
+                    if (fast) demod_full<false>(P, s_lut, lane, pcs, s56, s112);
+                    else      demod_full<true>(P, s_lut, lane, pcs, s56, s112);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        tot_cand += ncand;
         if (lane == 0) P.cand_counts[run] = ncand;
+    }
+    // totals: one pair of atomics per workgroup
+    if (lane == 0) {
+        atomicAdd(&s_tot[0], tot_fwd);
+        atomicAdd(&s_tot[1], tot_cand);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&P.hdr->n_forwarded, s_tot[0]);
+        atomicAdd(&P.hdr->n_preambles, s_tot[1]);
     }
 }
 
 // ------------------------------------------------------------------------------------
-// finalize_kernel - one workgroup: totals + exclusive prefix of the per-run preamble
-// counts (for compaction of the candidate list when the host asked for it).
+// prefix_kernel - one workgroup: exclusive prefix of the per-run preamble counts, only needed
+// when the host asked for the dense candidate list (keep_candidates, i.e. --stats).
 // ------------------------------------------------------------------------------------
-struct ResultHeader {
-    uint64_t n_forwarded;
-    uint64_t n_preambles;
-    uint32_t n_records;
-    uint32_t overflow;
-};
-
-__global__ __launch_bounds__(1024) void finalize_kernel(const uint32_t *counts, const uint32_t *cand_counts, uint32_t nruns,
-                                                        const uint32_t *rec_counter, const uint32_t *flags,
-                                                        uint64_t *cand_offsets, ResultHeader *hdr) {
-    __shared__ uint64_t part_f[1024];
-    __shared__ uint64_t part_c[1024];
+__global__ __launch_bounds__(1024) void prefix_kernel(const uint32_t *cand_counts, uint32_t nruns, uint64_t *cand_offsets) {
+    __shared__ uint64_t part[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t per = (nruns + 1023) / 1024;
     const uint32_t lo = min(t * per, nruns), hi = min(lo + per, nruns);
-    uint64_t f = 0, c = 0;
-    for (uint32_t r = lo; r < hi; r++) { f += counts[r]; c += cand_counts[r]; }
-    part_f[t] = f;
-    part_c[t] = c;
+    uint64_t c = 0;
+    for (uint32_t r = lo; r < hi; r++) c += cand_counts[r];
+    part[t] = c;
     __syncthreads();
     for (uint32_t step = 1; step < 1024; step <<= 1) {       // Hillis-Steele inclusive scan
-        uint64_t af = 0, ac = 0;
-        if (t >= step) { af = part_f[t - step]; ac = part_c[t - step]; }
+        uint64_t add = 0;
+        if (t >= step) add = part[t - step];
         __syncthreads();
-        part_f[t] += af;
-        part_c[t] += ac;
+        part[t] += add;
         __syncthreads();
     }
-    if (cand_offsets) {
-        uint64_t off = part_c[t] - c;                        // exclusive prefix of this thread's first run
-        for (uint32_t r = lo; r < hi; r++) { cand_offsets[r] = off; off += cand_counts[r]; }
-    }
-    if (t == 1023) {
-        hdr->n_forwarded = part_f[1023];
-        hdr->n_preambles = part_c[1023];
-        hdr->n_records = *rec_counter;
-        hdr->overflow = flags[0];
-    }
+    uint64_t off = part[t] - c;                              // exclusive prefix of this thread's first run
+    for (uint32_t r = lo; r < hi; r++) { cand_offsets[r] = off; off += cand_counts[r]; }
 }
 
 __global__ __launch_bounds__(256) void compact_candidates_kernel(const uint32_t *cand_slots, const uint32_t *cand_counts,
@@ -598,7 +673,6 @@ struct modes_gpu {
     uint64_t *d_cand_offsets = nullptr;
     uint64_t *d_cand_dense = nullptr; size_t cand_dense_elems = 0;
     modes_record *d_records = nullptr;
-    uint32_t *d_small = nullptr;      // [0] rec_counter, [1] flags
     ResultHeader *d_hdr = nullptr;
 
     ResultHeader *h_hdr = nullptr;    // pinned
@@ -685,7 +759,6 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     CREATE_TRY(hipMemcpy(ctx->d_lut, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(ctx->d_esyn, esyn, sizeof esyn, hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_records), (size_t)ctx->cfg.max_records * sizeof(modes_record)));
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_small), 16));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hdr), sizeof(ResultHeader)));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hdr), sizeof(ResultHeader), hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_records), (size_t)ctx->cfg.max_records * sizeof(modes_record),
@@ -700,7 +773,7 @@ void modes_gpu_destroy(modes_gpu *ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     void *dev[] = {ctx->d_lut, ctx->d_esyn, ctx->d_slots, ctx->d_cand_slots, ctx->d_counts, ctx->d_cand_offsets,
-                   ctx->d_cand_dense, ctx->d_records, ctx->d_small, ctx->d_hdr, ctx->d_stage};
+                   ctx->d_cand_dense, ctx->d_records, ctx->d_hdr, ctx->d_stage};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (ctx->h_hdr) (void)hipHostFree(ctx->h_hdr);
@@ -818,7 +891,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     }
     uint32_t *d_counts = ctx->d_counts, *d_cand_counts = ctx->d_counts + nruns;
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_small, 0, 16, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_hdr, 0, sizeof(ResultHeader), st));
 
     ScanParams sp{};
     sp.iq = base;
@@ -833,7 +906,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     sp.slot_cap = cap;
     sp.slots = ctx->d_slots;
     sp.counts = d_counts;
-    sp.flags = ctx->d_small + 1;
+    sp.hdr = ctx->d_hdr;
 
     DemodParams dp{};
     dp.iq = sp.iq;
@@ -849,7 +922,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     dp.cand_slots = ctx->cfg.keep_candidates ? ctx->d_cand_slots : nullptr;
     dp.cand_counts = d_cand_counts;
     dp.records = ctx->d_records;
-    dp.rec_counter = ctx->d_small;
+    dp.hdr = ctx->d_hdr;
     dp.max_records = ctx->cfg.max_records;
 
     const dim3 grid((nruns + kScanWaves - 1) / kScanWaves);
@@ -857,8 +930,8 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     hipLaunchKernelGGL(scan_kernel, grid, dim3(kScanWaves * kWave), 0, st, sp);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((nruns + 3) / 4, 1024u)), dim3(256), 0, st, dp);
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, d_counts, d_cand_counts, nruns, ctx->d_small,
-                       ctx->d_small + 1, ctx->cfg.keep_candidates ? ctx->d_cand_offsets : nullptr, ctx->d_hdr);
+    if (ctx->cfg.keep_candidates)
+        hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st, d_cand_counts, nruns, ctx->d_cand_offsets);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hdr, ctx->d_hdr, sizeof(ResultHeader), hipMemcpyDeviceToHost, st));
