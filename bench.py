@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--mib", type=int, default=1024, help="MiB of I/Q per GPU (default: the 1 GiB workload)")
     ap.add_argument("--cpu-mib", type=int, default=1024, help="MiB of the workload timed on the CPU baseline")
     ap.add_argument("--run-chunks", type=int, default=0)
+    ap.add_argument("--scan-variant", type=int, default=0, help="0 = production scan kernel, 1 = fused single-pass scan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -101,7 +102,7 @@ def main():
         nblocks += 1
     lo, hi = shard_byte_range(first_block, nblocks, total)
 
-    demod = Demodulator(device=local, fix=False, run_chunks=args.run_chunks)
+    demod = Demodulator(device=local, fix=False, run_chunks=args.run_chunks, scan_variant=args.scan_variant)
     iq = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
     demod.synth_noise(iq, first_byte=lo, seed=20260922, sigma_q16=941)
     if hi == total:

@@ -128,8 +128,13 @@ MODES_HD uint32_t pk_shr1(uint32_t a) { return MODES_UN(MODES_PK(a) >> (unsigned
 /* Four bytes I0 Q0 I1 Q1 (little-endian dword) -> packed (s0, s1). */
 MODES_HD uint32_t modes_power_pair(uint32_t w) {
     const uint32_t k127 = 0x007F007Fu;
-    uint32_t ip = w & 0x00FF00FFu;              /* (I0, I1) - v_perm / v_and       */
-    uint32_t qp = (w >> 8) & 0x00FF00FFu;       /* (Q0, Q1)                        */
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t ip = __builtin_amdgcn_perm(0u, w, 0x0c020c00u);   /* (I0, I1): one v_perm_b32 each */
+    uint32_t qp = __builtin_amdgcn_perm(0u, w, 0x0c030c01u);   /* (Q0, Q1)                      */
+#else
+    uint32_t ip = w & 0x00FF00FFu;              /* (I0, I1) */
+    uint32_t qp = (w >> 8) & 0x00FF00FFu;       /* (Q0, Q1) */
+#endif
     uint32_t ai = pk_sub(ip, k127), aq = pk_sub(qp, k127);   /* mod 2^16; squares are exact */
     return pk_add(pk_mul(ai, ai), pk_mul(aq, aq));            /* v_pk_mul_lo + v_pk_mad      */
 }
@@ -177,6 +182,48 @@ MODES_HD uint32_t modes_scan8(const uint32_t E[12]) {
     }
     return hit;
 }
+/* The ordering half of modes_scan8 only: r[q] holds, for positions 2q (low half) and 2q+1 (high
+ * half), a non-zero value iff the ten relations of dump1090.c:1602-1611 hold.  ~60 VALU ops. */
+MODES_HD void modes_order8(const uint32_t E[12], uint32_t r[4]) {
+    uint32_t O[11];
+#pragma unroll
+    for (int t = 0; t < 11; t++) O[t] = (E[t] >> 16) | (E[t + 1] << 16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t x0 = E[q], x1 = O[q], x2 = E[q + 1], x3 = O[q + 1], x4 = E[q + 2], x5 = O[q + 2],
+                       x6 = E[q + 3], x7 = O[q + 3], x8 = E[q + 4], x9 = O[q + 4];
+        const uint32_t m13 = pk_max(x1, x3);
+        uint32_t v = pk_subs(x0, pk_max(pk_max(m13, pk_max(x4, x5)), x6));   /* s0 > s1,s3,s4,s5,s6 */
+        v = pk_min(v, pk_subs(x2, m13));                                       /* s2 > s1,s3          */
+        v = pk_min(v, pk_subs(pk_min(x7, x9), x8));                            /* s7 > s8, s9 > s8    */
+        v = pk_min(v, pk_subs(x9, x6));                                        /* s9 > s6             */
+        r[q] = v;
+    }
+}
+
+/* modes_order8 with the odd-aligned pairs O[t] = (s[2t+1], s[2t+2]), t = 0..9, supplied by the
+ * caller (the production scan kernel reads them from a second LDS ring instead of building them). */
+MODES_HD void modes_order8_eo(const uint32_t E[11], const uint32_t O[10], uint32_t r[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t x0 = E[q], x1 = O[q], x2 = E[q + 1], x3 = O[q + 1], x4 = E[q + 2], x5 = O[q + 2],
+                       x6 = E[q + 3], x7 = O[q + 3], x8 = E[q + 4], x9 = O[q + 4];
+        const uint32_t m13 = pk_max(x1, x3);
+        uint32_t v = pk_subs(x0, pk_max(pk_max(m13, pk_max(x4, x5)), x6));
+        v = pk_min(v, pk_subs(x2, m13));
+        v = pk_min(v, pk_subs(pk_min(x7, x9), x8));
+        v = pk_min(v, pk_subs(x9, x6));
+        r[q] = v;
+    }
+}
+
+/* Necessary condition for the level tests of dump1090.c:1624-1642 on powers, in plain integers
+ * (the beta pass runs it on one position per lane):  9 * max(quiet) < s0 + s2 + s7 + s9.
+ * Derivation in the comment of modes_scan8. */
+MODES_HD bool modes_level_bound(uint32_t s0, uint32_t s2, uint32_t s7, uint32_t s9, uint32_t quiet_max) {
+    return 9u * quiet_max < s0 + s2 + s7 + s9;
+}
+
 /* position i of modes_scan8's mask */
 MODES_HD uint32_t modes_scan8_bit(int i) { return 1u << (((i & 1) << 4) + (i >> 1)); }
 #endif /* __clang__ */

@@ -171,7 +171,7 @@ struct ScanParams {
     ResultHeader *hdr;
 };
 
-__global__ __launch_bounds__(kScanWaves * kWave) void scan_kernel(ScanParams P) {
+__global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanParams P) {
     // wave-private ring: 2 chunk slots x 256 dwords (512 powers each)
     __shared__ __attribute__((aligned(16))) uint32_t ring_all[kScanWaves][512];
     const int lane = threadIdx.x & 63;
@@ -272,6 +272,210 @@ struct DemodParams {
     ResultHeader *hdr;
     uint32_t max_records;
 };
+
+// ------------------------------------------------------------------------------------
+// scan_kernel (production, scan_variant 0) - same work decomposition as scan_fused_kernel, but
+// split in two passes because the stage is VALU-bound (packed-u16 VALU issues at 16 lanes per
+// clock per SIMD on gfx950: ~90 % VALU-busy in the fused kernel, profiles/r01a):
+//
+//   alpha  every position, packed u16: only the ten ORDERING relations (exact on s).  1.4 % of
+//          positions survive; lanes owning a survivor push {their 22-sample window, the four
+//          packed results, the window's position} into a wave-private LDS queue.
+//   beta   whenever 64 entries are queued: one lane per entry, plain 32-bit integers: the level
+//          bound 9*max(quiet) < s0+s2+s7+s9 for the survivors of that entry.  Dense lanes, so the
+//          level test costs ~10x less per chunk than evaluating it packed at every position.
+//
+// Forwarded positions of a run are no longer in ascending order (the host sorts the candidate
+// list when it is requested; records are sorted anyway).
+// ------------------------------------------------------------------------------------
+constexpr int kQCap = 128;            // queue entries per wavefront (power of two, >= 2 * 64)
+constexpr int kQStride = 17;          // dwords per entry: 11 window + 4 results + 1 position + 1 pad (odd: no bank conflicts)
+constexpr int kScan2Waves = 2;
+
+__device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *queue, uint32_t qhead, uint32_t nb, int lane,
+                                          uint32_t *my_slots, uint32_t &count) {
+    const bool act = (uint32_t)lane < nb;
+    const uint32_t *e = queue + ((qhead + (uint32_t)lane) & (kQCap - 1)) * kQStride;
+    uint32_t m8 = 0, p0 = 0;
+    if (act) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t r = e[11 + q];
+            m8 |= ((r & 0xffffu) ? 1u : 0u) << (2 * q);
+            m8 |= ((r >> 16) ? 1u : 0u) << (2 * q + 1);
+        }
+        p0 = e[15];
+    }
+    const uint16_t *w = reinterpret_cast<const uint16_t *>(e);
+    uint64_t pending = __ballot(m8 != 0);
+    while (pending) {
+        bool fwd = false;
+        uint32_t p = 0;
+        if (m8) {
+            const int i = __builtin_ctz(m8);
+            m8 &= m8 - 1;
+            const uint16_t *x = w + i;
+            const uint32_t s0 = x[0], s2 = x[2], s4 = x[4], s5 = x[5], s7 = x[7], s9 = x[9], s11 = x[11], s12 = x[12],
+                           s13 = x[13], s14 = x[14];
+            const uint32_t quiet = max(max(max(s4, s5), max(s11, s12)), max(s13, s14));
+            p = p0 + (uint32_t)i;                                            // wraps for the 16 look-back positions of chunk 0
+            fwd = modes_level_bound(s0, s2, s7, s9, quiet) && (int64_t)p >= P.p_begin && (int64_t)p < P.p_end &&
+                  (((uint64_t)p + P.g0) & (MODES_BLOCK_STRIDE - 1)) < MODES_BLOCK_POSITIONS;   // j < 131070, :1593
+        }
+        const uint64_t fb = __ballot(fwd);
+        if (fwd) {
+            const uint32_t idx = count + (uint32_t)__builtin_popcountll(fb & ((1ull << lane) - 1));
+            if (idx < P.slot_cap) my_slots[idx] = p;
+        }
+        count += (uint32_t)__builtin_popcountll(fb);
+        pending = __ballot(m8 != 0);
+    }
+}
+
+// 16 bytes of chunk data at 32-bit offset `off` from the run's (wave-uniform) base pointer.
+template <bool GUARD>
+__device__ __forceinline__ uint4 load_chunk16(const uint8_t *run_base, int32_t off, const uint8_t *iq, int64_t base_off,
+                                              int64_t lo, int64_t hi) {
+    if (!GUARD) return *reinterpret_cast<const uint4 *>(run_base + off);
+    return load_iq16(iq, base_off + off, lo, hi);
+}
+
+// GUARD: the run touches an end of the span (byte-wise bounds checks on every load).
+// ORING: odd-aligned sample pairs come from a second LDS ring filled by the producing lane
+//        (1 DPP + 4 v_perm per lane) instead of 11 v_perm per consuming lane.
+template <bool GUARD, bool ORING>
+__device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int lane, uint32_t *ring, uint32_t *oring,
+                                         uint32_t *queue) {
+    const int64_t c0 = (int64_t)run * P.run_chunks;
+    const int64_t c1 = (c0 + (int64_t)P.run_chunks < (int64_t)P.nchunks) ? c0 + (int64_t)P.run_chunks : (int64_t)P.nchunks;
+    const uint8_t *iq = P.iq;
+    const int64_t lo = P.lo, hi = P.hi;
+    const int64_t base_off = c0 * kChunkBytes;
+    const uint8_t *run_base = iq + base_off;                                 // wave-uniform
+    const int32_t lane_off = lane * 16;
+
+    auto produce = [&](int64_t c, const uint4 &raw, bool all_lanes) {
+        const uint4 s = power16(raw);
+        const uint32_t slot = (uint32_t)((c & 1) * 256) + (uint32_t)lane * 4u;
+        if (all_lanes || lane >= 62) *reinterpret_cast<uint4 *>(&ring[slot]) = s;
+        if (ORING) {
+            // next lane's first pair (lane 63 gets 0: its last odd pair is never read)
+            const uint32_t nx = __builtin_amdgcn_update_dpp(0u, s.x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            const uint4 o = make_uint4((s.x >> 16) | (s.y << 16), (s.y >> 16) | (s.z << 16), (s.z >> 16) | (s.w << 16),
+                                       (s.w >> 16) | (nx << 16));
+            if (all_lanes || lane >= 62) *reinterpret_cast<uint4 *>(&oring[slot]) = o;
+        }
+    };
+
+    // prologue: the last 16 samples of chunk c0-1 (lanes 62, 63; lane 63's last odd pair needs the
+    // first sample of chunk c0, which the first iteration's odd pairs do not cover - it is only
+    // read through E, never through O, see window geometry below)
+    {
+        const uint4 raw = load_chunk16<true>(run_base, -kChunkBytes + lane_off, iq, base_off, lo, hi);
+        produce(c0 - 1, raw, false);
+    }
+    uint4 cur = load_chunk16<GUARD>(run_base, lane_off, iq, base_off, lo, hi);
+    uint4 nxt = load_chunk16<GUARD>(run_base, kChunkBytes + lane_off, iq, base_off, lo, hi);
+
+    uint32_t count = 0, qhead = 0, qn = 0;                                   // wave-uniform
+    uint32_t *my_slots = P.slots + (uint64_t)run * P.slot_cap;
+    int32_t off = lane_off;                                                  // offset of chunk c for this lane
+
+    for (int64_t c = c0; c < c1; c++, off += kChunkBytes) {
+        const uint4 raw = cur;
+        cur = nxt;
+        nxt = load_chunk16<GUARD>(run_base, off + 2 * kChunkBytes, iq, base_off, lo, hi);
+
+        produce(c, raw, true);
+        // LDS operations of one wavefront execute in issue order: the reads below see the writes
+        // above without a barrier; only the compiler must not reorder them.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // window of 24 powers starting at position 512c - 16 + 8*lane (dword index mod 512)
+        const uint32_t d0 = (uint32_t)(((c & 1) * 256) + 512 - 8 + lane * 4) & 511u;
+        const uint32_t d1 = (d0 + 4) & 511u, d2 = (d0 + 8) & 511u;
+        uint32_t E[12], r[4];
+        {
+            const uint4 a = *reinterpret_cast<const uint4 *>(&ring[d0]);
+            const uint4 b = *reinterpret_cast<const uint4 *>(&ring[d1]);
+            const uint4 d = *reinterpret_cast<const uint4 *>(&ring[d2]);
+            E[0] = a.x; E[1] = a.y; E[2] = a.z; E[3] = a.w;
+            E[4] = b.x; E[5] = b.y; E[6] = b.z; E[7] = b.w;
+            E[8] = d.x; E[9] = d.y; E[10] = d.z; E[11] = d.w;
+        }
+        if (ORING) {
+            uint32_t O[12];
+            const uint4 a = *reinterpret_cast<const uint4 *>(&oring[d0]);
+            const uint4 b = *reinterpret_cast<const uint4 *>(&oring[d1]);
+            const uint4 d = *reinterpret_cast<const uint4 *>(&oring[d2]);
+            O[0] = a.x; O[1] = a.y; O[2] = a.z; O[3] = a.w;
+            O[4] = b.x; O[5] = b.y; O[6] = b.z; O[7] = b.w;
+            O[8] = d.x; O[9] = d.y; O[10] = d.z; O[11] = d.w;
+            // The odd pair that straddles two producing lanes' chunks of different iterations (lane 63 of
+            // chunk c-1 -> dword 255 of its slot) is window index t = 7 - 4*lane... only lanes 0 and 1 can
+            // see it, at O[7] (lane 0) / O[3] (lane 1): rebuild it from E.
+            if (lane == 0) O[7] = (E[7] >> 16) | (E[8] << 16);
+            if (lane == 1) O[3] = (E[3] >> 16) | (E[4] << 16);
+            modes_order8_eo(E, O, r);
+        } else {
+            modes_order8(E, r);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- alpha survivors -> queue ----
+        const bool any = ((r[0] | r[1]) | (r[2] | r[3])) != 0;
+        const uint64_t hb = __ballot(any);
+        if (hb) {
+            if (any) {
+                const uint32_t slot = (qhead + qn + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1))) & (kQCap - 1);
+                uint32_t *e = queue + slot * kQStride;
+#pragma unroll
+                for (int t = 0; t < 11; t++) e[t] = E[t];
+#pragma unroll
+                for (int q = 0; q < 4; q++) e[11 + q] = r[q];
+                e[15] = (uint32_t)(c * kChunkSamples - kLookback + 8 * lane);
+            }
+            qn += (uint32_t)__builtin_popcountll(hb);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- beta: level bound for 64 queued entries at a time ----
+            if (qn >= 64) {
+                scan_beta(P, queue, qhead, 64, lane, my_slots, count);
+                qhead = (qhead + 64) & (kQCap - 1);
+                qn -= 64;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (qn) scan_beta(P, queue, qhead, qn, lane, my_slots, count);
+    if (lane == 0) {
+        P.counts[run] = count;
+        if (count > P.slot_cap) atomicOr(&P.hdr->overflow, 1u);
+    }
+}
+
+template <bool ORING>
+__global__ __launch_bounds__(kScan2Waves * kWave) void scan_kernel(ScanParams P) {
+    __shared__ __attribute__((aligned(16))) uint32_t ring_all[kScan2Waves][512];
+    __shared__ __attribute__((aligned(16))) uint32_t oring_all[ORING ? kScan2Waves : 1][ORING ? 512 : 4];
+    __shared__ uint32_t queue_all[kScan2Waves][kQCap * kQStride];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t run = blockIdx.x * kScan2Waves + wave;
+    if (run >= P.nruns) return;
+    // Runs whose loads (chunks c0-1 .. c1+1, the prefetch runs two chunks ahead) all lie inside the
+    // span take the unguarded instantiation; that is every run except the first and the last few.
+    const int64_t c0 = (int64_t)run * P.run_chunks;
+    const int64_t first = (c0 - 1) * kChunkBytes, last = (c0 + (int64_t)P.run_chunks + 2) * kChunkBytes;
+    uint32_t *oring = ORING ? oring_all[wave] : nullptr;
+    if (first >= P.lo && last <= P.hi) scan_run<false, ORING>(P, run, lane, ring_all[wave], oring, queue_all[wave]);
+    else                               scan_run<true, ORING>(P, run, lane, ring_all[wave], oring, queue_all[wave]);
+}
 
 // Sample / dword loads for the demod kernel.  GUARD = false: plain loads (the caller has checked,
 // wave-uniformly, that every byte it will touch lies inside the span) - no branches, so the loads
@@ -839,7 +1043,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     if (span->nblocks == 0) return fail(ctx, MODES_ERR_ARG, "detect: nblocks == 0");
     if ((reinterpret_cast<uintptr_t>(span->iq) & 1) != 0) return fail(ctx, MODES_ERR_ARG, "detect: iq must be 2-byte aligned");
     if (span->stream_byte0 & 1) return fail(ctx, MODES_ERR_ARG, "detect: stream_byte0 must be even");
-    if (span->nbytes > (1ull << 33)) return fail(ctx, MODES_ERR_ARG, "detect: at most 8 GiB per call");
+    if (span->nbytes > (1ull << 33) - 65536) return fail(ctx, MODES_ERR_ARG, "detect: at most 8 GiB - 64 KiB per call");
     // buffer `first_block` starts 476 bytes before stream byte 262144*first_block: the span must
     // reach back that far (or start at the beginning of the stream, where the carry is 127s).
     const uint64_t need0 = span->first_block * (uint64_t)MODES_DATA_LEN;
@@ -925,9 +1129,13 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     dp.hdr = ctx->d_hdr;
     dp.max_records = ctx->cfg.max_records;
 
-    const dim3 grid((nruns + kScanWaves - 1) / kScanWaves);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-    hipLaunchKernelGGL(scan_kernel, grid, dim3(kScanWaves * kWave), 0, st, sp);
+    if (ctx->cfg.scan_variant == 2)
+        hipLaunchKernelGGL(scan_kernel<true>, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st, sp);
+    else if (ctx->cfg.scan_variant == 1)
+        hipLaunchKernelGGL(scan_fused_kernel, dim3((nruns + kScanWaves - 1) / kScanWaves), dim3(kScanWaves * kWave), 0, st, sp);
+    else
+        hipLaunchKernelGGL(scan_kernel<false>, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st, sp);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((nruns + 3) / 4, 1024u)), dim3(256), 0, st, dp);
     if (ctx->cfg.keep_candidates)
@@ -982,6 +1190,8 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
         ctx->h_cands.clear();
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    // within a run the production scan forwards positions in queue order: restore stream order
+    std::sort(ctx->h_cands.begin(), ctx->h_cands.end());
     // records were appended in completion order: put them in stream order
     std::sort(ctx->h_records, ctx->h_records + hdr.n_records, [](const modes_record &a, const modes_record &b) {
         return a.block != b.block ? a.block < b.block : a.j < b.j;

@@ -161,13 +161,13 @@ def test_tuning_parameters_do_not_change_results(torch_cuda, streams):
     data = streams["frames"]
     iq = to_dev(torch_cuda, data)
     base = None
-    for rc in (0, 1, 3, 16, 64):
-        d = Demodulator(keep_candidates=True, run_chunks=rc)
+    for rc, variant in ((0, 0), (1, 0), (3, 0), (16, 0), (64, 0), (0, 1), (5, 1), (64, 1)):
+        d = Demodulator(keep_candidates=True, run_chunks=rc, scan_variant=variant)
         d.detect(iq)
         recs, cands, _ = d.fetch()
         if base is None:
             base = (recs, cands)
-        assert np.array_equal(recs, base[0]) and np.array_equal(cands, base[1]), rc
+        assert np.array_equal(recs, base[0]) and np.array_equal(cands, base[1]), (rc, variant)
         d.close()
     d = Demodulator(run_chunks=64, slot_cap=1)          # far too few slots: must fail, not drop
     d.detect(iq)
