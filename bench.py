@@ -31,6 +31,19 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def measured_traffic(mib):
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/traffic_latest.json,
+    written by tools/profile.sh on this same default workload); None for any other workload."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if mib != 1024 or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return int(json.load(f)["scan_kernel"]["hbm_read_bytes_per_launch"])
+    except (KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(iq, nbytes_sample):
     """Reference single-threaded C path on the host cores, on the first nbytes_sample bytes of the
     same workload.  Checker code (oracle/) is used here only as the thing being timed."""
@@ -160,7 +173,7 @@ def main():
         "preambles_per_step_rank0": int(n_pre),
         "kernel_ms": {"scan": round(scan_avg_ms, 4), "demod_finalize": round(float(np.mean(demod_ms)), 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.mib),
                      "kernel": "scan_kernel", "algorithmic_bytes_per_launch": int(hi - lo)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

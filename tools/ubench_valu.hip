@@ -21,7 +21,13 @@ constexpr int ITER = 4096;
         uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13,  \
                  a6 = a0 * 17, a7 = a0 * 19;                                                            \
         uint32_t b = seed * 77 + threadIdx.x, c = seed ^ 0x12345;                                       \
-        for (int i = 0; i < ITER; i++) {                                                                \
+        for (int i = 0; i < ITER / 4; i++) {                                                            \
+            ASM_TEMPLATE(a0) ASM_TEMPLATE(a1) ASM_TEMPLATE(a2) ASM_TEMPLATE(a3)                          \
+            ASM_TEMPLATE(a4) ASM_TEMPLATE(a5) ASM_TEMPLATE(a6) ASM_TEMPLATE(a7)                          \
+            ASM_TEMPLATE(a0) ASM_TEMPLATE(a1) ASM_TEMPLATE(a2) ASM_TEMPLATE(a3)                          \
+            ASM_TEMPLATE(a4) ASM_TEMPLATE(a5) ASM_TEMPLATE(a6) ASM_TEMPLATE(a7)                          \
+            ASM_TEMPLATE(a0) ASM_TEMPLATE(a1) ASM_TEMPLATE(a2) ASM_TEMPLATE(a3)                          \
+            ASM_TEMPLATE(a4) ASM_TEMPLATE(a5) ASM_TEMPLATE(a6) ASM_TEMPLATE(a7)                          \
             ASM_TEMPLATE(a0) ASM_TEMPLATE(a1) ASM_TEMPLATE(a2) ASM_TEMPLATE(a3)                          \
             ASM_TEMPLATE(a4) ASM_TEMPLATE(a5) ASM_TEMPLATE(a6) ASM_TEMPLATE(a7)                          \
         }                                                                                               \
@@ -50,6 +56,78 @@ constexpr int ITER = 4096;
 #define I_CMP(x)      asm volatile("v_cmp_gt_u32 vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(x) : "v"(b) : "vcc");
 #define I_MOVDPP(x)   asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
 #define I_SUBSDWA(x)  asm volatile("v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(x) : "v"(b));
+
+#define I_CMPVCC(x)   asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc");
+#define I_CMPSG(x)    asm volatile("v_cmp_gt_u32 s[20:21], %0, %1" : : "v"(x), "v"(b) : "s20", "s21");
+#define I_CMPU16(x)   asm volatile("v_cmp_gt_u16 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc");
+#define I_ADDC(x)     asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) : : "vcc");
+#define I_ADDCSG(x)   asm volatile("v_addc_co_u32 %0, s[22:23], %0, %0, s[20:21]" : "+v"(x) : : "s22", "s23");
+#define I_MAXU32(x)   asm volatile("v_max_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define I_MINU32(x)   asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define I_SUBU32(x)   asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define I_LSHR(x)     asm volatile("v_lshrrev_b32 %0, 16, %0" : "+v"(x));
+#define I_OR(x)       asm volatile("v_or_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define I_CNDMASK(x)  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b) : "vcc");
+#define I_MAXF32(x)   asm volatile("v_max_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define I_SUBF32C(x)  asm volatile("v_sub_f32 %0, %0, %1 clamp" : "+v"(x) : "v"(b));
+#define I_MULF32(x)   asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define I_MACF32(x)   asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define I_FMAC(x)     asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(x) : "v"(b), "v"(c));
+#define I_CVTUB(x)    asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(x));
+#define I_CVTU32(x)   asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x));
+#define I_MULU24(x)   asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x) : "v"(b));
+#define I_BFI(x)      asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(x) : "v"(b), "v"(c));
+#define I_BFE(x)      asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(x));
+#define I_ADD3(x)     asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define I_LSHLADD(x)  asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x) : "v"(b));
+#define I_ANDOR(x)    asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define I_SUBU16(x)   asm volatile("v_sub_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define I_MULLOU16(x) asm volatile("v_mul_lo_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define I_MADU16(x)   asm volatile("v_mad_u16 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define I_XOR(x)      asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define I_MAXI32(x)   asm volatile("v_max_i32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define I_DOT4I(x)    asm volatile("v_dot4_i32_i8 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define I_DOT2(x)     asm volatile("v_dot2_u32_u16 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define I_V_S1(x)     asm volatile("v_max_u32 %0, %0, %1\n s_and_b64 s[20:21], s[22:23], s[24:25]" : "+v"(x) : "v"(b) : "s20", "s21", "scc");
+#define I_V_S2(x)     asm volatile("v_max_u32 %0, %0, %1\n s_and_b64 s[20:21], s[22:23], s[24:25]\n s_andn2_b64 s[26:27], s[22:23], s[24:25]" : "+v"(x) : "v"(b) : "s20", "s21", "s26", "s27", "scc");
+#define I_CMPSG_S1(x) asm volatile("v_cmp_gt_u32 s[20:21], %0, %1\n s_and_b64 s[26:27], s[22:23], s[24:25]" : : "v"(x), "v"(b) : "s20", "s21", "s26", "s27", "scc");
+#define I_CMP_ADDC2(x) asm volatile("v_cmp_gt_u32 vcc, %1, %0\n v_max_u32 %0, %0, %1\n v_addc_co_u32 %2, vcc, %2, %2, vcc" : "+v"(x) : "v"(b), "v"(c) : "vcc");
+
+KERNEL(k_cmpvcc, I_CMPVCC)
+KERNEL(k_cmpsg, I_CMPSG)
+KERNEL(k_cmpu16, I_CMPU16)
+KERNEL(k_addc, I_ADDC)
+KERNEL(k_addcsg, I_ADDCSG)
+KERNEL(k_maxu32, I_MAXU32)
+KERNEL(k_minu32, I_MINU32)
+KERNEL(k_subu32, I_SUBU32)
+KERNEL(k_lshr, I_LSHR)
+KERNEL(k_or, I_OR)
+KERNEL(k_cndmask, I_CNDMASK)
+KERNEL(k_maxf32, I_MAXF32)
+KERNEL(k_subf32c, I_SUBF32C)
+KERNEL(k_mulf32, I_MULF32)
+KERNEL(k_macf32, I_MACF32)
+KERNEL(k_fmac, I_FMAC)
+KERNEL(k_cvtub, I_CVTUB)
+KERNEL(k_cvtu32, I_CVTU32)
+KERNEL(k_mulu24, I_MULU24)
+KERNEL(k_bfi, I_BFI)
+KERNEL(k_bfe, I_BFE)
+KERNEL(k_add3, I_ADD3)
+KERNEL(k_lshladd, I_LSHLADD)
+KERNEL(k_andor, I_ANDOR)
+KERNEL(k_subu16, I_SUBU16)
+KERNEL(k_mullou16, I_MULLOU16)
+KERNEL(k_madu16, I_MADU16)
+KERNEL(k_xor, I_XOR)
+KERNEL(k_maxi32, I_MAXI32)
+KERNEL(k_dot4i, I_DOT4I)
+KERNEL(k_dot2, I_DOT2)
+KERNEL(k_v_s1, I_V_S1)
+KERNEL(k_v_s2, I_V_S2)
+KERNEL(k_cmpsg_s1, I_CMPSG_S1)
+KERNEL(k_cmp_addc2, I_CMP_ADDC2)
 
 KERNEL(k_add, I_ADD)
 KERNEL(k_and, I_AND)
@@ -158,8 +236,20 @@ int main() {
               {"v_pk_fma_f16", k_pkfma16, 8}, {"v_mad_u32_u24", k_madu24, 8}, {"v_dot4_u32_u8", k_dot4, 8},
               {"v_lshl_or_b32", k_lshlor, 8}, {"v_sad_u8", k_sadu8, 8}, {"v_cmp+v_addc", k_cmp_addc, 16},
               {"v_mov_dpp row_shr", k_movdpp, 8}, {"v_sub_u32_sdwa", k_subsdwa, 8},
+              {"v_cmp_gt_u32 vcc", k_cmpvcc, 8}, {"v_cmp_gt_u32 sgpr", k_cmpsg, 8}, {"v_cmp_gt_u16 vcc", k_cmpu16, 8},
+              {"v_addc_co_u32 vcc", k_addc, 8}, {"v_addc_co_u32 sgpr", k_addcsg, 8}, {"v_max_u32", k_maxu32, 8},
+              {"v_min_u32", k_minu32, 8}, {"v_sub_u32", k_subu32, 8}, {"v_lshrrev_b32", k_lshr, 8}, {"v_or_b32", k_or, 8},
+              {"v_cndmask_b32", k_cndmask, 8}, {"v_max_f32", k_maxf32, 8}, {"v_sub_f32 clamp", k_subf32c, 8},
+              {"v_mul_f32", k_mulf32, 8}, {"v_mac_f32", k_macf32, 8}, {"v_fma_f32 clamp", k_fmac, 8},
+              {"v_cvt_f32_ubyte1", k_cvtub, 8}, {"v_cvt_f32_u32", k_cvtu32, 8}, {"v_mul_u32_u24", k_mulu24, 8},
+              {"v_bfi_b32", k_bfi, 8}, {"v_bfe_u32", k_bfe, 8}, {"v_add3_u32", k_add3, 8}, {"v_lshl_add_u32", k_lshladd, 8},
+              {"v_and_or_b32", k_andor, 8}, {"v_sub_u16", k_subu16, 8}, {"v_mul_lo_u16", k_mullou16, 8},
+              {"v_mad_u16", k_madu16, 8}, {"v_xor_b32", k_xor, 8}, {"v_max_i32", k_maxi32, 8},
+              {"v_dot4_i32_i8", k_dot4i, 8}, {"v_dot2_u32_u16", k_dot2, 8},
+              {"[v_max_u32 + 1 salu] per v", k_v_s1, 8}, {"[v_max_u32 + 2 salu] per v", k_v_s2, 8},
+              {"[v_cmp sgpr + 1 salu] per v", k_cmpsg_s1, 8}, {"[cmp,max,addc] per 3", k_cmp_addc2, 24},
               {"lds ring w128+3r128", k_lds_ring, 1}, {"4x (dpp wave_sh + add)", k_dpp_shift, 8}};
-    for (int wps : {1, 2, 4}) {          // waves per SIMD
+    for (int wps : {2, 4}) {          // waves per SIMD
         printf("-- %d wave(s) per SIMD (grid %d x 256)\n", wps, cus * wps);
         for (auto &k : ks) {
             const float ms = time_ms([&] { hipLaunchKernelGGL(k.fn, dim3(cus * wps), dim3(256), 0, 0, out, 1u); }, 5);
