@@ -201,27 +201,91 @@ MODES_HD void modes_order8(const uint32_t E[12], uint32_t r[4]) {
     }
 }
 
-/* modes_order8 with the odd-aligned pairs O[t] = (s[2t+1], s[2t+2]), t = 0..9, supplied by the
- * caller (the production scan kernel reads them from a second LDS ring instead of building them). */
-MODES_HD void modes_order8_eo(const uint32_t E[11], const uint32_t O[10], uint32_t r[4]) {
+/* Saturated powers for the production scan kernel: min(s, 32767).  32768 is attained only by
+ * I = Q = 255 and 32767 is not a sum of two squares, so the clamp keeps every ordering relation
+ * between samples exact; it buys one spare bit for the borrow trick of modes_order8_swar.
+ * On the device the clamp is free: v_pk_mad_i16 ... clamp saturates at 0x7fff. */
+MODES_HD uint32_t modes_power_pair_sat(uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t k127 = 0x007F007Fu;
+    const uint32_t ip = w & 0x00FF00FFu;                              /* (I0, I1): full-rate v_and    */
+    const uint32_t qp = __builtin_amdgcn_perm(0u, w, 0x0c030c01u);    /* (Q0, Q1): v_perm_b32         */
+    const uint32_t ai = pk_sub(ip, k127), aq = pk_sub(qp, k127);
+    uint32_t t, r;
+    /* one block so that the wait state between a packed producer and its consumer is kept */
+    asm("v_pk_mul_lo_u16 %0, %2, %2\n\ts_nop 0\n\tv_pk_mad_i16 %1, %3, %3, %0 clamp\n\ts_nop 0"
+        : "=&v"(t), "=v"(r) : "v"(ai), "v"(aq));
+    return r;
+#else
+    const uint32_t e = modes_power_pair(w);
+    const uint32_t lo = e & 0xffffu, hi = e >> 16;
+    return (lo > 32767u ? 32767u : lo) | ((hi > 32767u ? 32767u : hi) << 16);
+#endif
+}
+/* Four dwords (8 samples) at once; on the device the eight packed multiplies are interleaved so
+ * that no result is consumed by the next instruction (one s_nop instead of eight). */
+MODES_HD void modes_power8_sat(const uint32_t w[4], uint32_t out[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t k127 = 0x007F007Fu;
+    uint32_t ai[4], aq[4], t0, t1, t2, t3;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        ai[d] = pk_sub(w[d] & 0x00FF00FFu, k127);
+        aq[d] = pk_sub(__builtin_amdgcn_perm(0u, w[d], 0x0c030c01u), k127);
+    }
+    asm("s_nop 0\n\t"
+        "v_pk_mul_lo_u16 %4, %8, %8\n\t"
+        "v_pk_mul_lo_u16 %5, %9, %9\n\t"
+        "v_pk_mul_lo_u16 %6, %10, %10\n\t"
+        "v_pk_mul_lo_u16 %7, %11, %11\n\t"
+        "v_pk_mad_i16 %0, %12, %12, %4 clamp\n\t"
+        "v_pk_mad_i16 %1, %13, %13, %5 clamp\n\t"
+        "v_pk_mad_i16 %2, %14, %14, %6 clamp\n\t"
+        "v_pk_mad_i16 %3, %15, %15, %7 clamp\n\t"
+        "s_nop 0"
+        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(ai[0]), "v"(ai[1]), "v"(ai[2]), "v"(ai[3]), "v"(aq[0]), "v"(aq[1]), "v"(aq[2]), "v"(aq[3]));
+#else
+    for (int d = 0; d < 4; d++) out[d] = modes_power_pair_sat(w[d]);
+#endif
+}
+
+/* The ordering relations of dump1090.c:1602-1611 for 8 positions, production form.  Same max/min
+ * tree as modes_order8 (packed, half-rate ops), but the four final compares and their conjunction
+ * are plain 32-bit subtracts and ANDs (full-rate ops on gfx950, tools/ubench_valu.hip):
+ *     a > b   <=>   bit 15 of (b - a) mod 2^16          for a, b <= 32767.
+ * A 32-bit subtract of two packed pairs gives the low half exactly; the high half sees the low
+ * half's borrow, i.e. it tests a_hi > b_hi OR (a_hi == b_hi AND a_lo > b_lo): never a false
+ * negative, and the extra accepts are removed downstream like every other scan false positive.
+ * r[q]: bit 15 <-> position 2q, bit 31 <-> position 2q+1 (other bits are garbage).
+ * E must hold saturated powers (modes_power_pair_sat). */
+#define MODES_ORDER_FLAGS 0x80008000u
+MODES_HD void modes_order8_swar(const uint32_t E[12], uint32_t r[4]) {
+    uint32_t O[11];
+#pragma unroll
+    for (int t = 0; t < 11; t++) O[t] = (E[t] >> 16) | (E[t + 1] << 16);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t x0 = E[q], x1 = O[q], x2 = E[q + 1], x3 = O[q + 1], x4 = E[q + 2], x5 = O[q + 2],
                        x6 = E[q + 3], x7 = O[q + 3], x8 = E[q + 4], x9 = O[q + 4];
         const uint32_t m13 = pk_max(x1, x3);
-        uint32_t v = pk_subs(x0, pk_max(pk_max(m13, pk_max(x4, x5)), x6));
-        v = pk_min(v, pk_subs(x2, m13));
-        v = pk_min(v, pk_subs(pk_min(x7, x9), x8));
-        v = pk_min(v, pk_subs(x9, x6));
-        r[q] = v;
+        const uint32_t big = pk_max(pk_max(m13, pk_max(x4, x5)), x6);
+        r[q] = (big - x0) & (m13 - x2) & (x8 - pk_min(x7, x9)) & (x6 - x9);
     }
+}
+/* bit i of the result <-> position i of the window */
+MODES_HD uint32_t modes_order8_mask(const uint32_t r[4]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) m |= (((r[q] >> 15) & 1u) << (2 * q)) | (((r[q] >> 31) & 1u) << (2 * q + 1));
+    return m;
 }
 
 /* Necessary condition for the level tests of dump1090.c:1624-1642 on powers, in plain integers
  * (the beta pass runs it on one position per lane):  9 * max(quiet) < s0 + s2 + s7 + s9.
  * Derivation in the comment of modes_scan8. */
 MODES_HD bool modes_level_bound(uint32_t s0, uint32_t s2, uint32_t s7, uint32_t s9, uint32_t quiet_max) {
-    return 9u * quiet_max < s0 + s2 + s7 + s9;
+    return 9u * quiet_max < s0 + s2 + s7 + s9 + 4u;      /* + 4: the four pulses may be saturated powers (each <= 1 low) */
 }
 
 /* position i of modes_scan8's mask */

@@ -82,6 +82,14 @@ __device__ __forceinline__ uint4 power16(uint4 v) {
     return make_uint4(modes_power_pair(v.x), modes_power_pair(v.y), modes_power_pair(v.z), modes_power_pair(v.w));
 }
 
+// min(s, 32767): what the production scan kernel works on (modes_core.h)
+__device__ __forceinline__ uint4 power16_sat(uint4 v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+    modes_power8_sat(w, o);
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // Reference magnitude of buffer sample q (0 outside the stream).
 struct MagAt {
     const uint8_t *iq;
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void power_kernel(const uint8_t *__restrict__ 
                                                     uint16_t *__restrict__ out) {
     const uint64_t ngroups = (nsamples + 7) / 8;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * blockDim.x) {
-        uint4 s = power16(load_iq16(iq, (int64_t)(g * 16), 0, (int64_t)(nsamples * 2)));
+        uint4 s = power16_sat(load_iq16(iq, (int64_t)(g * 16), 0, (int64_t)(nsamples * 2)));
         uint32_t w[4] = {s.x, s.y, s.z, s.w};
         for (int t = 0; t < 8 && g * 8 + t < nsamples; t++) out[g * 8 + t] = (uint16_t)(w[t >> 1] >> (16 * (t & 1)));
     }
@@ -275,22 +283,36 @@ struct DemodParams {
 
 // ------------------------------------------------------------------------------------
 // scan_kernel (production, scan_variant 0) - same work decomposition as scan_fused_kernel, but
-// split in two passes because the stage is VALU-bound (packed-u16 VALU issues at 16 lanes per
-// clock per SIMD on gfx950: ~90 % VALU-busy in the fused kernel, profiles/r01a):
+// split in two passes because the stage is VALU-issue-bound (DESIGN.md 3.1 has the measured
+// issue costs: every packed / VOP3 op is half rate on gfx950):
 //
-//   alpha  every position, packed u16: only the ten ORDERING relations (exact on s).  1.4 % of
-//          positions survive; lanes owning a survivor push {their 22-sample window, the four
-//          packed results, the window's position} into a wave-private LDS queue.
+//   alpha  every position: the ten ORDERING relations (exact on s for even positions, superset
+//          for odd ones: modes_order8_swar).  ~1.5 % of positions survive; lanes owning a survivor
+//          push {their 24-sample window, the four result words, the window's position} into a
+//          wave-private LDS queue.
 //   beta   whenever 64 entries are queued: one lane per entry, plain 32-bit integers: the level
 //          bound 9*max(quiet) < s0+s2+s7+s9 for the survivors of that entry.  Dense lanes, so the
 //          level test costs ~10x less per chunk than evaluating it packed at every position.
 //
-// Forwarded positions of a run are no longer in ascending order (the host sorts the candidate
-// list when it is requested; records are sorted anyway).
+// The chunk loop is unrolled by two so that ring-slot parity is static: all LDS addresses are
+// loop-invariant VGPRs, the prefetched chunk lives in the registers it was loaded into (no
+// rotation moves), and global addresses are SGPR base + constant lane offset.
+//
+// Forwarded positions of a run are not in ascending order (the host sorts the candidate list
+// when it is requested; records are sorted anyway).
 // ------------------------------------------------------------------------------------
 constexpr int kQCap = 128;            // queue entries per wavefront (power of two, >= 2 * 64)
-constexpr int kQStride = 17;          // dwords per entry: 11 window + 4 results + 1 position + 1 pad (odd: no bank conflicts)
+constexpr int kQStride = 17;          // dwords per entry: 12 window + 4 results + 1 position (odd: no bank conflicts)
 constexpr int kScan2Waves = 2;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wavefront execute in issue order: a read sees an earlier write of the
+    // same wavefront without a barrier; only the compiler must not reorder them.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *queue, uint32_t qhead, uint32_t nb, int lane,
                                           uint32_t *my_slots, uint32_t &count) {
@@ -298,13 +320,9 @@ __device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *q
     const uint32_t *e = queue + ((qhead + (uint32_t)lane) & (kQCap - 1)) * kQStride;
     uint32_t m8 = 0, p0 = 0;
     if (act) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t r = e[11 + q];
-            m8 |= ((r & 0xffffu) ? 1u : 0u) << (2 * q);
-            m8 |= ((r >> 16) ? 1u : 0u) << (2 * q + 1);
-        }
-        p0 = e[15];
+        const uint32_t r[4] = {e[12], e[13], e[14], e[15]};
+        m8 = modes_order8_mask(r);
+        p0 = e[16];
     }
     const uint16_t *w = reinterpret_cast<const uint16_t *>(e);
     uint64_t pending = __ballot(m8 != 0);
@@ -332,126 +350,93 @@ __device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *q
     }
 }
 
-// 16 bytes of chunk data at 32-bit offset `off` from the run's (wave-uniform) base pointer.
+// GUARD: the run touches an end of the span (byte-wise bounds checks on every load).  Otherwise
+// chunks come through a raw buffer descriptor: SGPR base and offset + constant lane offset, no
+// address arithmetic in the vector unit.
 template <bool GUARD>
-__device__ __forceinline__ uint4 load_chunk16(const uint8_t *run_base, int32_t off, const uint8_t *iq, int64_t base_off,
-                                              int64_t lo, int64_t hi) {
-    if (!GUARD) return *reinterpret_cast<const uint4 *>(run_base + off);
-    return load_iq16(iq, base_off + off, lo, hi);
-}
-
-// GUARD: the run touches an end of the span (byte-wise bounds checks on every load).
-// ORING: odd-aligned sample pairs come from a second LDS ring filled by the producing lane
-//        (1 DPP + 4 v_perm per lane) instead of 11 v_perm per consuming lane.
-template <bool GUARD, bool ORING>
-__device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int lane, uint32_t *ring, uint32_t *oring,
-                                         uint32_t *queue) {
-    const int64_t c0 = (int64_t)run * P.run_chunks;
+__device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int lane, uint4 *ring4, uint32_t *queue) {
+    const int64_t c0 = (int64_t)run * P.run_chunks;                          // even (run_chunks is even)
     const int64_t c1 = (c0 + (int64_t)P.run_chunks < (int64_t)P.nchunks) ? c0 + (int64_t)P.run_chunks : (int64_t)P.nchunks;
     const uint8_t *iq = P.iq;
     const int64_t lo = P.lo, hi = P.hi;
     const int64_t base_off = c0 * kChunkBytes;
-    const uint8_t *run_base = iq + base_off;                                 // wave-uniform
-    const int32_t lane_off = lane * 16;
+    const uint32_t lane_off = (uint32_t)lane * 16u;
 
-    auto produce = [&](int64_t c, const uint4 &raw, bool all_lanes) {
-        const uint4 s = power16(raw);
-        const uint32_t slot = (uint32_t)((c & 1) * 256) + (uint32_t)lane * 4u;
-        if (all_lanes || lane >= 62) *reinterpret_cast<uint4 *>(&ring[slot]) = s;
-        if (ORING) {
-            // next lane's first pair (lane 63 gets 0: its last odd pair is never read)
-            const uint32_t nx = __builtin_amdgcn_update_dpp(0u, s.x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-            const uint4 o = make_uint4((s.x >> 16) | (s.y << 16), (s.y >> 16) | (s.z << 16), (s.z >> 16) | (s.w << 16),
-                                       (s.w >> 16) | (nx << 16));
-            if (all_lanes || lane >= 62) *reinterpret_cast<uint4 *>(&oring[slot]) = o;
-        }
+    // chunk c0 + k lives in ring slot k & 1 (64 x 16 bytes each).  Loop-invariant LDS pointers.
+    // A lane's 24-sample window = the 16 samples of the two lanes before it (previous chunk's lanes
+    // 62, 63 for lanes 0, 1: the ring wraps) + its own 8 samples, which never leave its registers.
+    uint4 *const wr0 = ring4 + lane, *const wr1 = ring4 + 64 + lane;
+    const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring4);  // LDS byte address (low half of the flat address)
+    const uint32_t rd0a = ring_lds + 16u * ((126 + lane) & 127), rd0b = ring_lds + 16u * ((127 + lane) & 127);
+    const uint32_t rd1a = ring_lds + 16u * ((190 + lane) & 127), rd1b = ring_lds + 16u * ((191 + lane) & 127);
+
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(iq + (GUARD ? 0 : base_off)), 0, 0x7fffffff, 0x00020000);
+    auto load = [&](int64_t k) -> uint4 {                                    // chunk c0 + k
+        if (!GUARD)
+            return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, (uint32_t)k * kChunkBytes, 0));
+        return load_iq16(iq, base_off + k * kChunkBytes + lane_off, lo, hi);
     };
-
-    // prologue: the last 16 samples of chunk c0-1 (lanes 62, 63; lane 63's last odd pair needs the
-    // first sample of chunk c0, which the first iteration's odd pairs do not cover - it is only
-    // read through E, never through O, see window geometry below)
-    {
-        const uint4 raw = load_chunk16<true>(run_base, -kChunkBytes + lane_off, iq, base_off, lo, hi);
-        produce(c0 - 1, raw, false);
-    }
-    uint4 cur = load_chunk16<GUARD>(run_base, lane_off, iq, base_off, lo, hi);
-    uint4 nxt = load_chunk16<GUARD>(run_base, kChunkBytes + lane_off, iq, base_off, lo, hi);
 
     uint32_t count = 0, qhead = 0, qn = 0;                                   // wave-uniform
     uint32_t *my_slots = P.slots + (uint64_t)run * P.slot_cap;
-    int32_t off = lane_off;                                                  // offset of chunk c for this lane
 
-    for (int64_t c = c0; c < c1; c++, off += kChunkBytes) {
-        const uint4 raw = cur;
-        cur = nxt;
-        nxt = load_chunk16<GUARD>(run_base, off + 2 * kChunkBytes, iq, base_off, lo, hi);
-
-        produce(c, raw, true);
-        // LDS operations of one wavefront execute in issue order: the reads below see the writes
-        // above without a barrier; only the compiler must not reorder them.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // window of 24 powers starting at position 512c - 16 + 8*lane (dword index mod 512)
-        const uint32_t d0 = (uint32_t)(((c & 1) * 256) + 512 - 8 + lane * 4) & 511u;
-        const uint32_t d1 = (d0 + 4) & 511u, d2 = (d0 + 8) & 511u;
-        uint32_t E[12], r[4];
-        {
-            const uint4 a = *reinterpret_cast<const uint4 *>(&ring[d0]);
-            const uint4 b = *reinterpret_cast<const uint4 *>(&ring[d1]);
-            const uint4 d = *reinterpret_cast<const uint4 *>(&ring[d2]);
-            E[0] = a.x; E[1] = a.y; E[2] = a.z; E[3] = a.w;
-            E[4] = b.x; E[5] = b.y; E[6] = b.z; E[7] = b.w;
-            E[8] = d.x; E[9] = d.y; E[10] = d.z; E[11] = d.w;
-        }
-        if (ORING) {
-            uint32_t O[12];
-            const uint4 a = *reinterpret_cast<const uint4 *>(&oring[d0]);
-            const uint4 b = *reinterpret_cast<const uint4 *>(&oring[d1]);
-            const uint4 d = *reinterpret_cast<const uint4 *>(&oring[d2]);
-            O[0] = a.x; O[1] = a.y; O[2] = a.z; O[3] = a.w;
-            O[4] = b.x; O[5] = b.y; O[6] = b.z; O[7] = b.w;
-            O[8] = d.x; O[9] = d.y; O[10] = d.z; O[11] = d.w;
-            // The odd pair that straddles two producing lanes' chunks of different iterations (lane 63 of
-            // chunk c-1 -> dword 255 of its slot) is window index t = 7 - 4*lane... only lanes 0 and 1 can
-            // see it, at O[7] (lane 0) / O[3] (lane 1): rebuild it from E.
-            if (lane == 0) O[7] = (E[7] >> 16) | (E[8] << 16);
-            if (lane == 1) O[3] = (E[3] >> 16) | (E[4] << 16);
-            modes_order8_eo(E, O, r);
-        } else {
-            modes_order8(E, r);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    // one chunk: powers `s` to slot `wr`, neighbours' through `rda/rdb`, alpha, push, maybe beta
+    auto step = [&](const uint4 &s, uint4 *wr, uint32_t rda, uint32_t rdb, int64_t c) {
+        *wr = s;
+        wave_lds_fence();
+        // two ds_read_b128, spelled out: hipcc splits the same loads written in C++ into six narrower
+        // LDS reads here.  LDS operations of a wavefront complete in order, so these see the write above.
+        u32x4 a, b;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(a), "=&v"(b) : "v"(rda), "v"(rdb) : "memory");
+        wave_lds_fence();
+        const uint32_t E[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, s.x, s.y, s.z, s.w};
+        uint32_t r[4];
+        modes_order8_swar(E, r);
 
         // ---- alpha survivors -> queue ----
-        const bool any = ((r[0] | r[1]) | (r[2] | r[3])) != 0;
+        const bool any = (((r[0] | r[1]) | (r[2] | r[3])) & MODES_ORDER_FLAGS) != 0;
         const uint64_t hb = __ballot(any);
         if (hb) {
             if (any) {
                 const uint32_t slot = (qhead + qn + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1))) & (kQCap - 1);
                 uint32_t *e = queue + slot * kQStride;
 #pragma unroll
-                for (int t = 0; t < 11; t++) e[t] = E[t];
+                for (int t = 0; t < 12; t++) e[t] = E[t];
 #pragma unroll
-                for (int q = 0; q < 4; q++) e[11 + q] = r[q];
-                e[15] = (uint32_t)(c * kChunkSamples - kLookback + 8 * lane);
+                for (int q = 0; q < 4; q++) e[12 + q] = r[q];
+                e[16] = (uint32_t)(c * kChunkSamples - kLookback + 8 * lane);
             }
             qn += (uint32_t)__builtin_popcountll(hb);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            wave_lds_fence();
             // ---- beta: level bound for 64 queued entries at a time ----
             if (qn >= 64) {
                 scan_beta(P, queue, qhead, 64, lane, my_slots, count);
                 qhead = (qhead + 64) & (kQCap - 1);
                 qn -= 64;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_fence();
             }
         }
+    };
+
+    // prologue: the last 16 samples of chunk c0-1 go to the tail of slot 1 (lanes 62, 63)
+    {
+        const uint4 s = power16_sat(load_iq16(iq, base_off - kChunkBytes + lane_off, lo, hi));
+        if (lane >= 62) *wr1 = s;
     }
+    uint4 x = load(0), y = load(1);                                          // two chunks in flight
+    int64_t c = c0;
+    for (; c + 2 <= c1; c += 2) {
+        const int64_t k = c - c0;
+        const uint4 sx = power16_sat(x);
+        x = load(k + 2);                                                     // back into the registers just consumed
+        step(sx, wr0, rd0a, rd0b, c);
+        const uint4 sy = power16_sat(y);
+        y = load(k + 3);
+        step(sy, wr1, rd1a, rd1b, c + 1);
+    }
+    if (c < c1) step(power16_sat(x), wr0, rd0a, rd0b, c);                    // odd tail (last run only)
     if (qn) scan_beta(P, queue, qhead, qn, lane, my_slots, count);
     if (lane == 0) {
         P.counts[run] = count;
@@ -459,22 +444,19 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
     }
 }
 
-template <bool ORING>
 __global__ __launch_bounds__(kScan2Waves * kWave) void scan_kernel(ScanParams P) {
-    __shared__ __attribute__((aligned(16))) uint32_t ring_all[kScan2Waves][512];
-    __shared__ __attribute__((aligned(16))) uint32_t oring_all[ORING ? kScan2Waves : 1][ORING ? 512 : 4];
+    __shared__ uint4 ring_all[kScan2Waves][128];
     __shared__ uint32_t queue_all[kScan2Waves][kQCap * kQStride];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: addresses stay in SGPRs
     const uint32_t run = blockIdx.x * kScan2Waves + wave;
     if (run >= P.nruns) return;
     // Runs whose loads (chunks c0-1 .. c1+1, the prefetch runs two chunks ahead) all lie inside the
     // span take the unguarded instantiation; that is every run except the first and the last few.
     const int64_t c0 = (int64_t)run * P.run_chunks;
     const int64_t first = (c0 - 1) * kChunkBytes, last = (c0 + (int64_t)P.run_chunks + 2) * kChunkBytes;
-    uint32_t *oring = ORING ? oring_all[wave] : nullptr;
-    if (first >= P.lo && last <= P.hi) scan_run<false, ORING>(P, run, lane, ring_all[wave], oring, queue_all[wave]);
-    else                               scan_run<true, ORING>(P, run, lane, ring_all[wave], oring, queue_all[wave]);
+    if (first >= P.lo && last <= P.hi) scan_run<false>(P, run, lane, ring_all[wave], queue_all[wave]);
+    else                               scan_run<true>(P, run, lane, ring_all[wave], queue_all[wave]);
 }
 
 // Sample / dword loads for the demod kernel.  GUARD = false: plain loads (the caller has checked,
@@ -1076,6 +1058,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     const uint64_t nchunks = (uint64_t)(p_end + kLookback + kChunkSamples - 1) / kChunkSamples;
     uint32_t R = ctx->cfg.run_chunks;
     if (R == 0) R = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(64, nchunks / 8192));
+    R += R & 1;                                                   // the scan loop is unrolled by two chunks
     const uint32_t nruns = (uint32_t)std::max<uint64_t>(1, (nchunks + R - 1) / R);
     uint32_t cap = ctx->cfg.slot_cap;
     if (cap == 0) cap = std::max<uint32_t>(64, R * 32);        // 1/16 of the run's positions
@@ -1130,12 +1113,10 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     dp.max_records = ctx->cfg.max_records;
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-    if (ctx->cfg.scan_variant == 2)
-        hipLaunchKernelGGL(scan_kernel<true>, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st, sp);
-    else if (ctx->cfg.scan_variant == 1)
+    if (ctx->cfg.scan_variant == 1)
         hipLaunchKernelGGL(scan_fused_kernel, dim3((nruns + kScanWaves - 1) / kScanWaves), dim3(kScanWaves * kWave), 0, st, sp);
     else
-        hipLaunchKernelGGL(scan_kernel<false>, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st, sp);
+        hipLaunchKernelGGL(scan_kernel, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st, sp);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((nruns + 3) / 4, 1024u)), dim3(256), 0, st, dp);
     if (ctx->cfg.keep_candidates)

@@ -28,6 +28,44 @@ void shim_scan_stream(const uint8_t *iq, uint64_t nsamples, uint8_t *flags) {
     }
 }
 
+// modes_power_pair_sat + modes_order8_swar (the production scan kernel's alpha pass) over a stream.
+// flags[p] = 1 if position p survives the ordering test.
+void shim_order_stream(const uint8_t *iq, uint64_t nsamples, uint8_t *flags) {
+    auto power2 = [&](uint64_t first) -> uint32_t {
+        uint8_t b[4] = {127, 127, 127, 127};
+        for (int t = 0; t < 4; t++) {
+            uint64_t off = 2 * first + t;
+            if (off < 2 * nsamples) b[t] = iq[off];
+        }
+        uint32_t w;
+        memcpy(&w, b, 4);
+        return modes_power_pair_sat(w);
+    };
+    for (uint64_t p0 = 0; p0 < nsamples; p0 += 8) {
+        uint32_t E[12], r[4];
+        for (int t = 0; t < 12; t++) E[t] = power2(p0 + 2 * t);
+        modes_order8_swar(E, r);
+        const uint32_t m = modes_order8_mask(r);
+        for (int i = 0; i < 8 && p0 + i < nsamples; i++) flags[p0 + i] = (m >> i) & 1u;
+    }
+}
+
+void shim_power_sat(const uint8_t *iq, uint64_t nsamples, uint16_t *s) {
+    for (uint64_t k = 0; k < nsamples; k += 2) {
+        uint8_t b[4] = {iq[2 * k], iq[2 * k + 1], 127, 127};
+        if (k + 1 < nsamples) { b[2] = iq[2 * k + 2]; b[3] = iq[2 * k + 3]; }
+        uint32_t w;
+        memcpy(&w, b, 4);
+        uint32_t pr = modes_power_pair_sat(w);
+        s[k] = (uint16_t)pr;
+        if (k + 1 < nsamples) s[k + 1] = (uint16_t)(pr >> 16);
+    }
+}
+
+int shim_level_bound(uint32_t s0, uint32_t s2, uint32_t s7, uint32_t s9, uint32_t quiet) {
+    return modes_level_bound(s0, s2, s7, s9, quiet) ? 1 : 0;
+}
+
 void shim_power(const uint8_t *iq, uint64_t nsamples, uint16_t *s) {
     for (uint64_t k = 0; k + 1 < nsamples + 1 && k < nsamples; k += 2) {
         uint8_t b[4] = {iq[2 * k], iq[2 * k + 1], 127, 127};

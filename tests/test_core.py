@@ -16,6 +16,9 @@ def shim():
     L = C.CDLL(build_shim())
     L.shim_scan_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     L.shim_power.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.shim_power_sat.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.shim_order_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.shim_level_bound.argtypes = [C.c_uint32] * 5
     L.shim_demod_both.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.shim_demod_parallel.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.shim_preamble_exact.argtypes = [C.c_void_p]
@@ -86,6 +89,74 @@ def test_power_pair_all_bytes(shim):
     i = iq[0::2].astype(np.int64) - 127
     q = iq[1::2].astype(np.int64) - 127
     assert np.array_equal(s, (i * i + q * q).astype(np.uint16))
+
+
+def numpy_order_mask(iq, relaxed_high=False):
+    """The ten ordering relations of dump1090.c:1602-1611 on powers."""
+    i = iq[0::2].astype(np.int64) - 127
+    q = iq[1::2].astype(np.int64) - 127
+    s = np.concatenate([i * i + q * q, np.zeros(24, dtype=np.int64)])
+    n = iq.size // 2
+    S = lambda k: s[k:k + n]
+    return (S(0) > np.maximum.reduce([S(1), S(3), S(4), S(5), S(6)])) & (S(2) > np.maximum(S(1), S(3))) \
+        & (np.minimum(S(7), S(9)) > S(8)) & (S(9) > S(6))
+
+
+def numpy_order_mask_relaxed(iq):
+    """Same with >= : an upper bound for what the borrow trick may additionally accept."""
+    i = iq[0::2].astype(np.int64) - 127
+    q = iq[1::2].astype(np.int64) - 127
+    s = np.concatenate([i * i + q * q, np.zeros(24, dtype=np.int64)])
+    n = iq.size // 2
+    S = lambda k: s[k:k + n]
+    return (S(0) >= np.maximum.reduce([S(1), S(3), S(4), S(5), S(6)])) & (S(2) >= np.maximum(S(1), S(3))) \
+        & (np.minimum(S(7), S(9)) >= S(8)) & (S(9) >= S(6))
+
+
+@pytest.mark.parametrize("case", ["modes1", "uniform", "coarse", "frames", "lowsnr", "noise", "extreme"])
+def test_order8_swar_is_exact_on_even_positions_and_a_superset_on_odd_ones(shim, streams, case):
+    if case == "extreme":
+        rng = np.random.default_rng(6)
+        vals = np.array([0, 1, 126, 127, 128, 254, 255], dtype=np.uint8)
+        iq = vals[rng.integers(0, len(vals), 2 * 65536)]
+    else:
+        iq = streams[case]
+    n = iq.size // 2
+    flags = np.zeros(n, dtype=np.uint8)
+    shim.shim_order_stream(iq.ctypes.data, n, flags.ctypes.data)
+    got, exact, relaxed = flags.astype(bool), numpy_order_mask(iq), numpy_order_mask_relaxed(iq)
+    assert np.array_equal(got[0::2], exact[0::2])                 # low halves: exact
+    assert not np.any(exact & ~got), "alpha dropped a position that satisfies the ordering relations"
+    assert not np.any(got & ~relaxed)                              # high halves: at most '>' -> '>='
+    assert got.sum() <= 1.5 * exact.sum() + 64
+    # every true preamble survives alpha, and the level bound keeps it
+    truth = true_preamble_mask(iq)
+    assert not np.any(truth & ~got)
+
+
+def test_level_bound_keeps_every_true_preamble(shim, streams):
+    for case in ("modes1", "frames", "coarse"):
+        iq = streams[case]
+        i = iq[0::2].astype(np.int64) - 127
+        q = iq[1::2].astype(np.int64) - 127
+        s = np.minimum(i * i + q * q, 32767)
+        for p in np.flatnonzero(true_preamble_mask(iq))[:4000]:
+            if p + 15 > s.size:
+                continue
+            quiet = max(s[p + 4], s[p + 5], s[p + 11], s[p + 12], s[p + 13], s[p + 14])
+            assert shim.shim_level_bound(int(s[p]), int(s[p + 2]), int(s[p + 7]), int(s[p + 9]), int(quiet))
+
+
+def test_power_sat_all_bytes(shim):
+    iq = np.stack(np.meshgrid(np.arange(256), np.arange(256), indexing="ij"), -1).astype(np.uint8).reshape(-1)
+    s = np.zeros(iq.size // 2, dtype=np.uint16)
+    shim.shim_power_sat(iq.ctypes.data, s.size, s.ctypes.data)
+    i = iq[0::2].astype(np.int64) - 127
+    q = iq[1::2].astype(np.int64) - 127
+    exact = i * i + q * q
+    assert np.array_equal(s, np.minimum(exact, 32767).astype(np.uint16))
+    # the clamp changes exactly one value and keeps the order of all values
+    assert (exact > 32767).sum() == 1 and not np.any(exact == 32767)
 
 
 def test_preamble_exact_matches_oracle(shim, streams):
