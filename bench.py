@@ -128,7 +128,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    scan_ms, demod_ms, n_msgs, n_pre = [], [], 0, 0
+    scan_ms, demod_ms, n_msgs, n_pre, n_fwd = [], [], 0, 0, 0
     t0 = None
     for step in range(args.warmup + args.steps):
         if step == args.warmup:
@@ -148,6 +148,7 @@ def main():
             if rank == 0:
                 n_msgs += m
             n_pre = info["n_preambles"]
+            n_fwd = info.get("n_forwarded", 0)
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -170,7 +171,7 @@ def main():
                    "step": "scan + demod kernels, record fetch%s, host resolve" % (
                        ", RCCL gather to rank 0" if world > 1 else "")},
         "msgs_per_s": round(n_msgs / elapsed, 2),
-        "preambles_per_step_rank0": int(n_pre),
+        "preambles_per_step_rank0": int(n_pre), "forwarded_per_step_rank0": int(n_fwd),
         "kernel_ms": {"scan": round(scan_avg_ms, 4), "demod_finalize": round(float(np.mean(demod_ms)), 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.mib),

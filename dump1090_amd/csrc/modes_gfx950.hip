@@ -105,14 +105,35 @@ struct MagAt {
     }
 };
 
+// The 129 x 129 magnitude LUT (33,282 bytes, padded to kLutVec 16-byte vectors in HBM) into LDS:
+// 16 bytes per lane, all loads of a thread in flight at once.
+constexpr int kLutVec = (129 * 129 * 2 + 15) / 16;       // 2081
+template <int THREADS>
+__device__ __forceinline__ void stage_lut(uint16_t *s_lut, const uint16_t *lut) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(lut);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
+    constexpr int kIter = (kLutVec + THREADS - 1) / THREADS;
+    uint4 v[kIter];
+#pragma unroll
+    for (int k = 0; k < kIter; k++) {
+        const int i = (int)threadIdx.x + k * THREADS;
+        v[k] = (i < kLutVec) ? src[i] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < kIter; k++) {
+        const int i = (int)threadIdx.x + k * THREADS;
+        if (i < kLutVec) dst[i] = v[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // K1 (parity of computeMagnitudeVector, dump1090.c:1454-1469): u8 I/Q -> u16 magnitude.
 // LUT staged in LDS; 8 samples per lane per iteration (16 B in, 16 B out).
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void magnitude_kernel(const uint8_t *__restrict__ iq, uint64_t nsamples,
                                                         const uint16_t *__restrict__ lut, uint16_t *__restrict__ mag) {
-    __shared__ uint16_t s_lut[129 * 129 + 1];
-    for (int i = threadIdx.x; i < 129 * 129; i += blockDim.x) s_lut[i] = lut[i];
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[kLutVec * 8];
+    stage_lut<256>(s_lut, lut);
     __syncthreads();
     const uint64_t ngroups = (nsamples + 7) / 8;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * blockDim.x) {
@@ -264,6 +285,9 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanPara
 // ------------------------------------------------------------------------------------
 // demod_kernel - one wavefront per run, one lane per forwarded position.
 // ------------------------------------------------------------------------------------
+constexpr int kDemodWaves = 8;        // wavefronts per demod workgroup (they share one 33 KB LUT copy in LDS)
+constexpr int kDemodGroup = 4;        // runs whose slot lists one demod wavefront walks together (power of two <= 64)
+
 struct DemodParams {
     const uint8_t *iq;
     int64_t lo, hi;
@@ -301,8 +325,8 @@ struct DemodParams {
 // Forwarded positions of a run are not in ascending order (the host sorts the candidate list
 // when it is requested; records are sorted anyway).
 // ------------------------------------------------------------------------------------
-constexpr int kQCap = 128;            // queue entries per wavefront (power of two, >= 2 * 64)
-constexpr int kQStride = 17;          // dwords per entry: 12 window + 4 results + 1 position (odd: no bank conflicts)
+constexpr int kQCap = 64;             // queue entries per wavefront: one beta pass
+constexpr int kQStride = 17;          // dwords per entry: 11 window + 4 results + 1 position + 1 pad (odd: no bank conflicts)
 constexpr int kScan2Waves = 2;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -314,15 +338,15 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *queue, uint32_t qhead, uint32_t nb, int lane,
+__device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *queue, uint32_t nb, int lane,
                                           uint32_t *my_slots, uint32_t &count) {
     const bool act = (uint32_t)lane < nb;
-    const uint32_t *e = queue + ((qhead + (uint32_t)lane) & (kQCap - 1)) * kQStride;
+    const uint32_t *e = queue + lane * kQStride;
     uint32_t m8 = 0, p0 = 0;
     if (act) {
-        const uint32_t r[4] = {e[12], e[13], e[14], e[15]};
+        const uint32_t r[4] = {e[11], e[12], e[13], e[14]};
         m8 = modes_order8_mask(r);
-        p0 = e[16];
+        p0 = e[15];
     }
     const uint16_t *w = reinterpret_cast<const uint16_t *>(e);
     uint64_t pending = __ballot(m8 != 0);
@@ -378,7 +402,7 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
         return load_iq16(iq, base_off + k * kChunkBytes + lane_off, lo, hi);
     };
 
-    uint32_t count = 0, qhead = 0, qn = 0;                                   // wave-uniform
+    uint32_t count = 0, qn = 0;                                              // wave-uniform
     uint32_t *my_slots = P.slots + (uint64_t)run * P.slot_cap;
 
     // one chunk: powers `s` to slot `wr`, neighbours' through `rda/rdb`, alpha, push, maybe beta
@@ -395,28 +419,26 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
         uint32_t r[4];
         modes_order8_swar(E, r);
 
-        // ---- alpha survivors -> queue ----
+        // ---- alpha survivors -> queue; beta (level bound) whenever the next push might not fit ----
         const bool any = (((r[0] | r[1]) | (r[2] | r[3])) & MODES_ORDER_FLAGS) != 0;
         const uint64_t hb = __ballot(any);
         if (hb) {
-            if (any) {
-                const uint32_t slot = (qhead + qn + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1))) & (kQCap - 1);
-                uint32_t *e = queue + slot * kQStride;
-#pragma unroll
-                for (int t = 0; t < 12; t++) e[t] = E[t];
-#pragma unroll
-                for (int q = 0; q < 4; q++) e[12 + q] = r[q];
-                e[16] = (uint32_t)(c * kChunkSamples - kLookback + 8 * lane);
-            }
-            qn += (uint32_t)__builtin_popcountll(hb);
-            wave_lds_fence();
-            // ---- beta: level bound for 64 queued entries at a time ----
-            if (qn >= 64) {
-                scan_beta(P, queue, qhead, 64, lane, my_slots, count);
-                qhead = (qhead + 64) & (kQCap - 1);
-                qn -= 64;
+            const uint32_t npush = (uint32_t)__builtin_popcountll(hb);
+            if (qn + npush > kQCap) {
+                scan_beta(P, queue, qn, lane, my_slots, count);
+                qn = 0;
                 wave_lds_fence();
             }
+            if (any) {
+                uint32_t *e = queue + (qn + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1))) * kQStride;
+#pragma unroll
+                for (int t = 0; t < 11; t++) e[t] = E[t];
+#pragma unroll
+                for (int q = 0; q < 4; q++) e[11 + q] = r[q];
+                e[15] = (uint32_t)(c * kChunkSamples - kLookback + 8 * lane);
+            }
+            qn += npush;
+            wave_lds_fence();
         }
     };
 
@@ -437,7 +459,7 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
         step(sy, wr1, rd1a, rd1b, c + 1);
     }
     if (c < c1) step(power16_sat(x), wr0, rd0a, rd0b, c);                    // odd tail (last run only)
-    if (qn) scan_beta(P, queue, qhead, qn, lane, my_slots, count);
+    if (qn) scan_beta(P, queue, qn, lane, my_slots, count);
     if (lane == 0) {
         P.counts[run] = count;
         if (count > P.slot_cap) atomicOr(&P.hdr->overflow, 1u);
@@ -671,11 +693,12 @@ __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t 
 //            (coalesced sample loads; the sequential parts of the reference become carry chains,
 //            see modes_core.h).  Positions whose first noise gate passes become records.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void demod_kernel(DemodParams P) {
-    __shared__ uint16_t s_lut[129 * 129 + 1];
-    __shared__ uint32_t s_list[4][64];
+__global__ __launch_bounds__(kDemodWaves * 64) void demod_kernel(DemodParams P) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[kLutVec * 8];
+    __shared__ uint32_t s_list[kDemodWaves][64];
+    __shared__ uint32_t s_pre[kDemodWaves][kDemodGroup];
     __shared__ unsigned long long s_tot[2];
-    for (int i = threadIdx.x; i < 129 * 129; i += blockDim.x) s_lut[i] = P.tab.lut[i];
+    stage_lut<kDemodWaves * 64>(s_lut, P.tab.lut);
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
     __syncthreads();
 
@@ -685,17 +708,38 @@ __global__ __launch_bounds__(256) void demod_kernel(DemodParams P) {
     const int64_t lo = P.lo, hi = P.hi;
     unsigned long long tot_fwd = 0, tot_cand = 0;
 
-    for (uint32_t run = blockIdx.x * 4 + wave; run < P.nruns; run += gridDim.x * 4) {
-        const uint32_t count = P.counts[run];
-        const uint32_t n = min(count, P.slot_cap);
-        const uint32_t *my = P.slots + (uint64_t)run * P.slot_cap;
+    // A wavefront takes kDemodGroup consecutive runs at a time and walks the concatenation of their
+    // slot lists 64 positions per iteration (dense lanes however short the individual lists are):
+    // s_pre = exclusive prefix of the runs' counts, output index o -> (run, index) by binary search.
+    const uint32_t ngroups = (P.nruns + kDemodGroup - 1) / kDemodGroup;
+    for (uint32_t group = blockIdx.x * kDemodWaves + wave; group < ngroups; group += gridDim.x * kDemodWaves) {
+        const uint32_t run0 = group * kDemodGroup;
+        uint32_t cnt = 0;
+        if (lane < kDemodGroup && run0 + lane < P.nruns) {
+            const uint32_t true_count = P.counts[run0 + lane];
+            cnt = min(true_count, P.slot_cap);
+            tot_fwd += true_count;                                           // summed over lanes at the end
+        }
+        uint32_t incl = cnt;                                                 // inclusive scan over lanes 0..kDemodGroup-1
+#pragma unroll
+        for (int off = 1; off < kDemodGroup; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane < kDemodGroup) s_pre[wave][lane] = incl - cnt;
+        const uint32_t n = __shfl(incl, kDemodGroup - 1, 64);                // forwarded positions of the group
+        wave_lds_fence();
         uint32_t ncand = 0;
-        tot_fwd += count;
+        const uint64_t cand_base = (uint64_t)group * kDemodGroup * P.slot_cap;
         for (uint32_t base = 0; base < n; base += 64) {
             // ---------------- stage 1 ----------------
             const uint32_t e = base + lane;
             const bool active = e < n;
-            const uint32_t p = active ? my[e] : 0u;
+            uint32_t rr = 0;
+#pragma unroll
+            for (int step = kDemodGroup / 2; step >= 1; step >>= 1)
+                if (s_pre[wave][rr + step] <= e) rr += step;
+            const uint32_t p = active ? P.slots[(uint64_t)(run0 + rr) * P.slot_cap + (e - s_pre[wave][rr])] : 0u;
             // fast path when every lane's 16-sample window is inside the span (wave-uniform test)
             const bool in1 = !active || samples_inside((int64_t)(p & ~1u), (int64_t)(p & ~1u) + 15, lo, hi);
             bool ok;
@@ -705,7 +749,7 @@ __global__ __launch_bounds__(256) void demod_kernel(DemodParams P) {
             const uint32_t rank = (uint32_t)__builtin_popcountll(okb & ((1ull << lane) - 1));
             if (ok) {
                 s_list[wave][rank] = p;
-                if (P.cand_slots) P.cand_slots[(uint64_t)run * P.slot_cap + ncand + rank] = p;
+                if (P.cand_slots) P.cand_slots[cand_base + ncand + rank] = p;
             }
             const uint32_t nlist = (uint32_t)__builtin_popcountll(okb);
             ncand += nlist;
@@ -746,9 +790,10 @@ __global__ __launch_bounds__(256) void demod_kernel(DemodParams P) {
             __builtin_amdgcn_wave_barrier();
         }
         tot_cand += ncand;
-        if (lane == 0) P.cand_counts[run] = ncand;
+        if (lane == 0) P.cand_counts[group] = ncand;
     }
-    // totals: one pair of atomics per workgroup
+    // totals: one pair of atomics per workgroup (tot_fwd is per lane, tot_cand wave-uniform)
+    tot_fwd = (unsigned long long)wave_sum((int)tot_fwd);                    // < 2^31 per wavefront (slot lists are u32-indexed)
     if (lane == 0) {
         atomicAdd(&s_tot[0], tot_fwd);
         atomicAdd(&s_tot[1], tot_cand);
@@ -935,7 +980,7 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     for (auto &e : ctx->ev) CREATE_TRY(hipEventCreate(&e));
     // tables: the magnitude LUT exactly as the reference builds it (dump1090.c:359-364, double
     // arithmetic on the host) and the 112 single-bit syndromes.
-    std::vector<uint16_t> lut(129 * 129);
+    std::vector<uint16_t> lut(kLutVec * 8, 0);             // padded to whole 16-byte vectors (stage_lut)
     for (int i = 0; i <= 128; i++)
         for (int q = 0; q <= 128; q++) lut[i * 129 + q] = (uint16_t)std::round(std::sqrt((double)(i * i + q * q)) * 360.0);
     uint32_t esyn[112];
@@ -1057,7 +1102,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
 
     const uint64_t nchunks = (uint64_t)(p_end + kLookback + kChunkSamples - 1) / kChunkSamples;
     uint32_t R = ctx->cfg.run_chunks;
-    if (R == 0) R = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(64, nchunks / 8192));
+    if (R == 0) R = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(32, nchunks / 8192));
     R += R & 1;                                                   // the scan loop is unrolled by two chunks
     const uint32_t nruns = (uint32_t)std::max<uint64_t>(1, (nchunks + R - 1) / R);
     uint32_t cap = ctx->cfg.slot_cap;
@@ -1065,7 +1110,8 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     if (cap > R * (uint32_t)kChunkSamples) cap = R * kChunkSamples;
 
     int rc;
-    size_t want = (size_t)nruns * cap * sizeof(uint32_t);
+    const uint32_t ngroups = (nruns + kDemodGroup - 1) / kDemodGroup;       // demod_kernel's unit of work and of candidate lists
+    size_t want = (size_t)ngroups * kDemodGroup * cap * sizeof(uint32_t);
     if ((rc = grow(ctx, &ctx->d_slots, &ctx->slots_bytes, want)) != MODES_OK) return rc;
     if (ctx->cfg.keep_candidates && (rc = grow(ctx, &ctx->d_cand_slots, &ctx->cand_slots_bytes, want)) != MODES_OK) return rc;
     if (ctx->counts_elems < nruns) {
@@ -1118,9 +1164,9 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     else
         hipLaunchKernelGGL(scan_kernel, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st, sp);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((nruns + 3) / 4, 1024u)), dim3(256), 0, st, dp);
+    hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((ngroups + kDemodWaves - 1) / kDemodWaves, 1024u)), dim3(kDemodWaves * 64), 0, st, dp);
     if (ctx->cfg.keep_candidates)
-        hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st, d_cand_counts, nruns, ctx->d_cand_offsets);
+        hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st, d_cand_counts, ngroups, ctx->d_cand_offsets);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hdr, ctx->d_hdr, sizeof(ResultHeader), hipMemcpyDeviceToHost, st));
@@ -1160,8 +1206,9 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_cand_dense), want * sizeof(uint64_t)));
             ctx->cand_dense_elems = want;
         }
-        hipLaunchKernelGGL(compact_candidates_kernel, dim3((ctx->nruns + 3) / 4), dim3(256), 0, st, ctx->d_cand_slots,
-                           ctx->d_counts + ctx->nruns, ctx->d_cand_offsets, ctx->nruns, ctx->slot_cap, ctx->g0,
+        const uint32_t ngroups = (ctx->nruns + kDemodGroup - 1) / kDemodGroup;
+        hipLaunchKernelGGL(compact_candidates_kernel, dim3((ngroups + 3) / 4), dim3(256), 0, st, ctx->d_cand_slots,
+                           ctx->d_counts + ctx->nruns, ctx->d_cand_offsets, ngroups, ctx->slot_cap * kDemodGroup, ctx->g0,
                            ctx->d_cand_dense);
         HIP_TRY(ctx, hipGetLastError());
         ctx->h_cands.resize(hdr.n_preambles);
