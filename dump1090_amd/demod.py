@@ -243,18 +243,30 @@ class Demodulator:
         return self._unpack(res)
 
     # ---- the whole path -----------------------------------------------------------------------
-    def demodulate(self, data, resolver: HostResolver | None = None):
-        """Whole stream (numpy uint8 on the host, or a CUDA uint8 tensor) -> list[Message]."""
+    def demodulate(self, data, resolver: HostResolver | None = None, batch_blocks: int = 8192):
+        """Whole stream (numpy uint8 on the host, or a CUDA uint8 tensor) -> list[Message].
+        The stream is walked `batch_blocks` buffers (2 GiB by default) per GPU call, like the
+        reference's main loop walks it one buffer at a time (dump1090.c:2969-2990); the resolver
+        carries the ICAO whitelist from batch to batch."""
         own = resolver is None
         if own:
             resolver = HostResolver(**self.flags)
         try:
-            if isinstance(data, np.ndarray):
-                recs, cands, _ = self.records_from_host(data)
-            else:
-                self.detect(data)
-                recs, cands, _ = self.fetch()
-            msgs = resolver.resolve(recs, cands)
+            n = data.size if isinstance(data, np.ndarray) else data.numel()
+            total = block_count(n)
+            msgs, tot = [], dict(n_records=0, n_forwarded=0, n_preambles=0, scan_ms=0.0, demod_ms=0.0)
+            for b0 in range(0, total, batch_blocks):
+                nb = min(batch_blocks, total - b0)
+                lo, hi = shard_byte_range(b0, nb, n)
+                if isinstance(data, np.ndarray):
+                    recs, cands, info = self.records_from_host(data[lo:hi], stream_byte0=lo, first_block=b0, nblocks=nb)
+                else:
+                    self.detect(data[lo:hi], stream_byte0=lo, first_block=b0, nblocks=nb)
+                    recs, cands, info = self.fetch()
+                msgs += resolver.resolve(recs, cands)
+                for k in tot:
+                    tot[k] += info[k]
+            self.last = dict(tot)
             self.last["stats"] = resolver.stats()
             self.last["stats_text"] = resolver.stats_text()
             return msgs

@@ -177,3 +177,27 @@ def run_ref(path: str, flags: list[str]) -> str:
     """stdout of the compiled reference under the constant-clock interposer."""
     env = dict(os.environ, LD_PRELOAD=FIXED_TIME)
     return subprocess.run([REF_BIN, "--ifile", path] + flags, capture_output=True, env=env, check=True).stdout.decode()
+
+
+def run_ref_bytes(data: np.ndarray, flags: list[str]) -> bytes:
+    """stdout of the compiled reference fed through --ifile - (stdin), constant clock.  For streams too
+    big for a temp file; `data` must be oracle-safe (multiple of 262144 bytes, >= 480 trailing 127s)."""
+    import threading
+    env = dict(os.environ, LD_PRELOAD=FIXED_TIME)
+    proc = subprocess.Popen([REF_BIN, "--ifile", "-"] + flags, stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+    view = memoryview(np.ascontiguousarray(data, dtype=np.uint8)).cast("B")
+
+    def feed():
+        step = 1 << 24
+        try:
+            for lo in range(0, len(view), step):
+                proc.stdin.write(view[lo:lo + step])
+        finally:
+            proc.stdin.close()
+
+    t = threading.Thread(target=feed, daemon=True)
+    t.start()
+    out = proc.stdout.read()
+    t.join()
+    assert proc.wait() == 0
+    return out

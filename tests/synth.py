@@ -202,6 +202,87 @@ def frames_stream(seed: int, nblocks: int, *, spacing: int = 3000, sigma_q16: in
     return finish_stream(iq), placed
 
 
+# ------------------------------------------------- big sparse streams (BASELINE configs 3-5)
+
+
+class SparseFrameStream:
+    """sigma-noise(seed) with frames added at given places, defined lazily so that it can be as big as
+    BASELINE's 8 GiB / 64 GiB configs: the device builds it as synth_noise + a scatter of `patches()`,
+    the host materialises any byte range with `window()`; both are the same bytes.
+
+    placements: list of (sample, frame_bytes, amp, phase, smear16); frames must not overlap.
+    The last 480 bytes are 127 (finish_stream)."""
+
+    SPAN = 16 + 224 + 2          # samples a frame can touch (long frame + smear tail), rounded up
+
+    def __init__(self, seed: int, nbytes: int, sigma_q16: int, placements):
+        assert nbytes % DATA_LEN == 0
+        self.seed, self.nbytes, self.sigma_q16 = seed, nbytes, sigma_q16
+        self.placements = sorted(placements, key=lambda p: p[0])
+        self._starts = np.array([p[0] for p in self.placements], dtype=np.int64)
+
+    def window(self, lo: int, hi: int) -> np.ndarray:
+        """Bytes [lo, hi) of the stream (lo even)."""
+        assert lo % 2 == 0 and 0 <= lo <= hi <= self.nbytes
+        out = noise_bytes(self.seed, lo, hi - lo, self.sigma_q16)
+        s_lo, s_hi = lo // 2, (hi + 1) // 2
+        a = int(np.searchsorted(self._starts, s_lo - self.SPAN, side="left"))
+        b = int(np.searchsorted(self._starts, s_hi, side="left"))
+        for sample, frame, amp, phase, smear in self.placements[a:b]:
+            add_frame(out, sample - s_lo, frame, amp, phase, smear)
+        tail = self.nbytes - 480
+        if hi > tail:
+            out[max(0, tail - lo):] = 127
+        return out
+
+    def patches(self):
+        """-> (first_byte int64[n], data uint8[n, 2*SPAN]): the final bytes of every frame's footprint."""
+        n = len(self.placements)
+        first = 2 * self._starts
+        data = np.empty((n, 2 * self.SPAN), dtype=np.uint8)
+        for k in range(n):
+            data[k] = self.window(int(first[k]), int(first[k]) + 2 * self.SPAN)
+        return first, data
+
+
+def config3_stream(seed: int, nblocks: int, *, per: int = 65536, sigma_q16: int = 941, amp=(40, 100),
+                   flip1: int = 10, edge_every: int = 997, smear=(0,), flip2: int = 0) -> SparseFrameStream:
+    """BASELINE config 3: sigma=3 noise + DF11/DF17 frames with valid parity, about one per `per`
+    samples at hashed offsets, amplitude 40..100, random carrier phase, one in `flip1` with one
+    flipped data bit; every `edge_every`-th frame sits at one of the buffer-seam offsets of
+    SURVEY.md 3.3 (EDGE_DELTAS) instead."""
+    nsamp = nblocks * BLOCK_STRIDE
+    placements = []
+    clean = {}
+    k = 0
+    for base in range(0, nsamp - per, per):
+        h = int(hash_at(seed ^ 0xC0F3, np.array([k], dtype=np.uint64))[0])
+        o = base + 300 + h % (per - 900)
+        if edge_every and k % edge_every == edge_every - 1:
+            seam = (base // BLOCK_STRIDE + 1) * BLOCK_STRIDE - CARRY
+            if seam + 300 < nsamp:
+                o = seam + EDGE_DELTAS[(k // edge_every) % len(EDGE_DELTAS)]
+        df = 17 if (h >> 9) & 1 else 11
+        pay = bytearray(_payload(seed, 14, k))
+        fb = bytearray(make_frame(df, bytes(pay)))
+        nb = len(fb) * 8
+        if flip2 and (h >> 20) % flip2 == 0:
+            for sh in (24, 34):
+                bit = 5 + (h >> sh) % (nb - 5)
+                fb[bit >> 3] ^= 0x80 >> (bit & 7)
+        elif flip1 and (h >> 20) % flip1 == 0:
+            bit = 5 + (h >> 24) % (nb - 5)
+            fb[bit >> 3] ^= 0x80 >> (bit & 7)
+        a = amp[0] + (h >> 44) % (amp[1] - amp[0] + 1)
+        sm = smear[(h >> 52) % len(smear)]
+        placements.append((o, bytes(fb), int(a), int((h >> 56) & 63), int(sm)))
+        clean[o] = make_frame(df, bytes(pay))
+        k += 1
+    st = SparseFrameStream(seed, nblocks * DATA_LEN, sigma_q16, placements)
+    st.clean = clean                 # sample -> the frame as transmitted before any bit flip
+    return st
+
+
 # ---------------------------------------------------------- named test streams
 
 def case_uniform(seed: int = 11, nblocks: int = 3) -> np.ndarray:
