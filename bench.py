@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--cpu-mib", type=int, default=1024, help="MiB of the workload timed on the CPU baseline")
     ap.add_argument("--run-chunks", type=int, default=0)
     ap.add_argument("--scan-variant", type=int, default=0, help="0 = production scan kernel, 1 = fused single-pass scan")
+    ap.add_argument("--depth", type=int, default=2, help="detect calls in flight (contexts used alternately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -115,7 +116,12 @@ def main():
         nblocks += 1
     lo, hi = shard_byte_range(first_block, nblocks, total)
 
-    demod = Demodulator(device=local, fix=False, run_chunks=args.run_chunks, scan_variant=args.scan_variant)
+    # Two contexts, used alternately: step i+1's kernels are queued before step i's records are fetched
+    # and resolved, so the GPU never waits for the host (the C host double-buffers the same way).
+    # Every step still does all of its work; K steps = K detects + K fetches + K resolves.
+    demods = [Demodulator(device=local, fix=False, run_chunks=args.run_chunks, scan_variant=args.scan_variant)
+              for _ in range(max(1, args.depth))]
+    demod = demods[0]
     iq = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
     demod.synth_noise(iq, first_byte=lo, seed=20260922, sigma_q16=941)
     if hi == total:
@@ -128,29 +134,48 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    scan_ms, demod_ms, n_msgs, n_pre, n_fwd = [], [], 0, 0, 0
-    t0 = None
-    for step in range(args.warmup + args.steps):
-        if step == args.warmup:
-            sync_all()
-            t0 = time.perf_counter()
-        demod.detect(iq, stream_byte0=lo, first_block=first_block, nblocks=nblocks)
-        recs, cands, info = demod.fetch()
+    scan_ms, demod_ms, n_pre, n_fwd = [], [], 0, 0
+    n_msgs = [0]
+
+    def finish(d, timed):
+        """fetch + (gather) + sequential host resolve of the detect in flight on context d"""
+        nonlocal n_pre, n_fwd
+        recs, cands, info = d.fetch()
         if world > 1:
             recs, cands = gather_records(recs, cands, dst=0, device=dev)
         if rank == 0:
             res = HostResolver(fix=False)
             m = res.count(recs, cands)
             res.close()
-        if step >= args.warmup:
+            if timed:
+                n_msgs[0] += m
+        if timed:
             scan_ms.append(info["scan_ms"])
             demod_ms.append(info["demod_ms"])
-            if rank == 0:
-                n_msgs += m
-            n_pre = info["n_preambles"]
-            n_fwd = info.get("n_forwarded", 0)
+        n_pre, n_fwd = info["n_preambles"], info.get("n_forwarded", 0)
+
+    in_flight = []                                  # contexts with a detect queued, oldest first
+    t0 = None
+    for step in range(args.warmup + args.steps):
+        if step == args.warmup:
+            while in_flight:
+                finish(in_flight.pop(0), False)
+            sync_all()
+            t0 = time.perf_counter()
+        d = demods[step % len(demods)]
+        if d in in_flight:                          # its previous detect must be fetched first
+            while in_flight:
+                x = in_flight.pop(0)
+                finish(x, step > args.warmup)
+                if x is d:
+                    break
+        d.detect(iq, stream_byte0=lo, first_block=first_block, nblocks=nblocks)
+        in_flight.append(d)
+    while in_flight:
+        finish(in_flight.pop(0), True)
     sync_all()
     elapsed = time.perf_counter() - t0
+    n_msgs = n_msgs[0]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -168,8 +193,8 @@ def main():
         "config": {"workload": "%d MiB synthetic uint8 IQ @ 2 Msps format per GPU (sigma=3 integer noise, seed "
                                "20260922), --no-fix, HBM-resident; BASELINE.json configs[1]" % args.mib,
                    "bytes_per_gpu": per_gpu, "flags": "--raw --no-fix", "sharding": "buffers over %d rank(s)" % world,
-                   "step": "scan + demod kernels, record fetch%s, host resolve" % (
-                       ", RCCL gather to rank 0" if world > 1 else "")},
+                   "step": "scan + demod kernels, record fetch%s, host resolve; %d detect(s) in flight" % (
+                       ", RCCL gather to rank 0" if world > 1 else "", len(demods))},
         "msgs_per_s": round(n_msgs / elapsed, 2),
         "preambles_per_step_rank0": int(n_pre), "forwarded_per_step_rank0": int(n_fwd),
         "kernel_ms": {"scan": round(scan_avg_ms, 4), "demod_finalize": round(float(np.mean(demod_ms)), 4)},
@@ -181,7 +206,8 @@ def main():
         line["cpu_baseline"] = cpu_baseline(iq, min(args.cpu_mib << 20, (hi - lo) // 262144 * 262144))
     if rank == 0:
         print(json.dumps(line), flush=True)
-    demod.close()
+    for d in demods:
+        d.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -23,6 +23,7 @@
 // No MFMA (integer scan, HBM-bound), no CUDA compatibility layer, wave64 only.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanPara
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t run = blockIdx.x * kScanWaves + wave;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.hdr = ResultHeader{0, 0, 0, 0};   // demod_kernel accumulates into it
     if (run >= P.nruns) return;
     uint32_t *ring = ring_all[wave];
 
@@ -276,10 +278,7 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanPara
             count += (uint32_t)__builtin_popcountll(hb);
         }
     }
-    if (lane == 0) {
-        P.counts[run] = count;
-        if (count > P.slot_cap) atomicOr(&P.hdr->overflow, 1u);
-    }
+    if (lane == 0) P.counts[run] = count;                 // true count; demod_kernel flags count > slot_cap
 }
 
 // ------------------------------------------------------------------------------------
@@ -293,6 +292,7 @@ struct DemodParams {
     int64_t lo, hi;
     uint64_t g0;
     uint32_t nruns;
+    uint32_t run_chunks;
     uint32_t slot_cap;
     const uint32_t *slots;
     const uint32_t *counts;
@@ -460,10 +460,7 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
     }
     if (c < c1) step(power16_sat(x), wr0, rd0a, rd0b, c);                    // odd tail (last run only)
     if (qn) scan_beta(P, queue, qn, lane, my_slots, count);
-    if (lane == 0) {
-        P.counts[run] = count;
-        if (count > P.slot_cap) atomicOr(&P.hdr->overflow, 1u);
-    }
+    if (lane == 0) P.counts[run] = count;                 // true count; demod_kernel flags count > slot_cap
 }
 
 __global__ __launch_bounds__(kScan2Waves * kWave) void scan_kernel(ScanParams P) {
@@ -472,6 +469,7 @@ __global__ __launch_bounds__(kScan2Waves * kWave) void scan_kernel(ScanParams P)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: addresses stay in SGPRs
     const uint32_t run = blockIdx.x * kScan2Waves + wave;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.hdr = ResultHeader{0, 0, 0, 0};   // demod_kernel accumulates into it
     if (run >= P.nruns) return;
     // Runs whose loads (chunks c0-1 .. c1+1, the prefetch runs two chunks ahead) all lie inside the
     // span take the unguarded instantiation; that is every run except the first and the last few.
@@ -608,6 +606,36 @@ __device__ __forceinline__ void gate_sums(const uint8_t *iq, int64_t lo, int64_t
     *d112 = s112;
 }
 
+// gate_sums<false> with half the memory instructions and packed index arithmetic: a bit pair is four
+// consecutive bytes (I_lo Q_lo I_hi Q_hi) at a 2-byte aligned address, fetched as ONE dword through a
+// raw buffer descriptor (the hardware runs in unaligned-access mode; no alignment is promised to the
+// compiler), and both LUT indices |I-127|*129 + |Q-127| come out of one v_pk_mad_u16.
+// voff = byte offset of pair `gl` of the preamble from the descriptor's base.
+typedef short modes_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_abs_diff127(uint32_t x) {
+    const modes_s16x2 d = __builtin_bit_cast(modes_s16x2, x) - (modes_s16x2){127, 127};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_abs(d));
+}
+__device__ __forceinline__ void gate_sums_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const uint16_t *s_lut, int gl,
+                                               int *d56, int *d112) {
+    uint32_t w[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 64u * i, 0, 0);
+    int s56 = 0, s112 = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const uint32_t ai = pk_abs_diff127(w[i] & 0x00FF00FFu);              // (|I_lo-127|, |I_hi-127|)
+        const uint32_t aq = pk_abs_diff127((w[i] >> 8) & 0x00FF00FFu);
+        const uint32_t idx = pk_add(pk_mul(ai, 0x00810081u), aq);           // both LUT indices (<= 16640)
+        const int a = s_lut[idx & 0xffffu], b = s_lut[idx >> 16];
+        const int d = a > b ? a - b : b - a;
+        s112 += d;
+        if (gl + 16 * i < 56) s56 += d;
+    }
+    *d56 = s56;
+    *d112 = s112;
+}
+
 template <bool GUARD>
 __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t *s_lut, int lane, int64_t pc, int sum56,
                                            int sum112) {
@@ -714,9 +742,14 @@ __global__ __launch_bounds__(kDemodWaves * 64) void demod_kernel(DemodParams P) 
     const uint32_t ngroups = (P.nruns + kDemodGroup - 1) / kDemodGroup;
     for (uint32_t group = blockIdx.x * kDemodWaves + wave; group < ngroups; group += gridDim.x * kDemodWaves) {
         const uint32_t run0 = group * kDemodGroup;
+        // every position of the group is >= gbase and < gbase + 2^20 samples: 32-bit buffer offsets
+        const int64_t gbase = (int64_t)__builtin_amdgcn_readfirstlane(run0) * P.run_chunks * kChunkSamples - 64;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(iq) + 2 * gbase, 0,
+                                                                              0x7fffffff, 0x00020000);
         uint32_t cnt = 0;
         if (lane < kDemodGroup && run0 + lane < P.nruns) {
             const uint32_t true_count = P.counts[run0 + lane];
+            if (true_count > P.slot_cap) atomicOr(&P.hdr->overflow, 1u);   // the scan dropped positions: the call fails
             cnt = min(true_count, P.slot_cap);
             tot_fwd += true_count;                                           // summed over lanes at the end
         }
@@ -767,7 +800,7 @@ __global__ __launch_bounds__(kDemodWaves * 64) void demod_kernel(DemodParams P) 
                 const bool in2 = !gact || samples_inside(pc - 1, pc + 239, lo, hi);
                 const bool fast = __all(in2);
                 if (gact) {
-                    if (fast) gate_sums<false>(iq, lo, hi, s_lut, pc, gl, &d56, &d112);
+                    if (fast) gate_sums_fast(rsrc, (uint32_t)(2 * (pc - gbase)) + 32u + 4u * (uint32_t)gl, s_lut, gl, &d56, &d112);
                     else      gate_sums<true>(iq, lo, hi, s_lut, pc, gl, &d56, &d112);
                 }
 #pragma unroll
@@ -891,7 +924,7 @@ struct modes_gpu {
     int maxfix = 1;
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // before / after the scan kernel, results on the host
     std::string err;
 
     uint16_t *d_lut = nullptr;
@@ -1124,8 +1157,6 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     }
     uint32_t *d_counts = ctx->d_counts, *d_cand_counts = ctx->d_counts + nruns;
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_hdr, 0, sizeof(ResultHeader), st));
-
     ScanParams sp{};
     sp.iq = base;
     sp.lo = byte_lo;
@@ -1147,6 +1178,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     dp.hi = sp.hi;
     dp.g0 = g0;
     dp.nruns = nruns;
+    dp.run_chunks = R;
     dp.slot_cap = cap;
     dp.slots = ctx->d_slots;
     dp.counts = d_counts;
@@ -1158,18 +1190,21 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     dp.hdr = ctx->d_hdr;
     dp.max_records = ctx->cfg.max_records;
 
+    // The header is zeroed by the scan kernel itself, so a detect is exactly: scan, demod, (prefix,)
+    // 24-byte copy.  Events: around the scan (the roofline kernel) and after the copy.
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     if (ctx->cfg.scan_variant == 1)
         hipLaunchKernelGGL(scan_fused_kernel, dim3((nruns + kScanWaves - 1) / kScanWaves), dim3(kScanWaves * kWave), 0, st, sp);
     else
         hipLaunchKernelGGL(scan_kernel, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st, sp);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((ngroups + kDemodWaves - 1) / kDemodWaves, 1024u)), dim3(kDemodWaves * 64), 0, st, dp);
+    hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((ngroups + kDemodWaves - 1) / kDemodWaves, 1024u)),
+                       dim3(kDemodWaves * 64), 0, st, dp);
     if (ctx->cfg.keep_candidates)
         hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st, d_cand_counts, ngroups, ctx->d_cand_offsets);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hdr, ctx->d_hdr, sizeof(ResultHeader), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
 
     ctx->last_stream = st;
     ctx->in_flight = true;
@@ -1184,8 +1219,10 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
     if (!res) return fail(ctx, MODES_ERR_ARG, "fetch: null result");
     if (!ctx->in_flight) return fail(ctx, MODES_ERR_STATE, "fetch: no detect in flight");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    hipStream_t st = ctx->last_stream;
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    // Wait for THIS detect only (other work may already be queued behind it on the caller's stream);
+    // what follows runs on the context's own stream.
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
+    hipStream_t st = ctx->own_stream;
     ctx->in_flight = false;
     memset(res, 0, sizeof *res);
     const ResultHeader hdr = *ctx->h_hdr;
@@ -1231,7 +1268,7 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
     res->n_forwarded = hdr.n_forwarded;
     res->n_preambles = hdr.n_preambles;
     (void)hipEventElapsedTime(&res->scan_ms, ctx->ev[0], ctx->ev[1]);
-    (void)hipEventElapsedTime(&res->demod_ms, ctx->ev[1], ctx->ev[2]);
+    (void)hipEventElapsedTime(&res->demod_ms, ctx->ev[1], ctx->ev[2]);      // demod (+ prefix) + header copy
     return MODES_OK;
 }
 

@@ -100,7 +100,7 @@ typedef struct {
     uint64_t            n_forwarded;   /* positions the s-domain scan forwarded       */
     uint64_t            n_preambles;   /* positions where dump1090.c:1602-1650 holds  */
     float               scan_ms;       /* HIP-event time of the scan kernel           */
-    float               demod_ms;      /* HIP-event time of the demod kernel          */
+    float               demod_ms;      /* demod kernel + result-header copy           */
 } modes_gpu_result;
 
 int  modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out);
