@@ -284,6 +284,9 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanPara
 // ------------------------------------------------------------------------------------
 // demod_kernel - one wavefront per run, one lane per forwarded position.
 // ------------------------------------------------------------------------------------
+#ifdef MODES_TRACE
+__device__ unsigned long long g_trace[8192 * 4];      // per demod wavefront: start, LUT staged, end, group
+#endif
 constexpr int kDemodWaves = 8;        // wavefronts per demod workgroup (they share one 33 KB LUT copy in LDS)
 constexpr int kDemodGroup = 4;        // runs whose slot lists one demod wavefront walks together (power of two <= 64)
 
@@ -570,32 +573,53 @@ __device__ __forceinline__ void slice_pass(int lane, int lo1, int hi1, int lo2, 
 // Full demodulation of one preamble by the whole wavefront (both attempts) -> record.
 // sum56 / sum112: the delta sums of dump1090.c:1713-1717 (already computed by the pre-gate).
 // Exact preamble predicate (dump1090.c:1602-1650) at buffer sample p, magnitudes from the LDS LUT.
-template <bool GUARD>
-__device__ __forceinline__ bool preamble_at(const uint8_t *iq, int64_t lo, int64_t hi, const uint16_t *s_lut, uint32_t p) {
-    const int64_t even = (int64_t)(p & ~1u);
-    int mm[16];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t w = load_dword<GUARD>(iq, 2 * even + 4 * i, lo, hi);
-        mm[2 * i] = mag_of(s_lut, w & 0xffffu);
-        mm[2 * i + 1] = mag_of(s_lut, w >> 16);
-    }
-    const bool odd = (p & 1u) != 0;
+// Both LUT indices |I-127|*129 + |Q-127| of a dword I0 Q0 I1 Q1 (two samples) in one packed value.
+typedef short modes_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_abs_diff127(uint32_t x) {
+    const modes_s16x2 d = __builtin_bit_cast(modes_s16x2, x) - (modes_s16x2){127, 127};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_abs(d));
+}
+__device__ __forceinline__ uint32_t pk_lut_index(uint32_t w) {
+    const uint32_t ai = pk_abs_diff127(w & 0x00FF00FFu);                     // (|I0-127|, |I1-127|)
+    const uint32_t aq = pk_abs_diff127((w >> 8) & 0x00FF00FFu);
+    return pk_add(pk_mul(ai, 0x00810081u), aq);                              // both <= 16640
+}
+
+// Exact preamble predicate (dump1090.c:1602-1650) at buffer sample p, magnitudes from the LDS LUT.
+// Guarded form: 2-byte loads, bytes outside the span read as 127.
+__device__ __forceinline__ bool preamble_at_guarded(const uint8_t *iq, int64_t lo, int64_t hi, const uint16_t *s_lut, uint32_t p) {
     int m[15];
 #pragma unroll
-    for (int t = 0; t < 15; t++) m[t] = odd ? mm[t + 1] : mm[t];
+    for (int t = 0; t < 15; t++) m[t] = mag_of(s_lut, load_sample<true>(iq, (int64_t)p + t, lo, hi));
+    struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
+    return modes_preamble_exact(Win{m});
+}
+// Fast form: the 15 samples are 8 dwords at a 2-byte aligned address (unaligned-access mode, raw buffer
+// descriptor); voff = byte offset of sample p from the descriptor's base.
+__device__ __forceinline__ bool preamble_at_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const uint16_t *s_lut) {
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 4u * i, 0, 0);
+    int m[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t idx = pk_lut_index(w[i]);
+        m[2 * i] = s_lut[idx & 0xffffu];
+        m[2 * i + 1] = s_lut[idx >> 16];
+    }
     struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
     return modes_preamble_exact(Win{m});
 }
 
-// Sums of |lo-hi| over pairs gl, gl+16, ... of the preamble at pc (one 16-lane group).
+// Sums of |lo-hi| over pairs gl, gl+kGateLanes, ... of the preamble at pc (one kGateLanes-lane group).
+constexpr int kGateLanes = 8;         // lanes per preamble in the gate pre-test -> 64 / 8 preambles per iteration
 template <bool GUARD>
 __device__ __forceinline__ void gate_sums(const uint8_t *iq, int64_t lo, int64_t hi, const uint16_t *s_lut, int64_t pc, int gl,
                                           int *d56, int *d112) {
     int s56 = 0, s112 = 0;
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-        const int k = gl + 16 * i;
+    for (int i = 0; i < 112 / kGateLanes; i++) {
+        const int k = gl + kGateLanes * i;
         const int a = mag_of(s_lut, load_sample<GUARD>(iq, pc + 16 + 2 * k, lo, hi));
         const int b = mag_of(s_lut, load_sample<GUARD>(iq, pc + 17 + 2 * k, lo, hi));
         const int d = a > b ? a - b : b - a;
@@ -611,26 +635,20 @@ __device__ __forceinline__ void gate_sums(const uint8_t *iq, int64_t lo, int64_t
 // raw buffer descriptor (the hardware runs in unaligned-access mode; no alignment is promised to the
 // compiler), and both LUT indices |I-127|*129 + |Q-127| come out of one v_pk_mad_u16.
 // voff = byte offset of pair `gl` of the preamble from the descriptor's base.
-typedef short modes_s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_abs_diff127(uint32_t x) {
-    const modes_s16x2 d = __builtin_bit_cast(modes_s16x2, x) - (modes_s16x2){127, 127};
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_abs(d));
-}
 __device__ __forceinline__ void gate_sums_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const uint16_t *s_lut, int gl,
                                                int *d56, int *d112) {
-    uint32_t w[7];
+    constexpr int kIter = 112 / kGateLanes;
+    uint32_t w[kIter];
 #pragma unroll
-    for (int i = 0; i < 7; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 64u * i, 0, 0);
+    for (int i = 0; i < kIter; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 4u * kGateLanes * i, 0, 0);
     int s56 = 0, s112 = 0;
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-        const uint32_t ai = pk_abs_diff127(w[i] & 0x00FF00FFu);              // (|I_lo-127|, |I_hi-127|)
-        const uint32_t aq = pk_abs_diff127((w[i] >> 8) & 0x00FF00FFu);
-        const uint32_t idx = pk_add(pk_mul(ai, 0x00810081u), aq);           // both LUT indices (<= 16640)
+    for (int i = 0; i < kIter; i++) {
+        const uint32_t idx = pk_lut_index(w[i]);                             // both LUT indices
         const int a = s_lut[idx & 0xffffu], b = s_lut[idx >> 16];
         const int d = a > b ? a - b : b - a;
         s112 += d;
-        if (gl + 16 * i < 56) s56 += d;
+        if (gl + kGateLanes * i < 56) s56 += d;
     }
     *d56 = s56;
     *d112 = s112;
@@ -721,14 +739,20 @@ __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t 
 //            (coalesced sample loads; the sequential parts of the reference become carry chains,
 //            see modes_core.h).  Positions whose first noise gate passes become records.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kDemodWaves * 64) void demod_kernel(DemodParams P) {
+__global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80))) void demod_kernel(DemodParams P) {
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[kLutVec * 8];
     __shared__ uint32_t s_list[kDemodWaves][64];
     __shared__ uint32_t s_pre[kDemodWaves][kDemodGroup];
     __shared__ unsigned long long s_tot[2];
+#ifdef MODES_TRACE
+    const unsigned long long t_start = wall_clock64();
+#endif
     stage_lut<kDemodWaves * 64>(s_lut, P.tab.lut);
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
     __syncthreads();
+#ifdef MODES_TRACE
+    const unsigned long long t_lut = wall_clock64();
+#endif
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -774,10 +798,10 @@ __global__ __launch_bounds__(kDemodWaves * 64) void demod_kernel(DemodParams P) 
                 if (s_pre[wave][rr + step] <= e) rr += step;
             const uint32_t p = active ? P.slots[(uint64_t)(run0 + rr) * P.slot_cap + (e - s_pre[wave][rr])] : 0u;
             // fast path when every lane's 16-sample window is inside the span (wave-uniform test)
-            const bool in1 = !active || samples_inside((int64_t)(p & ~1u), (int64_t)(p & ~1u) + 15, lo, hi);
+            const bool in1 = !active || samples_inside((int64_t)p, (int64_t)p + 15, lo, hi);
             bool ok;
-            if (__all(in1)) ok = active && preamble_at<false>(iq, lo, hi, s_lut, p);
-            else            ok = active && preamble_at<true>(iq, lo, hi, s_lut, p);
+            if (__all(in1)) ok = active && preamble_at_fast(rsrc, (uint32_t)(2 * ((int64_t)p - gbase)), s_lut);
+            else            ok = active && preamble_at_guarded(iq, lo, hi, s_lut, p);
             const uint64_t okb = __ballot(ok);
             const uint32_t rank = (uint32_t)__builtin_popcountll(okb & ((1ull << lane) - 1));
             if (ok) {
@@ -791,8 +815,9 @@ __global__ __launch_bounds__(kDemodWaves * 64) void demod_kernel(DemodParams P) 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             // ---------------- stage 2 + 3 ----------------
-            const int grp = lane >> 4, gl = lane & 15;
-            for (uint32_t c0 = 0; c0 < nlist; c0 += 4) {
+            constexpr int kPerIter = 64 / kGateLanes;                        // preambles per iteration
+            const int grp = lane / kGateLanes, gl = lane % kGateLanes;
+            for (uint32_t c0 = 0; c0 < nlist; c0 += kPerIter) {
                 const uint32_t c = c0 + (uint32_t)grp;
                 const bool gact = c < nlist;
                 const int64_t pc = gact ? (int64_t)s_list[wave][c] : 0;
@@ -804,16 +829,16 @@ __global__ __launch_bounds__(kDemodWaves * 64) void demod_kernel(DemodParams P) 
                     else      gate_sums<true>(iq, lo, hi, s_lut, pc, gl, &d56, &d112);
                 }
 #pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) {                     // reduce within each 16-lane group
+                for (int off = kGateLanes / 2; off >= 1; off >>= 1) {        // reduce within each group
                     d56 += __shfl_xor(d56, off, 64);
                     d112 += __shfl_xor(d112, off, 64);
                 }
                 const bool may_pass = gact && (d112 / 56 >= 2550 || d56 / 28 >= 2550);
                 uint64_t todo = __ballot(may_pass && gl == 0);
                 while (todo) {
-                    const int leader = __builtin_ctzll(todo);                // lane 0, 16, 32 or 48
+                    const int leader = __builtin_ctzll(todo);                // first lane of a group
                     todo &= todo - 1;
-                    const int64_t pcs = (int64_t)s_list[wave][c0 + (uint32_t)(leader >> 4)];
+                    const int64_t pcs = (int64_t)s_list[wave][c0 + (uint32_t)(leader / kGateLanes)];
                     const int s56 = __builtin_amdgcn_readlane(d56, leader), s112 = __builtin_amdgcn_readlane(d112, leader);
                     if (fast) demod_full<false>(P, s_lut, lane, pcs, s56, s112);
                     else      demod_full<true>(P, s_lut, lane, pcs, s56, s112);
@@ -825,6 +850,12 @@ __global__ __launch_bounds__(kDemodWaves * 64) void demod_kernel(DemodParams P) 
         tot_cand += ncand;
         if (lane == 0) P.cand_counts[group] = ncand;
     }
+#ifdef MODES_TRACE
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t w = blockIdx.x * kDemodWaves + (threadIdx.x >> 6);
+        if (w < 8192) { g_trace[4 * w] = t_start; g_trace[4 * w + 1] = t_lut; g_trace[4 * w + 2] = wall_clock64(); g_trace[4 * w + 3] = tot_cand; }
+    }
+#endif
     // totals: one pair of atomics per workgroup (tot_fwd is per lane, tot_cand wave-uniform)
     tot_fwd = (unsigned long long)wave_sum((int)tot_fwd);                    // < 2^31 per wavefront (slot lists are u32-indexed)
     if (lane == 0) {
@@ -945,6 +976,8 @@ struct modes_gpu {
 
     uint8_t *d_stage = nullptr;       size_t stage_bytes = 0;
 
+    uint32_t demod_wgs = 1024;        // workgroups of demod_kernel that are resident at once (occupancy x CUs)
+
     // geometry of the detect in flight
     bool in_flight = false;
     uint32_t nruns = 0, slot_cap = 0;
@@ -1010,6 +1043,13 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     } while (0)
     CREATE_TRY(hipSetDevice(cfg->device));
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    {   // demod_kernel is persistent: launch exactly as many workgroups as fit on the chip at once
+        hipDeviceProp_t prop;
+        int per_cu = 0;
+        CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
+        CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel, kDemodWaves * 64, 0));
+        ctx->demod_wgs = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, prop.multiProcessorCount);
+    }
     for (auto &e : ctx->ev) CREATE_TRY(hipEventCreate(&e));
     // tables: the magnitude LUT exactly as the reference builds it (dump1090.c:359-364, double
     // arithmetic on the host) and the 112 single-bit syndromes.
@@ -1198,7 +1238,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     else
         hipLaunchKernelGGL(scan_kernel, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st, sp);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((ngroups + kDemodWaves - 1) / kDemodWaves, 1024u)),
+    hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((ngroups + kDemodWaves - 1) / kDemodWaves, ctx->demod_wgs)),
                        dim3(kDemodWaves * 64), 0, st, dp);
     if (ctx->cfg.keep_candidates)
         hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st, d_cand_counts, ngroups, ctx->d_cand_offsets);
@@ -1285,5 +1325,11 @@ int modes_gpu_demod_host(modes_gpu *ctx, const uint8_t *iq, uint64_t nbytes, uin
     if ((rc = modes_gpu_detect(ctx, &span, ctx->own_stream)) != MODES_OK) return rc;
     return modes_gpu_fetch(ctx, res);
 }
+
+#ifdef MODES_TRACE
+int modes_gpu_trace(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"

@@ -93,6 +93,20 @@ constexpr int ITER = 4096;
 #define I_CMPSG_S1(x) asm volatile("v_cmp_gt_u32 s[20:21], %0, %1\n s_and_b64 s[26:27], s[22:23], s[24:25]" : : "v"(x), "v"(b) : "s20", "s21", "s26", "s27", "scc");
 #define I_CMP_ADDC2(x) asm volatile("v_cmp_gt_u32 vcc, %1, %0\n v_max_u32 %0, %0, %1\n v_addc_co_u32 %2, vcc, %2, %2, vcc" : "+v"(x) : "v"(b), "v"(c) : "vcc");
 
+#define I_CND64(x)    asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x) : "v"(b));
+#define I_CNDNEW(x)   asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(x) : "v"(b), "v"(c) : "vcc");
+#define I_BPERM(x)    asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(x) : "v"(b));
+#define I_SWIZ(x)     asm volatile("ds_swizzle_b32 %0, %0 offset:0x041F\n s_waitcnt lgkmcnt(0)" : "+v"(x));
+#define I_DPPXOR(x)   asm volatile("v_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x));
+#define I_DPPROR(x)   asm volatile("v_add_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(x));
+#define I_READLANE(x) asm volatile("v_readlane_b32 s20, %0, 5\n v_add_u32 %0, s20, %0" : "+v"(x) : : "s20");
+KERNEL(k_cnd64, I_CND64)
+KERNEL(k_cndnew, I_CNDNEW)
+KERNEL(k_bperm, I_BPERM)
+KERNEL(k_swiz, I_SWIZ)
+KERNEL(k_dppxor, I_DPPXOR)
+KERNEL(k_dppror, I_DPPROR)
+KERNEL(k_readlane, I_READLANE)
 KERNEL(k_cmpvcc, I_CMPVCC)
 KERNEL(k_cmpsg, I_CMPSG)
 KERNEL(k_cmpu16, I_CMPU16)
@@ -236,6 +250,9 @@ int main() {
               {"v_pk_fma_f16", k_pkfma16, 8}, {"v_mad_u32_u24", k_madu24, 8}, {"v_dot4_u32_u8", k_dot4, 8},
               {"v_lshl_or_b32", k_lshlor, 8}, {"v_sad_u8", k_sadu8, 8}, {"v_cmp+v_addc", k_cmp_addc, 16},
               {"v_mov_dpp row_shr", k_movdpp, 8}, {"v_sub_u32_sdwa", k_subsdwa, 8},
+              {"v_cndmask e64 sgpr", k_cnd64, 8}, {"v_cndmask vcc (no RAW)", k_cndnew, 8}, {"ds_bpermute+wait", k_bperm, 8},
+              {"ds_swizzle+wait", k_swiz, 8}, {"v_add_dpp quad_perm", k_dppxor, 8}, {"v_add_dpp row_ror", k_dppror, 8},
+              {"readlane+add", k_readlane, 16},
               {"v_cmp_gt_u32 vcc", k_cmpvcc, 8}, {"v_cmp_gt_u32 sgpr", k_cmpsg, 8}, {"v_cmp_gt_u16 vcc", k_cmpu16, 8},
               {"v_addc_co_u32 vcc", k_addc, 8}, {"v_addc_co_u32 sgpr", k_addcsg, 8}, {"v_max_u32", k_maxu32, 8},
               {"v_min_u32", k_minu32, 8}, {"v_sub_u32", k_subu32, 8}, {"v_lshrrev_b32", k_lshr, 8}, {"v_or_b32", k_or, 8},
@@ -249,7 +266,7 @@ int main() {
               {"[v_max_u32 + 1 salu] per v", k_v_s1, 8}, {"[v_max_u32 + 2 salu] per v", k_v_s2, 8},
               {"[v_cmp sgpr + 1 salu] per v", k_cmpsg_s1, 8}, {"[cmp,max,addc] per 3", k_cmp_addc2, 24},
               {"lds ring w128+3r128", k_lds_ring, 1}, {"4x (dpp wave_sh + add)", k_dpp_shift, 8}};
-    for (int wps : {2, 4}) {          // waves per SIMD
+    for (int wps : {4}) {          // waves per SIMD
         printf("-- %d wave(s) per SIMD (grid %d x 256)\n", wps, cus * wps);
         for (auto &k : ks) {
             const float ms = time_ms([&] { hipLaunchKernelGGL(k.fn, dim3(cus * wps), dim3(256), 0, 0, out, 1u); }, 5);
