@@ -4,13 +4,15 @@
 # Kernel-trace + stats in one run; counters in their own runs (never with --sys-trace etc.).
 set -u
 TAG=${1:-r01}
+shift || true
+EXTRA="$*"            # extra bench.py arguments, e.g. --scan-variant 2
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
-SHORT="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --depth 1 $EXTRA"
+SHORT="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --depth 1 $EXTRA"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -f csv -- $BENCH > "$OUT/kt.log" 2>&1
 echo "kt rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY \
