@@ -136,6 +136,9 @@ def main():
 
     scan_ms, demod_ms, n_pre, n_fwd = [], [], 0, 0
     n_msgs = [0]
+    # the kernels go to their own stream, so that the (tiny) RCCL size exchange of step i, issued on
+    # torch's current stream, does not queue behind the kernels of step i+1
+    work = torch.cuda.Stream(device=dev)
 
     def finish(d, timed):
         """fetch + (gather) + sequential host resolve of the detect in flight on context d"""
@@ -169,7 +172,7 @@ def main():
                 finish(x, step > args.warmup)
                 if x is d:
                     break
-        d.detect(iq, stream_byte0=lo, first_block=first_block, nblocks=nblocks)
+        d.detect(iq, stream_byte0=lo, first_block=first_block, nblocks=nblocks, stream=work)
         in_flight.append(d)
     while in_flight:
         finish(in_flight.pop(0), True)

@@ -11,8 +11,8 @@ without the HIP library / a GPU raises ModesError.
 from ._native import (BLOCK_POSITIONS, BLOCK_STRIDE, CARRY_BYTES, CARRY_SAMPLES, DATA_LEN, RECORD_DTYPE, ModesError,
                       ModesMessage)
 from .demod import (Demodulator, HostResolver, Message, block_count, onlyaddr_text, raw_text, shard_blocks,
-                    shard_byte_range)
+                    shard_byte_range, verbose_text)
 
 __all__ = ["Demodulator", "HostResolver", "Message", "ModesError", "ModesMessage", "RECORD_DTYPE", "block_count",
-           "shard_blocks", "shard_byte_range", "raw_text", "onlyaddr_text", "DATA_LEN", "CARRY_BYTES",
+           "shard_blocks", "shard_byte_range", "raw_text", "onlyaddr_text", "verbose_text", "DATA_LEN", "CARRY_BYTES",
            "BLOCK_STRIDE", "BLOCK_POSITIONS", "CARRY_SAMPLES"]

@@ -57,8 +57,11 @@ void show_help() {
 void on_message(const struct modesMessage *mm, uint32_t, uint32_t, void *user) {
     Sink *s = static_cast<Sink *>(user);
     if (s->opt->stats || !modes_host_wants(s->host, mm)) return;
-    char line[64];
-    int n = s->opt->onlyaddr ? modes_format_onlyaddr(mm, line) : modes_format_raw(mm, line);
+    char line[1024];
+    int n;
+    if (s->opt->onlyaddr) n = modes_format_onlyaddr(mm, line);
+    else if (s->opt->raw) n = modes_format_raw(mm, line);
+    else                  n = modes_format_verbose(mm, s->opt->check_crc, line, sizeof line);   // dump1090.c:1333-1450
     s->out.append(line, (size_t)n);
 }
 
@@ -100,10 +103,6 @@ int main(int argc, char **argv) {
     if (opt.filename.empty()) {
         fprintf(stderr, "dump1090_amd demodulates files only: give --ifile <file> (or '-').\n");
         return 1;
-    }
-    if (!opt.raw && !opt.onlyaddr && !opt.stats) {
-        fprintf(stderr, "note: the verbose message dump is not implemented; printing --raw lines.\n");
-        opt.raw = true;
     }
     if (opt.batch_blocks == 0) opt.batch_blocks = 1;
 

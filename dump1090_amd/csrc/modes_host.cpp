@@ -8,6 +8,7 @@
 #include "../../include/modes_host.h"
 
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -347,3 +348,165 @@ int modes_format_stats(const modes_host_stats *st, char *buf) {                 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Verbose message dump: what the reference prints for one message when neither --raw nor
+// --onlyaddr is given (displayModesMessage, dump1090.c:1314-1450, and the blank line
+// useModesMessage adds, dump1090.c:1814).  Written as a table of text fragments plus a small
+// appender; the strings are the output format and therefore have to be the reference's.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Out {
+    char *buf;
+    size_t cap, n;
+    void put(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
+        if (n >= cap) return;
+        va_list ap;
+        va_start(ap, fmt);
+        const int k = vsnprintf(buf + n, cap - n, fmt, ap);
+        va_end(ap);
+        if (k > 0) n += (size_t)k < cap - n ? (size_t)k : cap - n - 1;
+    }
+};
+
+// dump1090.c:1033-1054
+const char *const kCapability[8] = {
+    "Level 1 (Survillance Only)",
+    "Level 2 (DF0,4,5,11)",
+    "Level 3 (DF0,4,5,11,20,21)",
+    "Level 4 (DF0,4,5,11,20,21,24)",
+    "Level 2+3+4 (DF0,4,5,11,20,21,24,code7 - is on ground)",
+    "Level 2+3+4 (DF0,4,5,11,20,21,24,code7 - is on airborne)",
+    "Level 2+3+4 (DF0,4,5,11,20,21,24,code7)",
+    "Level 7 ???"};
+const char *const kFlightStatus[8] = {
+    "Normal, Airborne",
+    "Normal, On the ground",
+    "ALERT,  Airborne",
+    "ALERT,  On the ground",
+    "ALERT & Special Position Identification. Airborne or Ground",
+    "Special Position Identification. Airborne or Ground",
+    "Value 6 is not assigned",
+    "Value 7 is not assigned"};
+const char *const kAircraftType[4] = {"Aircraft Type D", "Aircraft Type C", "Aircraft Type B", "Aircraft Type A"};
+
+// getMEDescription, dump1090.c:1060-1086: (type range, subtype range) -> name
+struct MeName { int t0, t1, s0, s1; const char *name; };
+const MeName kMeNames[] = {
+    {1, 4, 0, 7, "Aircraft Identification and Category"},
+    {5, 8, 0, 7, "Surface Position"},
+    {9, 18, 0, 7, "Airborne Position (Baro Altitude)"},
+    {19, 19, 1, 4, "Airborne Velocity"},
+    {20, 22, 0, 7, "Airborne Position (GNSS Height)"},
+    {23, 23, 0, 0, "Test Message"},
+    {24, 24, 1, 1, "Surface System Status"},
+    {28, 28, 1, 1, "Extended Squitter Aircraft Status (Emergency)"},
+    {28, 28, 2, 2, "Extended Squitter Aircraft Status (1090ES TCAS RA)"},
+    {29, 29, 0, 1, "Target State and Status Message"},
+    {31, 31, 0, 1, "Aircraft Operational Status Message"},
+};
+const char *me_name(int type, int sub) {
+    for (const MeName &m : kMeNames)
+        if (type >= m.t0 && type <= m.t1 && sub >= m.s0 && sub <= m.s1) return m.name;
+    return "Unknown";
+}
+
+// decodeMovementField, dump1090.c:2056-2066: ground speed in knots (truncated), -1 = not available.
+// Piecewise linear: {last code of the segment, first code, knots per step, knots at the first code}.
+int movement_knots(int movement) {
+    if (movement == 0) return -1;
+    if (movement == 1) return 0;
+    static const struct { int last, first; double step, base; } seg[] = {
+        {8, 2, 0.125, 0.125}, {12, 9, 0.25, 1}, {38, 13, 0.5, 2}, {93, 39, 1, 15}, {108, 94, 2, 70}, {123, 109, 5, 100}};
+    for (const auto &g : seg)
+        if (movement <= g.last) return (int)((movement - g.first) * g.step + g.base);
+    return 175;
+}
+
+const char *unit_name(const struct modesMessage *mm) { return mm->unit == MODES_UNIT_METERS ? "meters" : "feet"; }
+
+void put_squitter(Out &o, const struct modesMessage *mm) {                       // dump1090.c:1382-1433
+    const int t = mm->metype, sub = mm->mesub;
+    if (t >= 1 && t <= 4) {
+        o.put("    Aircraft Type  : %s\n", kAircraftType[mm->aircraft_type & 3]);
+        o.put("    Identification : %s\n", mm->flight);
+    } else if (t >= 5 && t <= 18) {
+        o.put("    F flag   : %s\n", mm->fflag ? "odd" : "even");
+        o.put("    T flag   : %s\n", mm->tflag ? "UTC" : "non-UTC");
+        if (t <= 8) {
+            o.put("    Movement : %d", mm->movement);
+            if (mm->movement_valid) o.put(" (%d kt)\n", movement_knots(mm->movement));
+            else o.put(" (not available)\n");
+            o.put("    Track    : %d degrees%s\n", mm->ground_track, mm->ground_track_valid ? "" : " (not valid)");
+        } else {
+            o.put("    Altitude : %d feet\n", mm->altitude);
+        }
+        o.put("    Latitude : %d (not decoded)\n", mm->raw_latitude);
+        o.put("    Longitude: %d (not decoded)\n", mm->raw_longitude);
+    } else if (t == 19 && sub >= 1 && sub <= 4) {
+        if (sub <= 2) {
+            o.put("    EW direction      : %d\n", mm->ew_dir);
+            o.put("    EW velocity       : %d\n", mm->ew_velocity);
+            o.put("    NS direction      : %d\n", mm->ns_dir);
+            o.put("    NS velocity       : %d\n", mm->ns_velocity);
+            o.put("    Vertical rate src : %d\n", mm->vert_rate_source);
+            o.put("    Vertical rate sign: %d\n", mm->vert_rate_sign);
+            o.put("    Vertical rate     : %d\n", mm->vert_rate);
+        } else {                                                                   // no newlines in the reference either
+            o.put("    Heading status: %d", mm->heading_is_valid);
+            o.put("    Heading: %d", mm->heading);
+        }
+    } else {
+        o.put("    Unrecognized ME type: %d subtype: %d\n", t, sub);
+    }
+}
+
+}  // namespace
+
+extern "C" int modes_format_verbose(const struct modesMessage *mm, int check_crc, char *buf, size_t cap) {
+    Out o{buf, cap, 0};
+    if (cap) buf[0] = 0;
+    char raw[40];
+    modes_format_raw(mm, raw);
+    o.put("%s", raw);
+    o.put("CRC: %06x (%s)\n", (int)mm->crc, mm->crcok ? "ok" : "wrong");
+    if (mm->errorbit != -1) o.put("Single bit error fixed, bit %d\n", mm->errorbit);
+
+    const int df = mm->msgtype;
+    const bool altitude_reply = df == 4 || df == 20, identity_reply = df == 5 || df == 21;
+    if (df == 0) {
+        o.put("DF 0: Short Air-Air Surveillance.\n");
+        o.put("  Altitude       : %d %s\n", mm->altitude, unit_name(mm));
+        o.put("  ICAO Address   : %02x%02x%02x\n", mm->aa1, mm->aa2, mm->aa3);
+    } else if (altitude_reply || identity_reply) {
+        o.put("DF %d: %s, %s Reply.\n", df, df < 16 ? "Surveillance" : "Comm-B", altitude_reply ? "Altitude" : "Identity");
+        o.put("  Flight Status  : %s\n", kFlightStatus[mm->fs & 7]);
+        o.put("  DR             : %d\n", mm->dr);
+        o.put("  UM             : %d\n", mm->um);
+        if (altitude_reply) o.put("  Altitude       : %d %s\n", mm->altitude, unit_name(mm));
+        else                o.put("  Squawk         : %d\n", mm->identity);
+        o.put("  ICAO Address   : %02x%02x%02x\n", mm->aa1, mm->aa2, mm->aa3);
+    } else if (df == 11) {
+        o.put("DF 11: All Call Reply.\n");
+        o.put("  Capability  : %s\n", kCapability[mm->ca & 7]);
+        o.put("  ICAO Address: %02x%02x%02x\n", mm->aa1, mm->aa2, mm->aa3);
+    } else if (df == 17 || df == 18) {
+        if (df == 17) {
+            o.put("DF 17: ADS-B message.\n");
+            o.put("  Capability     : %d (%s)\n", mm->ca, kCapability[mm->ca & 7]);
+        } else {
+            o.put("DF 18: Extended Squitter.\n");
+            o.put("  Control Field  : %d\n", mm->ca);
+        }
+        o.put("  ICAO Address   : %02x%02x%02x\n", mm->aa1, mm->aa2, mm->aa3);
+        o.put("  Extended Squitter  Type: %d\n", mm->metype);
+        o.put("  Extended Squitter  Sub : %d\n", mm->mesub);
+        o.put("  Extended Squitter  Name: %s\n", me_name(mm->metype, mm->mesub));
+        if (df == 17) put_squitter(o, mm);                                        // DF18 stops at the name (dump1090.c:1434-1443)
+    } else if (check_crc) {
+        o.put("DF %d with good CRC received (decoding still not implemented).\n", df);
+    }
+    o.put("\n");                                                                   // useModesMessage, dump1090.c:1814
+    return (int)o.n;
+}

@@ -57,6 +57,7 @@ class Message:
     block: int
     j: int
     fields: dict
+    verbose: str = ""            # modes_format_verbose(): the reference's default (non --raw) dump of this message
 
     def raw_line(self) -> str:
         return "*" + self.msg[: self.msgbits // 8].hex() + ";\n"         # dump1090.c:1324-1326
@@ -69,14 +70,16 @@ _EXTRA_FIELDS = [f for f, _ in N.ModesMessage._fields_ if f not in (
     "msg", "msgbits", "msgtype", "crcok", "crc", "errorbit", "aa1", "aa2", "aa3", "phase_corrected", "iid")]
 
 
-def _to_message(e: N.Emitted) -> Message:
+def _to_message(e: N.Emitted, check_crc: bool = True) -> Message:
     mm = e.mm
+    buf = C.create_string_buffer(1024)
+    N.host_lib().modes_format_verbose(C.byref(mm), int(check_crc), buf, 1024)
     extra = {}
     for f in _EXTRA_FIELDS:
         v = getattr(mm, f)
         extra[f] = v.decode("ascii", "replace") if isinstance(v, bytes) else int(v)
     return Message(bytes(mm.msg), mm.msgbits, mm.msgtype, mm.crcok, mm.crc, mm.errorbit, mm.aa1, mm.aa2, mm.aa3,
-                   mm.phase_corrected, mm.iid, e.block, e.j, extra)
+                   mm.phase_corrected, mm.iid, e.block, e.j, extra, buf.value.decode("ascii", "replace"))
 
 
 class HostResolver:
@@ -84,6 +87,7 @@ class HostResolver:
 
     def __init__(self, fix: bool = True, aggressive: bool = False, check_crc: bool = True):
         self._lib = N.host_lib()
+        self.check_crc = check_crc
         cfg = N.HostConfig(int(fix), int(aggressive), int(check_crc), 0)
         self._h = self._lib.modes_host_create(C.byref(cfg))
         if not self._h:
@@ -107,7 +111,7 @@ class HostResolver:
         out = (N.Emitted * cap)()
         n = self._lib.modes_host_resolve_to_array(self._h, records.ctypes.data, records.size, cptr, ncand, out, cap)
         assert n <= cap
-        return [_to_message(out[i]) for i in range(n)]
+        return [_to_message(out[i], self.check_crc) for i in range(n)]
 
     def count(self, records: np.ndarray, candidates: np.ndarray | None = None) -> int:
         """Like resolve() but only counts the messages (no Python objects; used by the bench)."""
@@ -134,6 +138,11 @@ class HostResolver:
 
 def raw_text(msgs) -> str:
     return "".join(m.raw_line() for m in msgs)
+
+
+def verbose_text(msgs) -> str:
+    """The reference's default listing (no --raw): dump1090.c:1314-1450 + :1814."""
+    return "".join(m.verbose for m in msgs)
 
 
 def onlyaddr_text(msgs) -> str:

@@ -152,6 +152,11 @@ void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMess
  * Return the number of characters written. */
 int modes_format_raw(const struct modesMessage *mm, char *buf);
 int modes_format_onlyaddr(const struct modesMessage *mm, char *buf);
+/* The verbose dump of one message - what the reference prints when neither --raw nor --onlyaddr is
+ * given: displayModesMessage() (dump1090.c:1314-1450) plus the blank line of useModesMessage()
+ * (dump1090.c:1814).  check_crc = Modes.check_crc (only the "DF %d with good CRC" line reads it).
+ * At most cap-1 characters are written; 1024 bytes always suffice. */
+int modes_format_verbose(const struct modesMessage *mm, int check_crc, char *buf, size_t cap);
 /* The 9-line --stats summary (dump1090.c:2994-3005); buf >= 512 bytes. */
 int modes_format_stats(const modes_host_stats *st, char *buf);
 

@@ -38,6 +38,7 @@ RAW_FLAGSETS = {
     "aggressive_nocrc": ["--aggressive", "--no-crc-check"],
 }
 STATS_FLAGSETS = {"default": [], "nofix": ["--no-fix"], "aggressive": ["--aggressive"]}
+VERBOSE_FLAGSETS = {"default": [], "aggressive_nocrc": ["--aggressive", "--no-crc-check"]}   # no --raw: full text dump
 
 CASES = {
     "modes1": lambda: synth.modes1_padded(os.path.join(HERE, "modes1.bin")),
@@ -70,7 +71,7 @@ def main():
             path = os.path.join(tmp, name + ".bin")
             data.tofile(path)
             entry = {"nbytes": int(len(data)), "input_md5": hashlib.md5(data.tobytes()).hexdigest(),
-                     "raw": {}, "onlyaddr": {}, "stats": {}}
+                     "raw": {}, "onlyaddr": {}, "stats": {}, "verbose": {}}
             for fname, flags in RAW_FLAGSETS.items():
                 out = run_ref(path, ["--raw"] + flags)
                 entry["raw"][fname] = {"lines": out.count("\n"), "md5": hashlib.md5(out.encode()).hexdigest(),
@@ -81,12 +82,17 @@ def main():
             for fname, flags in STATS_FLAGSETS.items():
                 out = run_ref(path, ["--stats"] + flags)
                 entry["stats"][fname] = {"md5": hashlib.md5(out.encode()).hexdigest(), "text": out}
+            for fname, flags in VERBOSE_FLAGSETS.items():
+                out = run_ref(path, flags)
+                entry["verbose"][fname] = {"lines": out.count("\n"), "md5": hashlib.md5(out.encode()).hexdigest(),
+                                           "text": out}
             golden[name] = entry
             print(name, {k: v["lines"] for k, v in entry["raw"].items()})
     with gzip.open(os.path.join(HERE, "golden.json.gz"), "wt", compresslevel=9) as f:
         json.dump(golden, f, sort_keys=True)
     summary = {c: {"nbytes": e["nbytes"], "input_md5": e["input_md5"],
                    "raw": {k: {"lines": v["lines"], "md5": v["md5"]} for k, v in e["raw"].items()},
+                   "verbose": {k: {"lines": v["lines"], "md5": v["md5"]} for k, v in e["verbose"].items()},
                    "stats": {k: v["text"] for k, v in e["stats"].items()}} for c, e in golden.items()}
     with open(os.path.join(HERE, "golden_summary.json"), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)

@@ -112,6 +112,8 @@ def test_modes1_published_hash_from_host_buffer(torch_cuda, streams):
     (["--raw", "--aggressive", "--no-crc-check"], 824, "bec25488d6b84e9b0703d164de1cc873"),
     (["--onlyaddr"], 284, "bab0f055e262e216208a5cbbdf63fe24"),
     (["--stats"], 9, "bc3d1c04b24f4989f0fc4a2d1f45abdd"),
+    ([], 3202, "0bf2290fa954f1675437e52508ea8aa3"),                       # the verbose dump of every field
+    (["--aggressive", "--no-crc-check"], 5357, "b4e11b2e0017cdf772e49d300ab19158"),
     (["--raw", "--batch-blocks", "1"], 284, "4a81758c8bec5e45ffa8541c5622938a"),
 ])
 def test_cli_reproduces_reference_stdout(torch_cuda, flags, lines, md5):

@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 import oracle as orc
-from dump1090_amd import HostResolver, _native as N, block_count, onlyaddr_text, raw_text, shard_blocks, shard_byte_range
+from dump1090_amd import (HostResolver, _native as N, block_count, onlyaddr_text, raw_text, shard_blocks,
+                          shard_byte_range, verbose_text)
 from helpers import maxfix_of, oracle_records
 
 CASES = ["modes1", "uniform", "coarse", "edges", "edges_smear", "frames", "smear", "lowsnr"]
@@ -26,6 +27,9 @@ def test_resolve_reproduces_reference_listing(golden, streams, case):
             assert r.stats_text() == golden[case]["stats"][fs]["text"], (case, fs)
         if fs == "default":
             assert onlyaddr_text(msgs) == golden[case]["onlyaddr"]["default"]["text"]
+        if fs in golden[case]["verbose"]:
+            # the full text dump pins every decoded field of struct modesMessage
+            assert verbose_text(msgs) == golden[case]["verbose"][fs]["text"], (case, fs)
         r.close()
 
 
