@@ -102,7 +102,8 @@ SINK_FN = C.CFUNCTYPE(None, C.POINTER(ModesMessage), C.c_uint32, C.c_uint32, C.c
 
 # every symbol include/*.h declares (tests/test_abi.py checks the libraries export them)
 GPU_SYMBOLS = ("modes_gpu_create", "modes_gpu_destroy", "modes_gpu_last_error", "modes_gpu_compute_magnitude",
-               "modes_gpu_detect", "modes_gpu_fetch", "modes_gpu_demod_host", "modes_gpu_compute_power",
+               "modes_gpu_detect", "modes_gpu_fetch", "modes_gpu_demod_host", "modes_gpu_submit_host",
+               "modes_gpu_host_alloc", "modes_gpu_host_free", "modes_gpu_compute_power",
                "modes_gpu_synth_noise", "modes_gpu_fill", "modes_gpu_abi_version")
 HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_resolve", "modes_host_resolve_to_array",
                 "modes_host_wants",

@@ -1312,18 +1312,39 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
     return MODES_OK;
 }
 
-int modes_gpu_demod_host(modes_gpu *ctx, const uint8_t *iq, uint64_t nbytes, uint64_t stream_byte0, uint64_t first_block,
-                         uint64_t nblocks, modes_gpu_result *res) {
+int modes_gpu_submit_host(modes_gpu *ctx, const uint8_t *iq, uint64_t nbytes, uint64_t stream_byte0, uint64_t first_block,
+                          uint64_t nblocks) {
     if (!ctx) return MODES_ERR_ARG;
-    if (!iq && nbytes) return fail(ctx, MODES_ERR_ARG, "demod_host: null iq");
+    if (!iq && nbytes) return fail(ctx, MODES_ERR_ARG, "submit_host: null iq");
+    if (ctx->in_flight) return fail(ctx, MODES_ERR_STATE, "submit_host: a detect is already in flight on this context");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     int rc;
     const size_t want = (size_t)((nbytes + 15) & ~15ull) + 16;
     if ((rc = grow(ctx, &ctx->d_stage, &ctx->stage_bytes, want)) != MODES_OK) return rc;
+    // host -> HBM on the context's own stream, then the kernels behind it: asynchronous when `iq` is
+    // pinned (modes_gpu_host_alloc), so the caller can fill its other buffer meanwhile
     if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage, iq, nbytes, hipMemcpyHostToDevice, ctx->own_stream));
     modes_gpu_span span{ctx->d_stage, nbytes, stream_byte0, first_block, nblocks};
-    if ((rc = modes_gpu_detect(ctx, &span, ctx->own_stream)) != MODES_OK) return rc;
-    return modes_gpu_fetch(ctx, res);
+    return modes_gpu_detect(ctx, &span, ctx->own_stream);
+}
+
+int modes_gpu_demod_host(modes_gpu *ctx, const uint8_t *iq, uint64_t nbytes, uint64_t stream_byte0, uint64_t first_block,
+                         uint64_t nblocks, modes_gpu_result *res) {
+    const int rc = modes_gpu_submit_host(ctx, iq, nbytes, stream_byte0, first_block, nblocks);
+    return rc != MODES_OK ? rc : modes_gpu_fetch(ctx, res);
+}
+
+int modes_gpu_host_alloc(modes_gpu *ctx, size_t nbytes, void **out) {
+    if (!ctx || !out) return MODES_ERR_ARG;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    hipError_t e = hipHostMalloc(out, nbytes ? nbytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, MODES_ERR_NOMEM, "hipHostMalloc(%zu): %s", nbytes, hipGetErrorString(e));
+    return MODES_OK;
+}
+
+void modes_gpu_host_free(modes_gpu *ctx, void *p) {
+    if (ctx && p) { (void)hipSetDevice(ctx->cfg.device); (void)hipHostFree(p); }
 }
 
 #ifdef MODES_TRACE

@@ -129,6 +129,17 @@ int modes_gpu_demod_host(modes_gpu *ctx, const uint8_t *iq, uint64_t nbytes,
                          uint64_t stream_byte0, uint64_t first_block, uint64_t nblocks,
                          modes_gpu_result *res);
 
+/* The two halves of modes_gpu_demod_host, for hosts that overlap reading with the GPU the way the
+ * reference overlaps its reader thread with detectModeS (dump1090.c:2965-2990): submit copies the
+ * bytes to the context's device buffer and queues the kernels, all asynchronously when `iq` is pinned
+ * memory from modes_gpu_host_alloc; modes_gpu_fetch() later returns the records.  `iq` must stay
+ * untouched until that fetch.  One submit per context at a time (use two contexts to double-buffer). */
+int modes_gpu_submit_host(modes_gpu *ctx, const uint8_t *iq, uint64_t nbytes,
+                          uint64_t stream_byte0, uint64_t first_block, uint64_t nblocks);
+/* Pinned (page-locked) host memory for modes_gpu_submit_host. */
+int  modes_gpu_host_alloc(modes_gpu *ctx, size_t nbytes, void **out);
+void modes_gpu_host_free(modes_gpu *ctx, void *p);
+
 /* Debug / test taps of the scan kernel's inputs: s = (I-127)^2 + (Q-127)^2 per
  * sample (u16) for nsamples at d_iq.  Ordering compares on s equal ordering
  * compares on the magnitude (the LUT is strictly monotone in s). */
