@@ -463,7 +463,7 @@ MODES_HD void modes_pair_flags(int k, int lo, int hi, bool *weak, bool *strong, 
  * `first_equal` = (lo_0 == hi_0): the reference stores the value 2 for that pair and for the
  * weak pairs that repeat it; packing ORs `2 << (7 - t)` into byte k/8 (t = k%8), i.e. sets the
  * bit of pair k-1 unless t == 0, where it falls off the byte (dump1090.c:1696-1706). */
-MODES_HD void modes_pack_message(modes_m128 weak, modes_m128 strong, bool first_equal, uint8_t msg[14], uint8_t *errors) {
+MODES_HD modes_m128 modes_pack_bits(modes_m128 weak, modes_m128 strong, bool first_equal, uint8_t *errors) {
     modes_m128 bits = modes_chain(m128_andn(strong, weak), weak);
     bits.hi &= 0x0000FFFFFFFFFFFFull;
     *errors = first_equal ? 1 : 0;                 /* only pair 0 can take the lo==hi branch (:1677-1682) */
@@ -490,6 +490,10 @@ MODES_HD void modes_pack_message(modes_m128 weak, modes_m128 strong, bool first_
         const modes_m128 keep = m128_make(0x7F7F7F7F7F7F7F7Full, 0x7F7F7F7F7F7F7F7Full);
         bits = m128_or(bits, m128_and(twos, keep));
     }
+    return bits;                                   /* bit k of the mask = message bit k (MSB first) */
+}
+/* mask (bit k = message bit k) -> the 14 message bytes */
+MODES_HD void modes_bits_to_msg(modes_m128 bits, uint8_t msg[14]) {
     for (int b = 0; b < 14; b++) {
         const uint32_t v = (uint32_t)((b < 8 ? bits.lo >> (8 * b) : bits.hi >> (8 * (b - 8))) & 0xFF);
         /* pair 8b+t is bit t of v and bit 7-t of the byte */
@@ -498,6 +502,9 @@ MODES_HD void modes_pack_message(modes_m128 weak, modes_m128 strong, bool first_
         rev = ((rev & 0xAA) >> 1) | ((rev & 0x55) << 1);
         msg[b] = (uint8_t)rev;
     }
+}
+MODES_HD void modes_pack_message(modes_m128 weak, modes_m128 strong, bool first_equal, uint8_t msg[14], uint8_t *errors) {
+    modes_bits_to_msg(modes_pack_bits(weak, strong, first_equal, errors), msg);
 }
 
 /* Scale factors of applyPhaseCorrection (dump1090.c:1502-1516 / 1538-1539).

@@ -527,31 +527,91 @@ __device__ __forceinline__ bool m128_bit(modes_m128 m, int k) {      // k may be
     return (((k < 64) ? (m.lo >> (k & 63)) : (m.hi >> (k & 63))) & 1ull) != 0;
 }
 
-// Syndrome / repair lookup for one attempt (lane 0 only; rare: needs a passed noise gate).
-__device__ __forceinline__ void finish_attempt(const uint8_t msg[14], uint8_t errors, bool gate_ok, int maxfix,
-                                               const uint32_t *esyn, modes_attempt *out) {
+// XOR over the wavefront.
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v ^= (uint32_t)__shfl_xor((int)v, off, 64);
+    return v;
+}
+
+// Syndrome and repair lookup of one attempt by the whole wavefront (dump1090.c:1104, 1112-1117, 854-880).
+// `bits`: mask of the demodulated message (bit k = message bit k, MSB first), wave-uniform.
+// The syndrome is linear: the XOR of x^(111-p) mod G over the set bits, p = frame position = k + 112 - nbits;
+// lane L contributes frame positions L and L + 64.  The repair search of modes_find_fix (same result:
+// all 1- and 2-bit syndromes are distinct) runs one candidate first position per lane.  s_esyn: the
+// 112 single-bit syndromes in LDS.  Results are wave-uniform.
+struct AttemptFix {
+    uint32_t syndrome;
+    uint8_t nfix, pos0, pos1;
+};
+__device__ __forceinline__ int df_of_bits(modes_m128 bits) {                 // msg[0] >> 3
+    const uint32_t v = (uint32_t)bits.lo;
+    return (int)(((v & 1u) << 4) | ((v & 2u) << 2) | (v & 4u) | ((v & 8u) >> 2) | ((v & 16u) >> 4));
+}
+__device__ __forceinline__ AttemptFix wave_finish_attempt(modes_m128 bits, bool gate_ok, int maxfix, int lane,
+                                                          const uint32_t *s_esyn) {
+    AttemptFix r{0, 0, 0xff, 0xff};
+    if (!gate_ok) return r;
+    const int df = df_of_bits(bits);
+    const int nbits = modes_len_by_df(df);
+    const int shift = 112 - nbits;
+    const int pA = lane, pB = lane + 64;                                     // this lane's two frame positions
+    const uint32_t eA = s_esyn[pA], eB = pB < 112 ? s_esyn[pB] : 0u;
+    uint32_t c = 0;                                                          // message bit k sits at frame position k + shift
+    {
+        const int kA = pA - shift, kB = pB - shift;
+        if (kA >= 0 && ((kA < 64 ? bits.lo >> kA : bits.hi >> (kA - 64)) & 1ull)) c ^= eA;
+        if (pB < 112 && kB >= 0 && ((kB < 64 ? bits.lo >> kB : bits.hi >> (kB - 64)) & 1ull)) c ^= eB;
+    }
+    const uint32_t syn = wave_xor(c);
+    r.syndrome = syn;
+    if (syn == 0 || maxfix < 1 || !(df == 11 || df == 17 || df == 18)) return r;
+    const int first = (nbits == 112) ? 5 : 56;                               // frame bits this length may repair
+    const bool okA = pA >= first, okB = pB >= first && pB < 112;
+    {   // one flipped bit
+        const uint64_t bA = __ballot(okA && eA == syn), bB = __ballot(okB && eB == syn);
+        if (bA | bB) {
+            const int p = bA ? __builtin_ctzll(bA) : 64 + __builtin_ctzll(bB);
+            r.nfix = 1;
+            r.pos0 = (uint8_t)(p - shift);
+            return r;
+        }
+    }
+    if (maxfix < 2) return r;
+    // two flipped bits p < q: syn == esyn[p] ^ esyn[q]; lanes hold p, the loop walks q
+    for (int q = first + 1; q < 112; q++) {
+        const uint32_t want = syn ^ s_esyn[q];
+        const uint64_t bA = __ballot(okA && pA < q && eA == want), bB = __ballot(okB && pB < q && eB == want);
+        if (bA | bB) {
+            const int p = bA ? __builtin_ctzll(bA) : 64 + __builtin_ctzll(bB);
+            r.nfix = 2;
+            r.pos0 = (uint8_t)(p - shift);
+            r.pos1 = (uint8_t)(q - shift);
+            return r;
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ void store_attempt(modes_attempt *out, modes_m128 bits, uint8_t errors, bool gate_ok, AttemptFix f) {
+    uint8_t msg[14];
+    modes_bits_to_msg(bits, msg);
 #pragma unroll
     for (int b = 0; b < 14; b++) out->msg[b] = msg[b];
     out->errors = errors;
     out->gate_ok = gate_ok ? 1 : 0;
-    out->nfix = 0;
-    out->fixpos[0] = out->fixpos[1] = 0xff;
+    out->nfix = f.nfix;
+    out->fixpos[0] = f.pos0;
+    out->fixpos[1] = f.pos1;
 #pragma unroll
     for (int b = 0; b < 5; b++) out->pad[b] = 0;
-    out->syndrome = 0;
-    if (!gate_ok) return;
-    const int df = msg[0] >> 3;
-    const int bits = modes_len_by_df(df);
-    const uint32_t syn = modes_syndrome(msg, bits / 8);                      // modesChecksum, :1104
-    out->syndrome = syn;
-    if (syn != 0 && maxfix > 0 && (df == 11 || df == 17 || df == 18))        // :1112-1117
-        out->nfix = (uint8_t)modes_find_fix(syn, bits, maxfix, esyn, out->fixpos);
+    out->syndrome = f.syndrome;
 }
 
 // One slicing pass for the whole wavefront: lane L holds pairs k1 = L and k2 = L + 64.
 // Returns the packed message (wave-uniform) and, on request, the two delta sums.
-__device__ __forceinline__ void slice_pass(int lane, int lo1, int hi1, int lo2, int hi2, uint8_t msg[14], uint8_t *errors,
-                                           int *sum56, int *sum112) {
+__device__ __forceinline__ modes_m128 slice_pass(int lane, int lo1, int hi1, int lo2, int hi2, uint8_t *errors,
+                                                 int *sum56, int *sum112) {
     bool w1, s1, w2, s2;
     int d1, d2;
     modes_pair_flags(lane, lo1, hi1, &w1, &s1, &d1);
@@ -560,7 +620,7 @@ __device__ __forceinline__ void slice_pass(int lane, int lo1, int hi1, int lo2, 
     const modes_m128 weak = pair_ballot(w1, two && w2);
     const modes_m128 strong = pair_ballot(s1, two && s2);
     const bool first_equal = (__ballot(lo1 == hi1) & 1ull) != 0;             // pair 0 lives in lane 0
-    modes_pack_message(weak, strong, first_equal, msg, errors);
+    const modes_m128 bits = modes_pack_bits(weak, strong, first_equal, errors);
     if (sum56) {
         // both sums in one reduction: sum112 < 2^23, sum56 < 2^22
         const int all = d1 + (two ? d2 : 0);
@@ -568,6 +628,7 @@ __device__ __forceinline__ void slice_pass(int lane, int lo1, int hi1, int lo2, 
         *sum112 = wave_sum(all);
         *sum56 = wave_sum(first);
     }
+    return bits;
 }
 
 // Full demodulation of one preamble by the whole wavefront (both attempts) -> record.
@@ -655,8 +716,8 @@ __device__ __forceinline__ void gate_sums_fast(__amdgpu_buffer_rsrc_t rsrc, uint
 }
 
 template <bool GUARD>
-__device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t *s_lut, int lane, int64_t pc, int sum56,
-                                           int sum112) {
+__device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t *s_lut, const uint32_t *s_esyn, int lane,
+                                           int64_t pc, int sum56, int sum112) {
     const uint8_t *iq = P.iq;
     const int64_t lo = P.lo, hi = P.hi;
     const uint64_t g = (uint64_t)pc + P.g0;
@@ -669,14 +730,13 @@ __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t 
     const int hi2 = two ? mag_of(s_lut, load_sample<GUARD>(iq, pc + 145 + 2 * lane, lo, hi)) : 0;
     const int pre = (lane < 12) ? mag_of(s_lut, load_sample<GUARD>(iq, pc - 1 + lane, lo, hi)) : 0;
 
-    uint8_t msg0[14], err0;
-    slice_pass(lane, lo1, hi1, lo2, hi2, msg0, &err0, nullptr, nullptr);
-    const bool gate0 = modes_len_by_df(msg0[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+    uint8_t err0;
+    const modes_m128 bits0 = slice_pass(lane, lo1, hi1, lo2, hi2, &err0, nullptr, nullptr);
+    const bool gate0 = modes_len_by_df(df_of_bits(bits0)) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
     if (!gate0) return;                                                      // dump1090.c:1723-1726: position ends
 
-    uint8_t msg1[14], err1 = err0;
-#pragma unroll
-    for (int b = 0; b < 14; b++) msg1[b] = msg0[b];
+    uint8_t err1 = err0;
+    modes_m128 bits1 = bits0;
     bool gate1 = gate0;
     if (j != 0) {                                                            // dump1090.c:1660
         uint32_t up, dn;
@@ -710,19 +770,21 @@ __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t 
             nlo1 = (lane == 0) ? lu1 : (m128_bit(cm, lane - 1) ? lu1 : ld1);   // pair k uses c_(k-1)
             nlo2 = m128_bit(cm, lane + 63) ? lu2 : ld2;
         }
-        slice_pass(lane, nlo1, nhi1, nlo2, nhi2, msg1, &err1, nullptr, nullptr);
+        bits1 = slice_pass(lane, nlo1, nhi1, nlo2, nhi2, &err1, nullptr, nullptr);
         // the gate of the retry: uncorrected deltas, the retry's own length (dump1090.c:1708-1723)
-        gate1 = modes_len_by_df(msg1[0] >> 3) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+        gate1 = modes_len_by_df(df_of_bits(bits1)) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
     }
+    // syndromes and repair positions: the whole wavefront, both attempts (wave-uniform results)
+    const AttemptFix f0 = wave_finish_attempt(bits0, true, P.maxfix, lane, s_esyn);
+    const AttemptFix f1 = wave_finish_attempt(bits1, gate1, P.maxfix, lane, s_esyn);
     if (lane == 0) {
         const uint32_t idx = atomicAdd(&P.hdr->n_records, 1u);
         if (idx < P.max_records) {
-            modes_record rec;
-            rec.block = (uint32_t)(g / MODES_BLOCK_STRIDE);
-            rec.j = j;
-            finish_attempt(msg0, err0, true, P.maxfix, P.tab.esyn, &rec.att[0]);
-            finish_attempt(msg1, err1, gate1, P.maxfix, P.tab.esyn, &rec.att[1]);
-            P.records[idx] = rec;
+            modes_record *rec = &P.records[idx];
+            rec->block = (uint32_t)(g / MODES_BLOCK_STRIDE);
+            rec->j = j;
+            store_attempt(&rec->att[0], bits0, err0, true, f0);
+            store_attempt(&rec->att[1], bits1, err1, gate1, f1);
         }
     }
 }
@@ -743,11 +805,13 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[kLutVec * 8];
     __shared__ uint32_t s_list[kDemodWaves][64];
     __shared__ uint32_t s_pre[kDemodWaves][kDemodGroup];
+    __shared__ uint32_t s_esyn[112];
     __shared__ unsigned long long s_tot[2];
 #ifdef MODES_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
     stage_lut<kDemodWaves * 64>(s_lut, P.tab.lut);
+    if (threadIdx.x < 112) s_esyn[threadIdx.x] = P.tab.esyn[threadIdx.x];
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
     __syncthreads();
 #ifdef MODES_TRACE
@@ -840,8 +904,8 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
                     todo &= todo - 1;
                     const int64_t pcs = (int64_t)s_list[wave][c0 + (uint32_t)(leader / kGateLanes)];
                     const int s56 = __builtin_amdgcn_readlane(d56, leader), s112 = __builtin_amdgcn_readlane(d112, leader);
-                    if (fast) demod_full<false>(P, s_lut, lane, pcs, s56, s112);
-                    else      demod_full<true>(P, s_lut, lane, pcs, s56, s112);
+                    if (fast) demod_full<false>(P, s_lut, s_esyn, lane, pcs, s56, s112);
+                    else      demod_full<true>(P, s_lut, s_esyn, lane, pcs, s56, s112);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
