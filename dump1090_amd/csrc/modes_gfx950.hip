@@ -1037,6 +1037,8 @@ struct modes_gpu {
     ResultHeader *h_hdr = nullptr;    // pinned
     modes_record *h_records = nullptr;  // pinned, max_records
     std::vector<uint64_t> h_cands;
+    std::vector<std::pair<uint64_t, uint32_t>> sort_keys;
+    std::vector<modes_record> h_sorted;
 
     uint8_t *d_stage = nullptr;       size_t stage_bytes = 0;
 
@@ -1361,11 +1363,25 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
     HIP_TRY(ctx, hipStreamSynchronize(st));
     // within a run the production scan forwards positions in queue order: restore stream order
     std::sort(ctx->h_cands.begin(), ctx->h_cands.end());
-    // records were appended in completion order: put them in stream order
-    std::sort(ctx->h_records, ctx->h_records + hdr.n_records, [](const modes_record &a, const modes_record &b) {
-        return a.block != b.block ? a.block < b.block : a.j < b.j;
-    });
-    res->records = ctx->h_records;
+    // records were appended in completion order: put them in stream order (sort 16-byte keys, then
+    // gather the 64-byte records once)
+    const modes_record *sorted = ctx->h_records;
+    if (hdr.n_records > 1) {
+        std::vector<std::pair<uint64_t, uint32_t>> &keys = ctx->sort_keys;
+        keys.resize(hdr.n_records);
+        bool ascending = true;
+        for (uint32_t i = 0; i < hdr.n_records; i++) {
+            keys[i] = {((uint64_t)ctx->h_records[i].block << 32) | ctx->h_records[i].j, i};
+            if (i && keys[i].first < keys[i - 1].first) ascending = false;
+        }
+        if (!ascending) {
+            std::sort(keys.begin(), keys.end());
+            ctx->h_sorted.resize(hdr.n_records);
+            for (uint32_t i = 0; i < hdr.n_records; i++) ctx->h_sorted[i] = ctx->h_records[keys[i].second];
+            sorted = ctx->h_sorted.data();
+        }
+    }
+    res->records = sorted;
     res->n_records = hdr.n_records;
     res->candidates = ctx->h_cands.empty() ? nullptr : ctx->h_cands.data();
     res->n_candidates = ctx->h_cands.size();
