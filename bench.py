@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--run-chunks", type=int, default=0)
     ap.add_argument("--scan-variant", type=int, default=0, help="0 = production scan kernel, 1 = fused single-pass scan")
     ap.add_argument("--depth", type=int, default=2, help="detect calls in flight (contexts used alternately)")
+XX
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -119,8 +120,8 @@ def main():
     # Two contexts, used alternately: step i+1's kernels are queued before step i's records are fetched
     # and resolved, so the GPU never waits for the host (the C host double-buffers the same way).
     # Every step still does all of its work; K steps = K detects + K fetches + K resolves.
-    demods = [Demodulator(device=local, fix=False, run_chunks=args.run_chunks, scan_variant=args.scan_variant)
-              for _ in range(max(1, args.depth))]
+    demods = [Demodulator(device=local, fix=False, run_chunks=args.run_chunks, scan_variant=args.scan_variant,
+                          overlap=bool(args.overlap)) for _ in range(max(1, args.depth))]
     demod = demods[0]
     iq = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
     demod.synth_noise(iq, first_byte=lo, seed=20260922, sigma_q16=941)

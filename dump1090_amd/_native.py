@@ -34,7 +34,8 @@ class ModesError(RuntimeError):
 class GpuConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("fix_errors", C.c_int32), ("aggressive", C.c_int32),
                 ("keep_candidates", C.c_int32), ("run_chunks", C.c_uint32), ("slot_cap", C.c_uint32),
-                ("max_records", C.c_uint32), ("scan_variant", C.c_uint32)]
+                ("max_records", C.c_uint32), ("scan_variant", C.c_uint32), ("overlap", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class Attempt(C.Structure):

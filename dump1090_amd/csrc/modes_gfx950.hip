@@ -1304,13 +1304,21 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     else
         hipLaunchKernelGGL(scan_kernel, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st, sp);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+    // cfg.overlap: everything after the scan moves to the context's own stream (ordered behind the
+    // scan by ev[1]), so the next kernel on the caller's stream - typically another context's scan,
+    // which is issue-bound - runs concurrently with this latency-bound tail.
+    hipStream_t st2 = st;
+    if (ctx->cfg.overlap && st != ctx->own_stream) {
+        st2 = ctx->own_stream;
+        HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev[1], 0));
+    }
     hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((ngroups + kDemodWaves - 1) / kDemodWaves, ctx->demod_wgs)),
-                       dim3(kDemodWaves * 64), 0, st, dp);
+                       dim3(kDemodWaves * 64), 0, st2, dp);
     if (ctx->cfg.keep_candidates)
-        hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st, d_cand_counts, ngroups, ctx->d_cand_offsets);
+        hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st2, d_cand_counts, ngroups, ctx->d_cand_offsets);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hdr, ctx->d_hdr, sizeof(ResultHeader), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hdr, ctx->d_hdr, sizeof(ResultHeader), hipMemcpyDeviceToHost, st2));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st2));
 
     ctx->last_stream = st;
     ctx->in_flight = true;

@@ -58,6 +58,11 @@ typedef struct {
     uint32_t slot_cap;         /* tuning: forwarded positions per run, 0=auto         */
     uint32_t max_records;      /* record-list capacity, 0 = 1<<20                     */
     uint32_t scan_variant;     /* 0 = production scan kernel; others: see DESIGN.md   */
+    uint32_t overlap;          /* 1: only the scan kernel runs on the caller's stream; the demod
+                                  kernel and the result copy follow on the context's own stream, so
+                                  work the caller queues next (another context's scan) overlaps them.
+                                  The input must then stay untouched until modes_gpu_fetch().       */
+    uint32_t reserved;
 } modes_gpu_config;
 
 /* One demodulation attempt at a preamble position: dump1090.c:1666-1726 (bit
@@ -155,7 +160,7 @@ int modes_gpu_synth_noise(modes_gpu *ctx, void *d_out, uint64_t first_byte, uint
 int modes_gpu_fill(modes_gpu *ctx, void *d_out, uint64_t nbytes, uint8_t value, void *stream);
 
 /* ABI version of this header. */
-#define MODES_GFX950_ABI 1
+#define MODES_GFX950_ABI 2
 int modes_gpu_abi_version(void);
 
 #ifdef __cplusplus
