@@ -83,7 +83,9 @@ def main():
     ap.add_argument("--run-chunks", type=int, default=0)
     ap.add_argument("--scan-variant", type=int, default=0, help="0 = production scan kernel, 1 = fused single-pass scan")
     ap.add_argument("--depth", type=int, default=2, help="detect calls in flight (contexts used alternately)")
-XX
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="1: a step's demod kernel runs on a second stream, concurrent with the next step's scan "
+                         "(measured: +3 %% value, but the scan kernel then shares the chip: -10 %% on its own time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
