@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: a step's demod kernel runs on a second stream, concurrent with the next step's scan "
                          "(measured: +3 %% value, but the scan kernel then shares the chip: -10 %% on its own time)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
+                                                      "the N > 1 control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -103,11 +105,17 @@ def main():
                 args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if args.backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")     # where the gathered bytes travel
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # the global stream = world x (--mib) MiB; this rank demodulates its contiguous buffer range and
     # holds exactly the bytes that range needs (its buffers + the 476-byte carry in front).
@@ -148,7 +156,7 @@ def main():
         nonlocal n_pre, n_fwd
         recs, cands, info = d.fetch()
         if world > 1:
-            recs, cands = gather_records(recs, cands, dst=0, device=dev)
+            recs, cands = gather_records(recs, cands, dst=0, device=coll_dev)
         if rank == 0:
             res = HostResolver(fix=False)
             m = res.count(recs, cands)
@@ -183,7 +191,7 @@ def main():
     elapsed = time.perf_counter() - t0
     n_msgs = n_msgs[0]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -1043,6 +1043,8 @@ struct modes_gpu {
     uint8_t *d_stage = nullptr;       size_t stage_bytes = 0;
 
     uint32_t demod_wgs = 1024;        // workgroups of demod_kernel that are resident at once (occupancy x CUs)
+    bool full_slots = false;          // a run once overflowed the automatic slot_cap: size the lists for the worst case
+    modes_gpu_span last_span{};       // what the detect in flight was asked to do (for the overflow retry)
 
     // geometry of the detect in flight
     bool in_flight = false;
@@ -1245,7 +1247,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     R += R & 1;                                                   // the scan loop is unrolled by two chunks
     const uint32_t nruns = (uint32_t)std::max<uint64_t>(1, (nchunks + R - 1) / R);
     uint32_t cap = ctx->cfg.slot_cap;
-    if (cap == 0) cap = std::max<uint32_t>(64, R * 32);        // 1/16 of the run's positions
+    if (cap == 0) cap = ctx->full_slots ? R * kChunkSamples : std::max<uint32_t>(64, R * 32);   // 1/16 of the run's positions
     if (cap > R * (uint32_t)kChunkSamples) cap = R * kChunkSamples;
 
     int rc;
@@ -1321,6 +1323,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st2));
 
     ctx->last_stream = st;
+    ctx->last_span = *span;
     ctx->in_flight = true;
     ctx->nruns = nruns;
     ctx->slot_cap = cap;
@@ -1340,9 +1343,19 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
     ctx->in_flight = false;
     memset(res, 0, sizeof *res);
     const ResultHeader hdr = *ctx->h_hdr;
-    if (hdr.overflow)
-        return fail(ctx, MODES_ERR_OVERFLOW, "scan forwarded more than slot_cap=%u positions in one run; raise slot_cap",
-                    ctx->slot_cap);
+    if (hdr.overflow) {
+        // More than slot_cap positions of one run look like preambles (the automatic cap is 1/16 of
+        // the positions; only a periodic, preamble-like signal gets there).  Nothing may be dropped:
+        // with the automatic cap, repeat the call with worst-case lists and keep them from now on.
+        if (ctx->cfg.slot_cap != 0 || ctx->full_slots)
+            return fail(ctx, MODES_ERR_OVERFLOW, "scan forwarded more than slot_cap=%u positions in one run; raise slot_cap",
+                        ctx->slot_cap);
+        ctx->full_slots = true;
+        const modes_gpu_span again = ctx->last_span;
+        int rc = modes_gpu_detect(ctx, &again, ctx->last_stream);
+        if (rc != MODES_OK) return rc;
+        return modes_gpu_fetch(ctx, res);
+    }
     if (hdr.n_records > ctx->cfg.max_records)
         return fail(ctx, MODES_ERR_OVERFLOW, "%u records exceed max_records=%u", hdr.n_records, ctx->cfg.max_records);
     if (hdr.n_records) {

@@ -219,3 +219,28 @@ def test_full_size_noise_properties(torch_cuda):
     assert 2.0e-4 < cands.size / (n / 2) < 1.0e-3          # ~5e-4 preambles per sample on this noise
     assert HostResolver(fix=False).resolve(recs, cands) == []
     d.close()
+
+
+def test_slot_overflow_is_retried_not_dropped(torch_cuda):
+    """A periodic preamble-like signal (period 15 samples: pulses at 0, 2, 7, 9) makes 1/15 of ALL positions
+    valid preambles - more than the automatic per-run slot lists (1/16) hold.  The library must notice,
+    repeat the call with worst-case lists and still return exactly the oracle's records."""
+    from dump1090_amd import Demodulator
+    n = 2 * synth.DATA_LEN
+    iq = np.full(n, 127, dtype=np.uint8)
+    s = np.arange(n // 2)
+    pulse = np.isin(s % 15, (0, 2, 7, 9))
+    iq[0::2][pulse] = 210
+    iq[1::2][pulse] = 60
+    iq[-480:] = 127
+    d = Demodulator(keep_candidates=True, check_crc=False)
+    d.detect(to_dev(torch_cuda, iq))
+    recs, cands, info = d.fetch()
+    want_r, want_c = oracle_records(iq, 1)
+    assert want_c.size > (n // 2) // 16                                  # the scenario really overflows 1/16
+    assert np.array_equal(cands, want_c)
+    assert_records_equal(recs, want_r, "periodic")
+    d.detect(to_dev(torch_cuda, iq))                                     # the context keeps the big lists
+    recs2, cands2, _ = d.fetch()
+    assert np.array_equal(cands2, want_c) and recs2.size == recs.size
+    d.close()
