@@ -433,7 +433,9 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
                 wave_lds_fence();
             }
             if (any) {
-                uint32_t *e = queue + (qn + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1))) * kQStride;
+                // rank among the pushing lanes: v_mbcnt counts the mask bits below this lane
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u));
+                uint32_t *e = queue + (qn + below) * kQStride;
 #pragma unroll
                 for (int t = 0; t < 11; t++) e[t] = E[t];
 #pragma unroll
