@@ -108,8 +108,8 @@ GPU_SYMBOLS = ("modes_gpu_create", "modes_gpu_destroy", "modes_gpu_last_error", 
                "modes_gpu_synth_noise", "modes_gpu_fill", "modes_gpu_abi_version")
 HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_resolve", "modes_host_resolve_to_array",
                 "modes_host_wants",
-                "modes_host_get_stats", "modes_host_decode", "modes_format_raw", "modes_format_onlyaddr",
-                "modes_format_verbose", "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
+                "modes_host_get_stats", "modes_host_decode", "modes_format_raw", "modes_format_raw_net",
+                "modes_format_onlyaddr", "modes_format_verbose", "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
                 "modes_block_count")
 
 _gpu = None
@@ -163,6 +163,7 @@ def host_lib():
         L.modes_host_decode.argtypes = [C.c_void_p, C.POINTER(Attempt), C.POINTER(ModesMessage)]
         L.modes_host_decode.restype = None
         L.modes_format_raw.argtypes = [C.POINTER(ModesMessage), C.c_char_p]
+        L.modes_format_raw_net.argtypes = [C.POINTER(ModesMessage), C.c_char_p]
         L.modes_format_onlyaddr.argtypes = [C.POINTER(ModesMessage), C.c_char_p]
         L.modes_format_verbose.argtypes = [C.POINTER(ModesMessage), C.c_int, C.c_char_p, C.c_size_t]
         L.modes_format_stats.argtypes = [C.POINTER(HostStats), C.c_char_p]

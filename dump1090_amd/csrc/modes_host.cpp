@@ -318,8 +318,7 @@ uint64_t modes_host_resolve_to_array(modes_host *h, const modes_record *recs, ui
     return s.n;
 }
 
-int modes_format_raw(const struct modesMessage *mm, char *buf) {                  // :1324-1326
-    static const char hex[] = "0123456789abcdef";
+static int format_hex_line(const struct modesMessage *mm, char *buf, const char *hex) {
     int n = 0;
     buf[n++] = '*';
     for (int b = 0; b < mm->msgbits / 8; b++) {
@@ -330,6 +329,12 @@ int modes_format_raw(const struct modesMessage *mm, char *buf) {                
     buf[n++] = '\n';
     buf[n] = 0;
     return n;
+}
+int modes_format_raw(const struct modesMessage *mm, char *buf) {                  // :1324-1326
+    return format_hex_line(mm, buf, "0123456789abcdef");
+}
+int modes_format_raw_net(const struct modesMessage *mm, char *buf) {              // modesSendRawOutput, :2381-2393
+    return format_hex_line(mm, buf, "0123456789ABCDEF");
 }
 
 int modes_format_onlyaddr(const struct modesMessage *mm, char *buf) {             // :1319

@@ -151,6 +151,9 @@ void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMess
  *   onlyaddr: "%02x%02x%02x\n" (dump1090.c:1319)
  * Return the number of characters written. */
 int modes_format_raw(const struct modesMessage *mm, char *buf);
+/* The line the reference writes to its raw-output TCP clients (port 30002; modesSendRawOutput,
+ * dump1090.c:2381-2393): the same frame in UPPER-case hex.  The sockets themselves are out of scope. */
+int modes_format_raw_net(const struct modesMessage *mm, char *buf);
 int modes_format_onlyaddr(const struct modesMessage *mm, char *buf);
 /* The verbose dump of one message - what the reference prints when neither --raw nor --onlyaddr is
  * given: displayModesMessage() (dump1090.c:1314-1450) plus the blank line of useModesMessage()

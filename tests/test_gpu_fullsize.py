@@ -82,7 +82,9 @@ def test_config3_eight_gib_frames_listing_matches_reference(torch_cuda, nblocks)
     for lo in (0, 2 * st.placements[777][0] - 64, st.nbytes - 4096):
         lo -= lo % 2
         assert np.array_equal(iq[lo:lo + 4096].cpu().numpy(), st.window(lo, lo + 4096))
-    msgs = d.demodulate(iq, batch_blocks=12288)                    # 3 GPU calls of <= 3 GiB
+    # one GPU call of 32767 buffers (8 GiB - 256 KiB + carry: positions up to 2^32 - 2^17, the 32-bit
+    # limit of a call) and one with the remaining two buffers
+    msgs = d.demodulate(iq, batch_blocks=32767)
     got = raw_text(msgs)
     want = reference_stdout(iq.cpu().numpy(), "default", "--raw")
     assert hashlib.md5(got.encode()).hexdigest() == hashlib.md5(want.encode()).hexdigest(), \

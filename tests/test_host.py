@@ -106,3 +106,21 @@ def test_cli_fails_loudly_without_gpu():
     fixture = os.path.join(os.path.dirname(__file__), "golden", "modes1.bin")
     p = subprocess.run([exe, "--ifile", fixture, "--raw"], capture_output=True)
     assert p.returncode == 1 and p.stdout == b"" and b"no HIP device" in p.stderr
+
+
+def test_raw_net_line_is_the_raw_line_in_upper_case(streams):
+    """modesSendRawOutput (dump1090.c:2381-2393) differs from --raw only in the case of the hex digits."""
+    data = streams["frames"]
+    recs, cands = oracle_records(data, 1)
+    lib = N.host_lib()
+    cfg = N.HostConfig(1, 0, 1, 0)
+    h = lib.modes_host_create(C.byref(cfg))
+    out = (N.Emitted * (2 * recs.size + 16))()
+    n = lib.modes_host_resolve_to_array(h, recs.ctypes.data, recs.size, cands.ctypes.data, cands.size, out, len(out))
+    assert n > 50
+    a, b = C.create_string_buffer(64), C.create_string_buffer(64)
+    for i in range(n):
+        lib.modes_format_raw(C.byref(out[i].mm), a)
+        lib.modes_format_raw_net(C.byref(out[i].mm), b)
+        assert b.value == a.value.upper() and b.value != a.value or a.value.upper() == a.value
+    lib.modes_host_destroy(h)
