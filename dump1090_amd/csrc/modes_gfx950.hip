@@ -14,11 +14,14 @@
 // scan_kernel is the only stage that touches every sample; it never materialises
 // magnitudes.  Each lane turns 16 bytes (8 I/Q pairs) into 8 packed-u16 powers
 // s = (I-127)^2+(Q-127)^2, shares them with its wavefront through a wave-private
-// 2 KiB LDS ring (no workgroup barrier anywhere), reads back a 24-sample window and
-// evaluates 8 preamble positions with v_pk_*_u16 arithmetic (modes_scan8).  Because
-// the reference's magnitude LUT is strictly monotone in s, the ten ordering tests
-// are exact on s; the six level tests are replaced by a necessary condition in s and
-// re-checked exactly (LUT) by demod_kernel on the ~0.1 % of positions forwarded.
+// 2 KiB LDS ring (no workgroup barrier anywhere), reads the two lanes before it and
+// evaluates 8 preamble positions (alpha: the ordering relations, modes_order8_swar);
+// the ~1.5 % survivors are queued in LDS and a dense second pass (beta) applies the
+// level tests as a necessary condition in s.  Because the reference's magnitude LUT is
+// strictly monotone in s, the ordering tests are exact on s; everything forwarded
+// (~0.07 % of positions) is re-checked exactly (LUT) by demod_kernel.
+// scan_fused_kernel (scan_variant 1) is the single-pass first version, kept as an
+// independent implementation the tests compare the production kernel with.
 //
 // No MFMA (integer scan, HBM-bound), no CUDA compatibility layer, wave64 only.
 
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanPara
 }
 
 // ------------------------------------------------------------------------------------
-// demod_kernel - one wavefront per run, one lane per forwarded position.
+// demod_kernel parameters
 // ------------------------------------------------------------------------------------
 #ifdef MODES_TRACE
 __device__ unsigned long long g_trace[8192 * 4];      // per demod wavefront: start, LUT staged, end, group
@@ -792,16 +795,17 @@ __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t 
 }
 
 // ------------------------------------------------------------------------------------
-// demod_kernel - persistent workgroups, one wavefront per run.
+// demod_kernel - persistent workgroups; a wavefront takes kDemodGroup runs at a time.
 //   stage 1: one lane per forwarded position: exact preamble predicate (dump1090.c:1602-1650)
 //            on LUT magnitudes; survivors compacted, in order, into a wave-private LDS list.
-//   stage 2: noise-gate pre-test (dump1090.c:1713-1723), four preambles per iteration, 16 lanes
-//            each: sum of |lo-hi| over the 56 and the 112 bit pairs.  A position whose sums fail
+//   stage 2: noise-gate pre-test (dump1090.c:1713-1723), 64 / kGateLanes preambles per iteration,
+//            kGateLanes lanes each: sum of |lo-hi| over the 56 and the 112 bit pairs.  A position whose sums fail
 //            the gate for BOTH message lengths ends here (that is nearly every preamble found in
 //            noise), whatever its bits are.
 //   stage 3: the wavefront demodulates the survivors one at a time, all 64 lanes cooperating
 //            (coalesced sample loads; the sequential parts of the reference become carry chains,
-//            see modes_core.h).  Positions whose first noise gate passes become records.
+//            see modes_core.h), then syndrome and repair search, again by the whole wavefront.
+//            Positions whose first noise gate passes become records.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80))) void demod_kernel(DemodParams P) {
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[kLutVec * 8];
