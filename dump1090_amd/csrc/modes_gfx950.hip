@@ -402,10 +402,15 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t *>(iq + (GUARD ? 0 : base_off)), 0, 0x7fffffff, 0x00020000);
-    auto load = [&](int64_t k) -> uint4 {                                    // chunk c0 + k
+    // chunk c0 + k.  The prefetch runs two chunks ahead; past the end of the run it re-reads the run's
+    // last chunk (a cache hit, one s_min) instead of pulling the next run's first two chunks from
+    // HBM a second time (that cost 6 % extra traffic).
+    const uint32_t klast = (uint32_t)(c1 - c0 - 1);
+    auto load = [&](int64_t k) -> uint4 {
+        const uint32_t kk = (uint32_t)k < klast ? (uint32_t)k : klast;
         if (!GUARD)
-            return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, (uint32_t)k * kChunkBytes, 0));
-        return load_iq16(iq, base_off + k * kChunkBytes + lane_off, lo, hi);
+            return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, kk * kChunkBytes, 0));
+        return load_iq16(iq, base_off + (int64_t)kk * kChunkBytes + lane_off, lo, hi);
     };
 
     uint32_t count = 0, qn = 0;                                              // wave-uniform
