@@ -44,6 +44,16 @@ def hash_at(seed: int, idx: np.ndarray) -> np.ndarray:
         return mix64((np.uint64(seed) + idx.astype(np.uint64) * _GOLD) & _M64)
 
 
+def noise_at(seed: int, idx: np.ndarray, sigma_q16: int = 941) -> np.ndarray:
+    """The noise byte at every stream byte index in `idx` (any shape)."""
+    h = hash_at(seed, idx)
+    g = np.zeros(h.shape, dtype=np.int64)
+    for b in range(8):
+        g += ((h >> np.uint64(8 * b)) & np.uint64(0xFF)).astype(np.int64)
+    v = 127 + (((g - 1020) * sigma_q16 + 58982) >> 16)
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
 def noise_bytes(seed: int, first_byte: int, nbytes: int, sigma_q16: int = 941) -> np.ndarray:
     """Approximately Gaussian bytes around 127.4.
 
@@ -55,12 +65,7 @@ def noise_bytes(seed: int, first_byte: int, nbytes: int, sigma_q16: int = 941) -
     step = 1 << 22
     for lo in range(0, nbytes, step):
         hi = min(nbytes, lo + step)
-        h = hash_at(seed, np.arange(first_byte + lo, first_byte + hi, dtype=np.uint64))
-        g = np.zeros(hi - lo, dtype=np.int64)
-        for b in range(8):
-            g += ((h >> np.uint64(8 * b)) & np.uint64(0xFF)).astype(np.int64)
-        v = 127 + (((g - 1020) * sigma_q16 + 58982) >> 16)
-        out[lo:hi] = np.clip(v, 0, 255).astype(np.uint8)
+        out[lo:hi] = noise_at(seed, np.arange(first_byte + lo, first_byte + hi, dtype=np.uint64), sigma_q16)
     return out
 
 
@@ -239,9 +244,18 @@ class SparseFrameStream:
         """-> (first_byte int64[n], data uint8[n, 2*SPAN]): the final bytes of every frame's footprint."""
         n = len(self.placements)
         first = 2 * self._starts
-        data = np.empty((n, 2 * self.SPAN), dtype=np.uint8)
-        for k in range(n):
-            data[k] = self.window(int(first[k]), int(first[k]) + 2 * self.SPAN)
+        width = 2 * self.SPAN
+        data = np.empty((n, width), dtype=np.uint8)
+        tail = self.nbytes - 480
+        for lo in range(0, n, 16384):                    # noise for many footprints at once, frames one by one
+            hi = min(n, lo + 16384)
+            idx = first[lo:hi, None].astype(np.uint64) + np.arange(width, dtype=np.uint64)[None, :]
+            data[lo:hi] = noise_at(self.seed, idx, self.sigma_q16)
+            for k in range(lo, hi):
+                sample, frame, amp, phase, smear = self.placements[k]
+                add_frame(data[k], 0, frame, amp, phase, smear)
+                if first[k] + width > tail:
+                    data[k, max(0, tail - int(first[k])):] = 127
         return first, data
 
 

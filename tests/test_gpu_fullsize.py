@@ -119,3 +119,43 @@ def test_config5_low_snr_aggressive_matches_reference(torch_cuda):
     assert len(msgs) > 1000                                         # the path is exercised, not vacuous
     assert any(m.phase_corrected for m in msgs) and any(m.errorbit >= 0 for m in msgs)
     d.close()
+
+
+@pytest.mark.skipif(os.environ.get("MODES_FULL64") != "1", reason="~6 min and 64 GiB of HBM + host RAM: set MODES_FULL64=1")
+def test_config4_sixty_four_gib_in_eight_shards_matches_reference(torch_cuda):
+    """configs[3]'s data size on ONE GPU: the 64 GiB stream (524,287 frames) is cut into the 8 buffer ranges
+    bench.py --gpus 8 would give its ranks, each range is demodulated on its own from exactly the bytes
+    that rank would hold (its buffers + the 476-byte carry), the record lists are concatenated in rank
+    order and resolved once - the N = 8 data path without the 8 GPUs.  The listing must equal the
+    reference's on the whole stream."""
+    from dump1090_amd import Demodulator, HostResolver, block_count, raw_text, shard_blocks, shard_byte_range
+    torch = torch_cuda
+    nblocks = 262144
+    free, _ = torch.cuda.mem_get_info()
+    if free < nblocks * synth.DATA_LEN * 1.2:
+        pytest.skip("not enough free HBM for the 64 GiB stream")
+    st = synth.config3_stream(4, nblocks)
+    d = Demodulator()
+    iq = build_on_device(torch, d, st)
+    total = block_count(st.nbytes)
+    recs = []
+    for rank in range(8):
+        first, n = shard_blocks(total - 1, 8, rank)
+        if rank == 7:
+            n += 1                                               # the EOF buffer goes to the last rank (bench.py)
+        lo, hi = shard_byte_range(first, n, st.nbytes)
+        shard = iq[lo:hi]                                        # what this rank would hold
+        for b0 in range(first, first + n, 16384):                # <= 4 GiB per GPU call
+            nb = min(16384, first + n - b0)
+            blo, bhi = shard_byte_range(b0, nb, st.nbytes)
+            d.detect(shard[blo - lo:bhi - lo], stream_byte0=blo, first_block=b0, nblocks=nb)
+            r, _, _ = d.fetch()
+            recs.append(r)
+    res = HostResolver()
+    got = raw_text(res.resolve(np.concatenate(recs), None))
+    res.close()
+    want = reference_stdout(iq.cpu().numpy(), "default", "--raw")
+    assert got.count("\n") > 500000
+    assert hashlib.md5(got.encode()).hexdigest() == hashlib.md5(want.encode()).hexdigest(), \
+        "listing differs from the reference (%d vs %d lines)" % (got.count("\n"), want.count("\n"))
+    d.close()
