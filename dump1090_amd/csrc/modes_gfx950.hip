@@ -1154,6 +1154,7 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
 void modes_gpu_destroy(modes_gpu *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->in_flight && ctx->ev[2]) (void)hipEventSynchronize(ctx->ev[2]);   // kernels of a detect nobody fetched
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     void *dev[] = {ctx->d_lut, ctx->d_esyn, ctx->d_slots, ctx->d_cand_slots, ctx->d_counts, ctx->d_cand_offsets,
                    ctx->d_cand_dense, ctx->d_records, ctx->d_hdr, ctx->d_stage};
