@@ -712,17 +712,19 @@ __device__ __forceinline__ void gate_sums_fast(__amdgpu_buffer_rsrc_t rsrc, uint
     uint32_t w[kIter];
 #pragma unroll
     for (int i = 0; i < kIter; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 4u * kGateLanes * i, 0, 0);
-    int s56 = 0, s112 = 0;
+    // pairs gl + kGateLanes * i: the first 56 / kGateLanes iterations are the short message's pairs for every lane
+    static_assert(56 % kGateLanes == 0, "the 56-pair prefix must end on an iteration boundary");
+    uint32_t acc = 0, s56 = 0;
 #pragma unroll
     for (int i = 0; i < kIter; i++) {
+        if (i == 56 / kGateLanes) s56 = acc;
         const uint32_t idx = pk_lut_index(w[i]);                             // both LUT indices
-        const int a = s_lut[idx & 0xffffu], b = s_lut[idx >> 16];
-        const int d = a > b ? a - b : b - a;
-        s112 += d;
-        if (gl + kGateLanes * i < 56) s56 += d;
+        const uint32_t a = s_lut[idx & 0xffffu], b = s_lut[idx >> 16];
+        acc = __builtin_amdgcn_sad_u16(a, b, acc);                           // acc += |a - b| (high halves are zero)
     }
-    *d56 = s56;
-    *d112 = s112;
+    (void)gl;
+    *d56 = (int)s56;
+    *d112 = (int)acc;
 }
 
 template <bool GUARD>
