@@ -10,6 +10,11 @@ uint8 I/Q in 2 Msps file format (sigma = 3 integer noise, tests/synth.py), --no-
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Before the W warmup steps the bench runs `--settle` (80) more untimed steps: the chip's power management
+needs ~40 back-to-back steps to reach its sustained clocks (tools/scan_steps.py: the scan kernel takes 0.22,
+0.27 and 0.21 ms at steps 1, 10 and 60 of an uninterrupted run); the K timed steps are therefore the
+sustained rate, which is what a stream of many batches sees.
+
 Prints ONE JSON line on rank 0.  `roofline` is for the scan kernel (the only stage that reads
 every sample): algorithmic bytes = 2 per sample, duration = HIP events recorded around the kernel
 on its launch stream inside libmodes_gfx950.so.  `cpu_baseline` (N == 1 only) times the compiled
@@ -88,6 +93,10 @@ def main():
     ap.add_argument("--run-chunks", type=int, default=0)
     ap.add_argument("--scan-variant", type=int, default=0, help="0 = production scan kernel, 1 = fused single-pass scan")
     ap.add_argument("--depth", type=int, default=2, help="detect calls in flight (contexts used alternately)")
+    ap.add_argument("--settle", type=int, default=80,
+                    help="extra untimed steps before the W warmup steps: the chip's power management needs ~40 "
+                         "back-to-back steps (13 ms) to settle - the scan kernel runs 0.22, 0.27, 0.21 ms at steps "
+                         "1, 10, 60 of a sustained run (tools/scan_steps.py)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: a step's demod kernel runs on a second stream, concurrent with the next step's scan "
                          "(measured: +3 %% value, but the scan kernel then shares the chip: -10 %% on its own time)")
@@ -175,8 +184,9 @@ def main():
 
     in_flight = []                                  # contexts with a detect queued, oldest first
     t0 = None
-    for step in range(args.warmup + args.steps):
-        if step == args.warmup:
+    warm = args.settle + args.warmup
+    for step in range(warm + args.steps):
+        if step == warm:
             while in_flight:
                 finish(in_flight.pop(0), False)
             sync_all()
@@ -185,7 +195,7 @@ def main():
         if d in in_flight:                          # its previous detect must be fetched first
             while in_flight:
                 x = in_flight.pop(0)
-                finish(x, step > args.warmup)
+                finish(x, step > warm)
                 if x is d:
                     break
         d.detect(iq, stream_byte0=lo, first_block=first_block, nblocks=nblocks, stream=work)
@@ -212,6 +222,7 @@ def main():
         "config": {"workload": "%d MiB synthetic uint8 IQ @ 2 Msps format per GPU (sigma=3 integer noise, seed "
                                "20260922), --no-fix, HBM-resident; BASELINE.json configs[1]" % args.mib,
                    "bytes_per_gpu": per_gpu, "flags": "--raw --no-fix", "sharding": "buffers over %d rank(s)" % world,
+                   "settle_steps": args.settle,
                    "step": "scan + demod kernels, record fetch%s, host resolve; %d detect(s) in flight" % (
                        ", RCCL gather to rank 0" if world > 1 else "", len(demods))},
         "msgs_per_s": round(n_msgs / elapsed, 2),

@@ -32,10 +32,13 @@ for f in find("*kernel_trace.csv"):
     if os.sep + "kt" + os.sep not in f:
         continue
     d = defaultdict(list)
+    order = defaultdict(list)
     meta = {}
-    for row in csv.DictReader(open(f)):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    for row in rows:
         n = short(row["Kernel_Name"])
         d[n].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        order[n].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
         meta[n] = (row.get("VGPR_Count"), row.get("Accum_VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"),
                    row.get("Scratch_Size"), row.get("Workgroup_Size"), row.get("Grid_Size"))
     print("== kernel trace durations (%s)" % os.path.relpath(f, out))
@@ -43,6 +46,9 @@ for f in find("*kernel_trace.csv"):
         v.sort()
         print("  %-24s n=%4d  median %9.1f us  min %9.1f  max %9.1f   vgpr/agpr/sgpr/lds/scratch/wg/grid=%s" % (
             n, len(v), v[len(v) // 2] / 1e3, v[0] / 1e3, v[-1] / 1e3, meta[n]))
+        if n in order and len(order[n]) > 12:
+            tail = order[n][-10:]                       # the timed steps (after bench.py's settle + warmup)
+            print("  %-24s last 10 launches (the timed region): avg %9.1f us" % (n, sum(tail) / len(tail) / 1e3))
 
 for f in find("*counter_collection.csv"):
     agg = defaultdict(lambda: defaultdict(list))
