@@ -189,6 +189,14 @@ struct ResultHeader {
     uint32_t overflow;                // some run overflowed its slots
 };
 
+// What one demod workgroup found, written straight to pinned host memory when the workgroup retires
+// (plain stores, visible to the host once the kernel has completed): no totals atomics on the device
+// and no result-copy kernel behind demod_kernel.
+struct WgTotals {
+    unsigned long long n_forwarded, n_preambles;
+    uint32_t n_records, overflow;
+};
+
 struct ScanParams {
     const uint8_t *iq;    // 16-byte aligned base
     int64_t lo, hi;       // valid bytes [lo, hi) relative to iq (lo < 16: alignment slack)
@@ -307,7 +315,8 @@ struct DemodParams {
     uint32_t *cand_slots;      // [nruns][slot_cap] or nullptr
     uint32_t *cand_counts;     // [nruns]
     modes_record *records;
-    ResultHeader *hdr;
+    ResultHeader *hdr;         // device: record append counter (zeroed by the scan kernel)
+    WgTotals *host_totals;     // device view of the pinned per-workgroup totals, [gridDim.x]
     uint32_t max_records;
 };
 
@@ -728,8 +737,8 @@ __device__ __forceinline__ void gate_sums_fast(__amdgpu_buffer_rsrc_t rsrc, uint
 }
 
 template <bool GUARD>
-__device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t *s_lut, const uint32_t *s_esyn, int lane,
-                                           int64_t pc, int sum56, int sum112) {
+__device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t *s_lut, const uint32_t *s_esyn, uint32_t *wg_records,
+                                           int lane, int64_t pc, int sum56, int sum112) {
     const uint8_t *iq = P.iq;
     const int64_t lo = P.lo, hi = P.hi;
     const uint64_t g = (uint64_t)pc + P.g0;
@@ -791,6 +800,7 @@ __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t 
     const AttemptFix f1 = wave_finish_attempt(bits1, gate1, P.maxfix, lane, s_esyn);
     if (lane == 0) {
         const uint32_t idx = atomicAdd(&P.hdr->n_records, 1u);
+        atomicAdd(wg_records, 1u);
         if (idx < P.max_records) {
             modes_record *rec = &P.records[idx];
             rec->block = (uint32_t)(g / MODES_BLOCK_STRIDE);
@@ -820,12 +830,13 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
     __shared__ uint32_t s_pre[kDemodWaves][kDemodGroup];
     __shared__ uint32_t s_esyn[112];
     __shared__ unsigned long long s_tot[2];
+    __shared__ uint32_t s_flags[2];            // records appended by this workgroup, slot-list overflow seen
 #ifdef MODES_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
     stage_lut<kDemodWaves * 64>(s_lut, P.tab.lut);
     if (threadIdx.x < 112) s_esyn[threadIdx.x] = P.tab.esyn[threadIdx.x];
-    if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
+    if (threadIdx.x < 2) { s_tot[threadIdx.x] = 0; s_flags[threadIdx.x] = 0; }
     __syncthreads();
 #ifdef MODES_TRACE
     const unsigned long long t_lut = wall_clock64();
@@ -850,7 +861,7 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
         uint32_t cnt = 0;
         if (lane < kDemodGroup && run0 + lane < P.nruns) {
             const uint32_t true_count = P.counts[run0 + lane];
-            if (true_count > P.slot_cap) atomicOr(&P.hdr->overflow, 1u);   // the scan dropped positions: the call fails
+            if (true_count > P.slot_cap) atomicOr(&s_flags[1], 1u);        // the scan dropped positions: the call fails
             cnt = min(true_count, P.slot_cap);
             tot_fwd += true_count;                                           // summed over lanes at the end
         }
@@ -917,8 +928,8 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
                     todo &= todo - 1;
                     const int64_t pcs = (int64_t)s_list[wave][c0 + (uint32_t)(leader / kGateLanes)];
                     const int s56 = __builtin_amdgcn_readlane(d56, leader), s112 = __builtin_amdgcn_readlane(d112, leader);
-                    if (fast) demod_full<false>(P, s_lut, s_esyn, lane, pcs, s56, s112);
-                    else      demod_full<true>(P, s_lut, s_esyn, lane, pcs, s56, s112);
+                    if (fast) demod_full<false>(P, s_lut, s_esyn, &s_flags[0], lane, pcs, s56, s112);
+                    else      demod_full<true>(P, s_lut, s_esyn, &s_flags[0], lane, pcs, s56, s112);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -940,10 +951,7 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
         atomicAdd(&s_tot[1], tot_cand);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&P.hdr->n_forwarded, s_tot[0]);
-        atomicAdd(&P.hdr->n_preambles, s_tot[1]);
-    }
+    if (threadIdx.x == 0) P.host_totals[blockIdx.x] = WgTotals{s_tot[0], s_tot[1], s_flags[0], s_flags[1]};
 }
 
 // ------------------------------------------------------------------------------------
@@ -1047,7 +1055,9 @@ struct modes_gpu {
     modes_record *d_records = nullptr;
     ResultHeader *d_hdr = nullptr;
 
-    ResultHeader *h_hdr = nullptr;    // pinned
+    WgTotals *h_totals = nullptr;     // pinned + mapped, one per demod workgroup
+    WgTotals *h_totals_dev = nullptr;
+    uint32_t demod_grid = 0;          // workgroups of the demod launch in flight
     modes_record *h_records = nullptr;  // pinned, max_records
     std::vector<uint64_t> h_cands;
     std::vector<std::pair<uint64_t, uint32_t>> sort_keys;
@@ -1145,7 +1155,8 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     CREATE_TRY(hipMemcpy(ctx->d_esyn, esyn, sizeof esyn, hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_records), (size_t)ctx->cfg.max_records * sizeof(modes_record)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hdr), sizeof(ResultHeader)));
-    CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hdr), sizeof(ResultHeader), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_totals), sizeof(WgTotals) * ctx->demod_wgs, hipHostMallocMapped));
+    CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_totals_dev), ctx->h_totals, 0));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_records), (size_t)ctx->cfg.max_records * sizeof(modes_record),
                              hipHostMallocDefault));
 #undef CREATE_TRY
@@ -1162,7 +1173,7 @@ void modes_gpu_destroy(modes_gpu *ctx) {
                    ctx->d_cand_dense, ctx->d_records, ctx->d_hdr, ctx->d_stage};
     for (void *p : dev)
         if (p) (void)hipFree(p);
-    if (ctx->h_hdr) (void)hipHostFree(ctx->h_hdr);
+    if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
     if (ctx->h_records) (void)hipHostFree(ctx->h_records);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1310,6 +1321,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     dp.cand_counts = d_cand_counts;
     dp.records = ctx->d_records;
     dp.hdr = ctx->d_hdr;
+    dp.host_totals = ctx->h_totals_dev;
     dp.max_records = ctx->cfg.max_records;
 
     // The header is zeroed by the scan kernel itself, so a detect is exactly: scan, demod, (prefix,)
@@ -1328,12 +1340,11 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
         st2 = ctx->own_stream;
         HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev[1], 0));
     }
-    hipLaunchKernelGGL(demod_kernel, dim3(std::min<uint32_t>((ngroups + kDemodWaves - 1) / kDemodWaves, ctx->demod_wgs)),
-                       dim3(kDemodWaves * 64), 0, st2, dp);
+    ctx->demod_grid = std::min<uint32_t>((ngroups + kDemodWaves - 1) / kDemodWaves, ctx->demod_wgs);
+    hipLaunchKernelGGL(demod_kernel, dim3(ctx->demod_grid), dim3(kDemodWaves * 64), 0, st2, dp);
     if (ctx->cfg.keep_candidates)
         hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st2, d_cand_counts, ngroups, ctx->d_cand_offsets);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hdr, ctx->d_hdr, sizeof(ResultHeader), hipMemcpyDeviceToHost, st2));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st2));
 
     ctx->last_stream = st;
@@ -1356,7 +1367,14 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
     hipStream_t st = ctx->own_stream;
     ctx->in_flight = false;
     memset(res, 0, sizeof *res);
-    const ResultHeader hdr = *ctx->h_hdr;
+    ResultHeader hdr{0, 0, 0, 0};
+    for (uint32_t b = 0; b < ctx->demod_grid; b++) {
+        const WgTotals &t = ctx->h_totals[b];
+        hdr.n_forwarded += t.n_forwarded;
+        hdr.n_preambles += t.n_preambles;
+        hdr.n_records += t.n_records;
+        hdr.overflow |= t.overflow;
+    }
     if (hdr.overflow) {
         // More than slot_cap positions of one run look like preambles (the automatic cap is 1/16 of
         // the positions; only a periodic, preamble-like signal gets there).  Nothing may be dropped:
