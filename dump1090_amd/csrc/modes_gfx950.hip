@@ -181,11 +181,12 @@ __global__ __launch_bounds__(256) void power_kernel(const uint8_t *__restrict__ 
 // synchronisation, no atomics; forwarded positions go to the run's private slot list in
 // ascending order, so the concatenation over runs is already sorted.
 // ------------------------------------------------------------------------------------
-// Totals of one detect call, accumulated on the device (zeroed by a memset node before the scan).
+// Totals of one detect call.  On the device only n_records is live (the record append counter, zeroed
+// by the scan kernel); the host fills the rest by summing the per-workgroup WgTotals.
 struct ResultHeader {
-    unsigned long long n_forwarded;   // positions forwarded by the scan (atomics, one per demod workgroup)
+    unsigned long long n_forwarded;   // positions forwarded by the scan
     unsigned long long n_preambles;   // positions where the full predicate holds
-    uint32_t n_records;               // record-list append counter
+    uint32_t n_records;               // records appended
     uint32_t overflow;                // some run overflowed its slots
 };
 
