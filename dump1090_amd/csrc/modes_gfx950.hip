@@ -195,7 +195,9 @@ struct ResultHeader {
 // and no result-copy kernel behind demod_kernel.
 struct WgTotals {
     unsigned long long n_forwarded, n_preambles;
-    uint32_t n_records, overflow;
+    uint32_t n_records;      // records written
+    uint32_t n_reserved;     // record slots reserved (whole kRecChunk blocks; the unused ones are marked invalid)
+    uint32_t overflow, pad;
 };
 
 struct ScanParams {
@@ -299,6 +301,13 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanPara
 #ifdef MODES_TRACE
 __device__ unsigned long long g_trace[8192 * 4];      // per demod wavefront: start, LUT staged, end, group
 #endif
+// Record slots are reserved kRecChunk at a time per wavefront: one global atomic per 32 records.
+// (One atomic per record saturates a single counter at ~88 per microsecond: 8.7 ms per GiB on the
+// reference's own message-dense capture.)  Unused slots of a wavefront's last block get block = ~0.
+constexpr uint32_t kRecChunk = 32;
+constexpr uint32_t kInvalidBlock = 0xFFFFFFFFu;
+struct RecCursor { uint32_t next, end; };   // wave-uniform
+
 constexpr int kDemodWaves = 8;        // wavefronts per demod workgroup (they share one 33 KB LUT copy in LDS)
 constexpr int kDemodGroup = 4;        // runs whose slot lists one demod wavefront walks together (power of two <= 64)
 
@@ -738,8 +747,8 @@ __device__ __forceinline__ void gate_sums_fast(__amdgpu_buffer_rsrc_t rsrc, uint
 }
 
 template <bool GUARD>
-__device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t *s_lut, const uint32_t *s_esyn, uint32_t *wg_records,
-                                           int lane, int64_t pc, int sum56, int sum112) {
+__device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t *s_lut, const uint32_t *s_esyn, uint32_t *wg_counts,
+                                           RecCursor &cur, int lane, int64_t pc, int sum56, int sum112) {
     const uint8_t *iq = P.iq;
     const int64_t lo = P.lo, hi = P.hi;
     const uint64_t g = (uint64_t)pc + P.g0;
@@ -799,9 +808,18 @@ __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t 
     // syndromes and repair positions: the whole wavefront, both attempts (wave-uniform results)
     const AttemptFix f0 = wave_finish_attempt(bits0, true, P.maxfix, lane, s_esyn);
     const AttemptFix f1 = wave_finish_attempt(bits1, gate1, P.maxfix, lane, s_esyn);
+    if (cur.next == cur.end) {                                               // wave-uniform: reserve the next block
+        uint32_t base = 0;
+        if (lane == 0) {
+            base = atomicAdd(&P.hdr->n_records, kRecChunk);
+            atomicAdd(&wg_counts[2], kRecChunk);
+        }
+        cur.next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        cur.end = cur.next + kRecChunk;
+    }
+    const uint32_t idx = cur.next++;
     if (lane == 0) {
-        const uint32_t idx = atomicAdd(&P.hdr->n_records, 1u);
-        atomicAdd(wg_records, 1u);
+        atomicAdd(&wg_counts[0], 1u);
         if (idx < P.max_records) {
             modes_record *rec = &P.records[idx];
             rec->block = (uint32_t)(g / MODES_BLOCK_STRIDE);
@@ -831,13 +849,14 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
     __shared__ uint32_t s_pre[kDemodWaves][kDemodGroup];
     __shared__ uint32_t s_esyn[112];
     __shared__ unsigned long long s_tot[2];
-    __shared__ uint32_t s_flags[2];            // records appended by this workgroup, slot-list overflow seen
+    __shared__ uint32_t s_flags[3];            // records written by this workgroup, slot-list overflow seen, slots reserved
 #ifdef MODES_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
     stage_lut<kDemodWaves * 64>(s_lut, P.tab.lut);
     if (threadIdx.x < 112) s_esyn[threadIdx.x] = P.tab.esyn[threadIdx.x];
-    if (threadIdx.x < 2) { s_tot[threadIdx.x] = 0; s_flags[threadIdx.x] = 0; }
+    if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
+    if (threadIdx.x < 3) s_flags[threadIdx.x] = 0;
     __syncthreads();
 #ifdef MODES_TRACE
     const unsigned long long t_lut = wall_clock64();
@@ -848,6 +867,7 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
     const uint8_t *iq = P.iq;
     const int64_t lo = P.lo, hi = P.hi;
     unsigned long long tot_fwd = 0, tot_cand = 0;
+    RecCursor cur{0, 0};
 
     // A wavefront takes kDemodGroup consecutive runs at a time and walks the concatenation of their
     // slot lists 64 positions per iteration (dense lanes however short the individual lists are):
@@ -929,8 +949,8 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
                     todo &= todo - 1;
                     const int64_t pcs = (int64_t)s_list[wave][c0 + (uint32_t)(leader / kGateLanes)];
                     const int s56 = __builtin_amdgcn_readlane(d56, leader), s112 = __builtin_amdgcn_readlane(d112, leader);
-                    if (fast) demod_full<false>(P, s_lut, s_esyn, &s_flags[0], lane, pcs, s56, s112);
-                    else      demod_full<true>(P, s_lut, s_esyn, &s_flags[0], lane, pcs, s56, s112);
+                    if (fast) demod_full<false>(P, s_lut, s_esyn, s_flags, cur, lane, pcs, s56, s112);
+                    else      demod_full<true>(P, s_lut, s_esyn, s_flags, cur, lane, pcs, s56, s112);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -945,6 +965,9 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
         if (w < 8192) { g_trace[4 * w] = t_start; g_trace[4 * w + 1] = t_lut; g_trace[4 * w + 2] = wall_clock64(); g_trace[4 * w + 3] = tot_cand; }
     }
 #endif
+    // the unused tail of this wavefront's last block of record slots
+    for (uint32_t i = cur.next + (uint32_t)lane; i < cur.end; i += 64)
+        if (i < P.max_records) P.records[i].block = kInvalidBlock;
     // totals: one pair of atomics per workgroup (tot_fwd is per lane, tot_cand wave-uniform)
     tot_fwd = (unsigned long long)wave_sum((int)tot_fwd);                    // < 2^31 per wavefront (slot lists are u32-indexed)
     if (lane == 0) {
@@ -952,7 +975,7 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
         atomicAdd(&s_tot[1], tot_cand);
     }
     __syncthreads();
-    if (threadIdx.x == 0) P.host_totals[blockIdx.x] = WgTotals{s_tot[0], s_tot[1], s_flags[0], s_flags[1]};
+    if (threadIdx.x == 0) P.host_totals[blockIdx.x] = WgTotals{s_tot[0], s_tot[1], s_flags[0], s_flags[2], s_flags[1], 0};
 }
 
 // ------------------------------------------------------------------------------------
@@ -1036,6 +1059,23 @@ __global__ __launch_bounds__(256) void fill_kernel(uint8_t *out, uint64_t nbytes
 // host side of the ABI
 // ======================================================================================
 
+// LSD radix sort of (48-bit key, index) pairs, three 16-bit passes; std::sort below a few thousand.
+static void sort_keys48(std::vector<std::pair<uint64_t, uint32_t>> &a, std::vector<std::pair<uint64_t, uint32_t>> &tmp) {
+    const size_t n = a.size();
+    if (n < 4096) { std::sort(a.begin(), a.end()); return; }
+    tmp.resize(n);
+    std::vector<uint32_t> count(65536);
+    for (int pass = 0; pass < 3; pass++) {
+        const int shift = 16 * pass;
+        std::fill(count.begin(), count.end(), 0u);
+        for (size_t i = 0; i < n; i++) count[(a[i].first >> shift) & 0xffff]++;
+        uint32_t sum = 0;
+        for (auto &c : count) { const uint32_t t = c; c = sum; sum += t; }
+        for (size_t i = 0; i < n; i++) tmp[count[(a[i].first >> shift) & 0xffff]++] = a[i];
+        a.swap(tmp);
+    }
+}
+
 struct modes_gpu {
     modes_gpu_config cfg{};
     int maxfix = 1;
@@ -1061,12 +1101,13 @@ struct modes_gpu {
     uint32_t demod_grid = 0;          // workgroups of the demod launch in flight
     modes_record *h_records = nullptr;  // pinned, max_records
     std::vector<uint64_t> h_cands;
-    std::vector<std::pair<uint64_t, uint32_t>> sort_keys;
+    std::vector<std::pair<uint64_t, uint32_t>> sort_keys, sort_tmp;
     std::vector<modes_record> h_sorted;
 
     uint8_t *d_stage = nullptr;       size_t stage_bytes = 0;
 
     uint32_t demod_wgs = 1024;        // workgroups of demod_kernel that are resident at once (occupancy x CUs)
+    bool auto_records = false;        // max_records was 0: the record list grows when a call needs more
     bool full_slots = false;          // a run once overflowed the automatic slot_cap: size the lists for the worst case
     modes_gpu_span last_span{};       // what the detect in flight was asked to do (for the overflow retry)
 
@@ -1125,7 +1166,8 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     modes_gpu *ctx = new (std::nothrow) modes_gpu;
     if (!ctx) return fail(nullptr, MODES_ERR_NOMEM, "out of memory");
     ctx->cfg = *cfg;
-    if (ctx->cfg.max_records == 0) ctx->cfg.max_records = 1u << 20;
+    ctx->auto_records = ctx->cfg.max_records == 0;
+    if (ctx->auto_records) ctx->cfg.max_records = 1u << 20;
     ctx->maxfix = cfg->fix_errors ? (cfg->aggressive ? 2 : 1) : 0;
     auto bail = [&](int rc) { g_create_error = ctx->err; modes_gpu_destroy(ctx); return rc; };
 #define CREATE_TRY(call)                                                                              \
@@ -1369,12 +1411,14 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
     ctx->in_flight = false;
     memset(res, 0, sizeof *res);
     ResultHeader hdr{0, 0, 0, 0};
+    uint64_t n_reserved = 0;                                  // record slots handed out (>= records written)
     for (uint32_t b = 0; b < ctx->demod_grid; b++) {
         const WgTotals &t = ctx->h_totals[b];
         hdr.n_forwarded += t.n_forwarded;
         hdr.n_preambles += t.n_preambles;
         hdr.n_records += t.n_records;
         hdr.overflow |= t.overflow;
+        n_reserved += t.n_reserved;
     }
     if (hdr.overflow) {
         // More than slot_cap positions of one run look like preambles (the automatic cap is 1/16 of
@@ -1389,10 +1433,26 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
         if (rc != MODES_OK) return rc;
         return modes_gpu_fetch(ctx, res);
     }
-    if (hdr.n_records > ctx->cfg.max_records)
-        return fail(ctx, MODES_ERR_OVERFLOW, "%u records exceed max_records=%u", hdr.n_records, ctx->cfg.max_records);
-    if (hdr.n_records) {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_records, ctx->d_records, (size_t)hdr.n_records * sizeof(modes_record),
+    if (n_reserved > ctx->cfg.max_records) {
+        // n_reserved is what the call needs (the counter keeps counting past the capacity).  With the
+        // automatic capacity, grow the list with some slack and repeat the call; nothing may be dropped.
+        const uint64_t want = n_reserved + (n_reserved >> 2) + 65536;
+        if (!ctx->auto_records || want > 0xFFFFFFFFull)
+            return fail(ctx, MODES_ERR_OVERFLOW, "%llu record slots exceed max_records=%u", (unsigned long long)n_reserved,
+                        ctx->cfg.max_records);
+        (void)hipFree(ctx->d_records); ctx->d_records = nullptr;
+        (void)hipHostFree(ctx->h_records); ctx->h_records = nullptr;
+        ctx->cfg.max_records = (uint32_t)want;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_records), (size_t)want * sizeof(modes_record)));
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_records), (size_t)want * sizeof(modes_record),
+                                   hipHostMallocDefault));
+        const modes_gpu_span again = ctx->last_span;
+        int rc = modes_gpu_detect(ctx, &again, ctx->last_stream);
+        if (rc != MODES_OK) return rc;
+        return modes_gpu_fetch(ctx, res);
+    }
+    if (n_reserved) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_records, ctx->d_records, (size_t)n_reserved * sizeof(modes_record),
                                     hipMemcpyDeviceToHost, st));
     }
     if (ctx->cfg.keep_candidates && hdr.n_preambles) {
@@ -1417,21 +1477,28 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
     HIP_TRY(ctx, hipStreamSynchronize(st));
     // within a run the production scan forwards positions in queue order: restore stream order
     std::sort(ctx->h_cands.begin(), ctx->h_cands.end());
-    // records were appended in completion order: put them in stream order (sort 16-byte keys, then
-    // gather the 64-byte records once)
+    // Records sit in the reserved slots in completion order, with invalid slots in between: put the
+    // valid ones in stream order (radix sort of 48-bit keys (buffer, offset), then one gather).
     const modes_record *sorted = ctx->h_records;
-    if (hdr.n_records > 1) {
+    {
         std::vector<std::pair<uint64_t, uint32_t>> &keys = ctx->sort_keys;
-        keys.resize(hdr.n_records);
+        keys.clear();
+        keys.reserve(hdr.n_records);
         bool ascending = true;
-        for (uint32_t i = 0; i < hdr.n_records; i++) {
-            keys[i] = {((uint64_t)ctx->h_records[i].block << 32) | ctx->h_records[i].j, i};
-            if (i && keys[i].first < keys[i - 1].first) ascending = false;
+        for (uint32_t i = 0; i < (uint32_t)n_reserved; i++) {
+            const modes_record &r = ctx->h_records[i];
+            if (r.block == kInvalidBlock) continue;
+            const uint64_t k = ((uint64_t)r.block << 17) | r.j;           // j < 131072
+            if (!keys.empty() && k < keys.back().first) ascending = false;
+            keys.emplace_back(k, i);
         }
-        if (!ascending) {
-            std::sort(keys.begin(), keys.end());
-            ctx->h_sorted.resize(hdr.n_records);
-            for (uint32_t i = 0; i < hdr.n_records; i++) ctx->h_sorted[i] = ctx->h_records[keys[i].second];
+        if (keys.size() != hdr.n_records)
+            return fail(ctx, MODES_ERR_HIP, "record list inconsistent: %zu valid slots, %u records counted", keys.size(),
+                        hdr.n_records);
+        if (!ascending || keys.size() != n_reserved) {
+            if (!ascending) sort_keys48(keys, ctx->sort_tmp);
+            ctx->h_sorted.resize(keys.size());
+            for (size_t i = 0; i < keys.size(); i++) ctx->h_sorted[i] = ctx->h_records[keys[i].second];
             sorted = ctx->h_sorted.data();
         }
     }

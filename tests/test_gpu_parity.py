@@ -244,3 +244,34 @@ def test_slot_overflow_is_retried_not_dropped(torch_cuda):
     recs2, cands2, _ = d.fetch()
     assert np.array_equal(cands2, want_c) and recs2.size == recs.size
     d.close()
+
+
+def test_dense_capture_grows_record_list_and_matches_reference(torch_cuda):
+    """The reference's own capture is far denser than any real feed (~750 records per MiB).  Tiled to
+    1.5 GiB it yields more records than the automatic list capacity (2^20): the library must grow the
+    list and repeat the call, and the ordered --raw listing must still equal the reference's.  A context
+    with an explicit, too small max_records must fail with MODES_ERR_OVERFLOW instead (never truncate)."""
+    import hashlib
+    import os
+    from dump1090_amd import Demodulator, raw_text
+    torch = torch_cuda
+    one = synth.modes1_padded(os.path.join(os.path.dirname(__file__), "golden", "modes1.bin"))
+    reps = (3 << 29) // one.size
+    host = np.tile(one, reps)
+    iq = torch.from_numpy(host).to("cuda:0")
+    d = Demodulator()
+    msgs = d.demodulate(iq, batch_blocks=8192)
+    assert d.last["n_records"] > (1 << 20)
+    got = raw_text(msgs)
+    if orc.have_ref():
+        want = orc.run_ref_bytes(host, ["--raw"]).decode()
+    else:
+        want = orc.raw_text(orc.run_stream(host, cap=1 << 22, **orc.FLAGSETS["default"])[0])
+    assert got.count("\n") == want.count("\n")
+    assert hashlib.md5(got.encode()).hexdigest() == hashlib.md5(want.encode()).hexdigest()
+    d.close()
+    small = Demodulator(max_records=4096)
+    small.detect(iq[:64 * synth.DATA_LEN])
+    with pytest.raises(RuntimeError, match="OVERFLOW"):
+        small.fetch()
+    small.close()
