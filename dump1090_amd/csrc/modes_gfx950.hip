@@ -299,7 +299,11 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanPara
 // demod_kernel parameters
 // ------------------------------------------------------------------------------------
 #ifdef MODES_TRACE
-__device__ unsigned long long g_trace[8192 * 4];      // per demod wavefront: start, LUT staged, end, group
+__device__ unsigned long long g_trace[8192 * 8];      // per demod wavefront: start, LUT staged, end, preambles, then
+                                                      // summed over its groups: list set-up, stage 1, stages 2+3, stage-2 iterations
+#define TRACE_T(var) const unsigned long long var = wall_clock64()
+#else
+#define TRACE_T(var)
 #endif
 // Record slots are reserved kRecChunk at a time per wavefront: one global atomic per 32 records.
 // (One atomic per record saturates a single counter at ~88 per microsecond: 8.7 ms per GiB on the
@@ -868,6 +872,9 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
     const int64_t lo = P.lo, hi = P.hi;
     unsigned long long tot_fwd = 0, tot_cand = 0;
     RecCursor cur{0, 0};
+#ifdef MODES_TRACE
+    unsigned long long tr_setup = 0, tr_s1 = 0, tr_s23 = 0, tr_it = 0;
+#endif
 
     // A wavefront takes kDemodGroup consecutive runs at a time and walks the concatenation of their
     // slot lists 64 positions per iteration (dense lanes however short the individual lists are):
@@ -875,6 +882,7 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
     const uint32_t ngroups = (P.nruns + kDemodGroup - 1) / kDemodGroup;
     for (uint32_t group = blockIdx.x * kDemodWaves + wave; group < ngroups; group += gridDim.x * kDemodWaves) {
         const uint32_t run0 = group * kDemodGroup;
+        TRACE_T(tg0);
         // every position of the group is >= gbase and < gbase + 2^20 samples: 32-bit buffer offsets
         const int64_t gbase = (int64_t)__builtin_amdgcn_readfirstlane(run0) * P.run_chunks * kChunkSamples - 64;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(iq) + 2 * gbase, 0,
@@ -897,8 +905,12 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
         wave_lds_fence();
         uint32_t ncand = 0;
         const uint64_t cand_base = (uint64_t)group * kDemodGroup * P.slot_cap;
+#ifdef MODES_TRACE
+        tr_setup += wall_clock64() - tg0;
+#endif
         for (uint32_t base = 0; base < n; base += 64) {
             // ---------------- stage 1 ----------------
+            TRACE_T(ts1);
             const uint32_t e = base + lane;
             const bool active = e < n;
             uint32_t rr = 0;
@@ -923,6 +935,11 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+#ifdef MODES_TRACE
+            const unsigned long long ts2 = wall_clock64();
+            tr_s1 += ts2 - ts1;
+            tr_it += (nlist + 64 / kGateLanes - 1) / (64 / kGateLanes);
+#endif
             // ---------------- stage 2 + 3 ----------------
             constexpr int kPerIter = 64 / kGateLanes;                        // preambles per iteration
             const int grp = lane / kGateLanes, gl = lane % kGateLanes;
@@ -955,6 +972,9 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#ifdef MODES_TRACE
+            tr_s23 += wall_clock64() - ts2;
+#endif
         }
         tot_cand += ncand;
         if (lane == 0) P.cand_counts[group] = ncand;
@@ -962,7 +982,11 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
 #ifdef MODES_TRACE
     if ((threadIdx.x & 63) == 0) {
         const uint32_t w = blockIdx.x * kDemodWaves + (threadIdx.x >> 6);
-        if (w < 8192) { g_trace[4 * w] = t_start; g_trace[4 * w + 1] = t_lut; g_trace[4 * w + 2] = wall_clock64(); g_trace[4 * w + 3] = tot_cand; }
+        if (w < 8192) {
+            unsigned long long *t = &g_trace[8 * w];
+            t[0] = t_start; t[1] = t_lut; t[2] = wall_clock64(); t[3] = tot_cand;
+            t[4] = tr_setup; t[5] = tr_s1; t[6] = tr_s23; t[7] = tr_it;
+        }
     }
 #endif
     // the unused tail of this wavefront's last block of record slots
@@ -1550,7 +1574,7 @@ void modes_gpu_host_free(modes_gpu *ctx, void *p) {
 
 #ifdef MODES_TRACE
 int modes_gpu_trace(unsigned long long *out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 8192 * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 

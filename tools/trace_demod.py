@@ -12,14 +12,16 @@ iq = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:0")
 d.synth_noise(iq, 0, seed=20260922, sigma_q16=941)
 for _ in range(3):
     d.detect(iq); d.fetch()
-t = np.zeros(8192 * 4, dtype=np.uint64)
+t = np.zeros(8192 * 8, dtype=np.uint64)
 lib = N.gpu_lib()
 assert lib.modes_gpu_trace(t.ctypes.data_as(C.c_void_p)) == 0
-t = t.reshape(-1, 4).astype(np.int64)
+t = t.reshape(-1, 8).astype(np.int64)
 t = t[t[:, 0] != 0]                      # wavefronts that ran
 print("wavefronts", len(t))
 t0 = t[:, 0].min()
 start, lut, end, cand = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0, t[:, 3]
 print("demod_ms", d.last["demod_ms"])
-for name, v in (("start", start), ("lut done", lut), ("end", end), ("life", end - start), ("work", end - lut), ("cands", cand)):
+setup, s1, s23, it = t[:, 4] / 100.0, t[:, 5] / 100.0, t[:, 6] / 100.0, t[:, 7]
+for name, v in (("start", start), ("lut done", lut), ("end", end), ("life", end - start), ("work", end - lut), ("cands", cand),
+                ("setup", setup), ("stage 1", s1), ("stage 2+3", s23), ("s2 iters", it), ("us/s2 iter", s23 / np.maximum(it, 1))):
     print("%-9s min %8.2f p10 %8.2f p50 %8.2f p90 %8.2f max %8.2f  (us)" % (name, v.min(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
