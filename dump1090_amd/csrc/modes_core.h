@@ -88,11 +88,16 @@ MODES_HD uint32_t modes_power(uint32_t i_byte, uint32_t q_byte) {
     int i = (int)i_byte - 127, q = (int)q_byte - 127;
     return (uint32_t)(i * i + q * q);
 }
+/* Index into OUR copy of the table.  The reference indexes maglut by (|I-127|, |Q-127|)
+ * (129 x 129 entries); the value depends on s alone, so the device keeps it as a function table
+ * of the saturated power  min(s, 32767)  - 32768 u16 = 64 KiB of LDS - and the index of a pair of
+ * samples is modes_power_pair_sat: two subtracts, a multiply and a multiply-add (packed), no
+ * absolute values.  s = 32768 occurs only for I = Q = 255 and 32767 is not a sum of two squares, so
+ * entry 32767 holds maglut[128][128] and nothing collides. */
+#define MODES_LUT_ENTRIES 32768
 MODES_HD uint32_t modes_lut_index(uint32_t i_byte, uint32_t q_byte) {
-    int i = (int)i_byte - 127, q = (int)q_byte - 127;
-    if (i < 0) i = -i;
-    if (q < 0) q = -q;
-    return (uint32_t)(i * 129 + q);
+    const uint32_t s = modes_power(i_byte, q_byte);
+    return s > 32767u ? 32767u : s;
 }
 
 /* ---------------------------------------------------- preamble predicates */

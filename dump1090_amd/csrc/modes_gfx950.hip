@@ -57,7 +57,7 @@ constexpr int kLookback = 16;               // positions of the previous chunk s
 // ------------------------------------------------------------------------------------
 
 struct DeviceTables {
-    const uint16_t *lut;     // 129*129 magnitudes, dump1090.c:359-364 (built on the host in double)
+    const uint16_t *lut;     // the reference's magnitudes (dump1090.c:359-364, built on the host in double) by saturated power
     const uint32_t *esyn;    // 112 single-bit syndromes
 };
 
@@ -109,24 +109,21 @@ struct MagAt {
     }
 };
 
-// The 129 x 129 magnitude LUT (33,282 bytes, padded to kLutVec 16-byte vectors in HBM) into LDS:
-// 16 bytes per lane, all loads of a thread in flight at once.
-constexpr int kLutVec = (129 * 129 * 2 + 15) / 16;       // 2081
+// The magnitude table (MODES_LUT_ENTRIES u16 = 64 KiB, modes_core.h) into LDS: 16 bytes per lane,
+// four loads of a thread in flight at a time.
+constexpr int kLutVec = MODES_LUT_ENTRIES * 2 / 16;       // 4096
 template <int THREADS>
 __device__ __forceinline__ void stage_lut(uint16_t *s_lut, const uint16_t *lut) {
     const uint4 *src = reinterpret_cast<const uint4 *>(lut);
     uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
-    constexpr int kIter = (kLutVec + THREADS - 1) / THREADS;
-    uint4 v[kIter];
+    static_assert(kLutVec % (4 * THREADS) == 0, "whole batches");
+#pragma unroll 1
+    for (int i = (int)threadIdx.x; i < kLutVec; i += 4 * THREADS) {
+        uint4 v[4];
 #pragma unroll
-    for (int k = 0; k < kIter; k++) {
-        const int i = (int)threadIdx.x + k * THREADS;
-        v[k] = (i < kLutVec) ? src[i] : make_uint4(0, 0, 0, 0);
-    }
+        for (int k = 0; k < 4; k++) v[k] = src[i + k * THREADS];
 #pragma unroll
-    for (int k = 0; k < kIter; k++) {
-        const int i = (int)threadIdx.x + k * THREADS;
-        if (i < kLutVec) dst[i] = v[k];
+        for (int k = 0; k < 4; k++) dst[i + k * THREADS] = v[k];
     }
 }
 
@@ -667,17 +664,8 @@ __device__ __forceinline__ modes_m128 slice_pass(int lane, int lo1, int hi1, int
 // Full demodulation of one preamble by the whole wavefront (both attempts) -> record.
 // sum56 / sum112: the delta sums of dump1090.c:1713-1717 (already computed by the pre-gate).
 // Exact preamble predicate (dump1090.c:1602-1650) at buffer sample p, magnitudes from the LDS LUT.
-// Both LUT indices |I-127|*129 + |Q-127| of a dword I0 Q0 I1 Q1 (two samples) in one packed value.
-typedef short modes_s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_abs_diff127(uint32_t x) {
-    const modes_s16x2 d = __builtin_bit_cast(modes_s16x2, x) - (modes_s16x2){127, 127};
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_abs(d));
-}
-__device__ __forceinline__ uint32_t pk_lut_index(uint32_t w) {
-    const uint32_t ai = pk_abs_diff127(w & 0x00FF00FFu);                     // (|I0-127|, |I1-127|)
-    const uint32_t aq = pk_abs_diff127((w >> 8) & 0x00FF00FFu);
-    return pk_add(pk_mul(ai, 0x00810081u), aq);                              // both <= 16640
-}
+// Both LUT indices of a dword I0 Q0 I1 Q1 (two samples) in one packed value: the saturated powers.
+__device__ __forceinline__ uint32_t pk_lut_index(uint32_t w) { return modes_power_pair_sat(w); }
 
 // Exact preamble predicate (dump1090.c:1602-1650) at buffer sample p, magnitudes from the LDS LUT.
 // Guarded form: 2-byte loads, bytes outside the span read as 127.
@@ -688,12 +676,11 @@ __device__ __forceinline__ bool preamble_at_guarded(const uint8_t *iq, int64_t l
     struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
     return modes_preamble_exact(Win{m});
 }
-// Fast form: the 15 samples are 8 dwords at a 2-byte aligned address (unaligned-access mode, raw buffer
+// Fast form: the 15 samples are two 16-byte loads at a 2-byte aligned address (unaligned-access mode, raw buffer
 // descriptor); voff = byte offset of sample p from the descriptor's base.
 __device__ __forceinline__ bool preamble_at_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const uint16_t *s_lut) {
-    uint32_t w[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 4u * i, 0, 0);
+    const u32x4 wa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0), wb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16u, 0, 0);
+    const uint32_t w[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
     int m[16];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -724,30 +711,38 @@ __device__ __forceinline__ void gate_sums(const uint8_t *iq, int64_t lo, int64_t
     *d112 = s112;
 }
 
-// gate_sums<false> with half the memory instructions and packed index arithmetic: a bit pair is four
-// consecutive bytes (I_lo Q_lo I_hi Q_hi) at a 2-byte aligned address, fetched as ONE dword through a
-// raw buffer descriptor (the hardware runs in unaligned-access mode; no alignment is promised to the
-// compiler), and both LUT indices |I-127|*129 + |Q-127| come out of one v_pk_mad_u16.
-// voff = byte offset of pair `gl` of the preamble from the descriptor's base.
+// gate_sums<false> for kGateLanes = 8, whole cache lines per instruction: a preamble's 112 bit pairs are
+// 448 consecutive bytes at a 2-byte aligned address; lane gl of its group fetches bytes
+// [16 gl + 128 i, + 16) for i = 0..3 (i = 3: lanes 0..3) as 16-byte loads through a raw buffer
+// descriptor (the hardware runs in unaligned-access mode; no alignment is promised to the
+// compiler), so the eight lanes of a group consume 128 consecutive bytes per instruction.  With one
+// dword per lane and instruction the same lines were pulled into the L1 four times over.
+// A bit pair is one dword (I_lo Q_lo I_hi Q_hi); both LUT indices (saturated powers) come out of one
+// packed multiply + multiply-add.  voff = byte offset of the preamble's pair 0 from the descriptor's base.
 __device__ __forceinline__ void gate_sums_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const uint16_t *s_lut, int gl,
                                                int *d56, int *d112) {
-    constexpr int kIter = 112 / kGateLanes;
-    uint32_t w[kIter];
+    static_assert(kGateLanes == 8, "lane -> byte mapping below");
+    u32x4 w[4];
+    const uint32_t o = voff + 16u * (uint32_t)gl;
 #pragma unroll
-    for (int i = 0; i < kIter; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 4u * kGateLanes * i, 0, 0);
-    // pairs gl + kGateLanes * i: the first 56 / kGateLanes iterations are the short message's pairs for every lane
-    static_assert(56 % kGateLanes == 0, "the 56-pair prefix must end on an iteration boundary");
-    uint32_t acc = 0, s56 = 0;
+    for (int i = 0; i < 3; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 128u * i, 0, 0);
+    w[3] = u32x4{0, 0, 0, 0};                                                // four equal bytes: a pair with |lo - hi| = 0
+    if (gl < 4) w[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 384u, 0, 0);
+    uint32_t acc[4];
 #pragma unroll
-    for (int i = 0; i < kIter; i++) {
-        if (i == 56 / kGateLanes) s56 = acc;
-        const uint32_t idx = pk_lut_index(w[i]);                             // both LUT indices
-        const uint32_t a = s_lut[idx & 0xffffu], b = s_lut[idx >> 16];
-        acc = __builtin_amdgcn_sad_u16(a, b, acc);                           // acc += |a - b| (high halves are zero)
+    for (int i = 0; i < 4; i++) {
+        acc[i] = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t idx = pk_lut_index(w[i][t]);                      // both LUT indices
+            const uint32_t a = s_lut[idx & 0xffffu], b = s_lut[idx >> 16];
+            acc[i] = __builtin_amdgcn_sad_u16(a, b, acc[i]);                 // += |a - b| (high halves are zero)
+        }
     }
-    (void)gl;
+    // pairs 4 gl + 32 i + t: i = 0 is all short-message pairs, i = 1 those of lanes 0..5 (pairs 32..55)
+    const uint32_t s56 = acc[0] + (gl < 6 ? acc[1] : 0u);
     *d56 = (int)s56;
-    *d112 = (int)acc;
+    *d112 = (int)(acc[0] + acc[1] + acc[2] + acc[3]);
 }
 
 template <bool GUARD>
@@ -951,7 +946,7 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
                 const bool in2 = !gact || samples_inside(pc - 1, pc + 239, lo, hi);
                 const bool fast = __all(in2);
                 if (gact) {
-                    if (fast) gate_sums_fast(rsrc, (uint32_t)(2 * (pc - gbase)) + 32u + 4u * (uint32_t)gl, s_lut, gl, &d56, &d112);
+                    if (fast) gate_sums_fast(rsrc, (uint32_t)(2 * (pc - gbase)) + 32u, s_lut, gl, &d56, &d112);
                     else      gate_sums<true>(iq, lo, hi, s_lut, pc, gl, &d56, &d112);
                 }
 #pragma unroll
@@ -1211,9 +1206,10 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     for (auto &e : ctx->ev) CREATE_TRY(hipEventCreate(&e));
     // tables: the magnitude LUT exactly as the reference builds it (dump1090.c:359-364, double
     // arithmetic on the host) and the 112 single-bit syndromes.
-    std::vector<uint16_t> lut(kLutVec * 8, 0);             // padded to whole 16-byte vectors (stage_lut)
+    std::vector<uint16_t> lut(MODES_LUT_ENTRIES, 0);
     for (int i = 0; i <= 128; i++)
-        for (int q = 0; q <= 128; q++) lut[i * 129 + q] = (uint16_t)std::round(std::sqrt((double)(i * i + q * q)) * 360.0);
+        for (int q = 0; q <= 128; q++)
+            lut[std::min(i * i + q * q, 32767)] = (uint16_t)std::round(std::sqrt((double)(i * i + q * q)) * 360.0);
     uint32_t esyn[112];
     for (int p = 0; p < 112; p++) esyn[p] = modes_bit_syndrome(p);
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_lut), lut.size() * 2));

@@ -8,7 +8,7 @@ from dump1090_amd import _native as N
 N.GPU_LIB = sys.argv[1]
 from dump1090_amd import Demodulator
 d = Demodulator(fix=False)
-iq = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:0")
+iq = torch.empty((int(sys.argv[2]) if len(sys.argv) > 2 else 1024) << 20, dtype=torch.uint8, device="cuda:0")
 d.synth_noise(iq, 0, seed=20260922, sigma_q16=941)
 for _ in range(3):
     d.detect(iq); d.fetch()
