@@ -99,6 +99,14 @@ class Emitted(C.Structure):
     _fields_ = [("mm", ModesMessage), ("block", C.c_uint32), ("j", C.c_uint32)]
 
 
+class Aircraft(C.Structure):
+    """modes_aircraft (include/modes_host.h), the reference's struct aircraft without the list link."""
+    _fields_ = [("addr", C.c_uint32), ("hexaddr", C.c_char * 7), ("flight", C.c_char * 9), ("altitude", C.c_int),
+                ("speed", C.c_int), ("track", C.c_int), ("odd_cprlat", C.c_int), ("odd_cprlon", C.c_int),
+                ("even_cprlat", C.c_int), ("even_cprlon", C.c_int), ("lat", C.c_double), ("lon", C.c_double),
+                ("odd_cprtime", C.c_int64), ("even_cprtime", C.c_int64), ("seen_ms", C.c_int64), ("messages", C.c_long)]
+
+
 SINK_FN = C.CFUNCTYPE(None, C.POINTER(ModesMessage), C.c_uint32, C.c_uint32, C.c_void_p)
 
 # every symbol include/*.h declares (tests/test_abi.py checks the libraries export them)
@@ -110,7 +118,9 @@ HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_resolve",
                 "modes_host_wants",
                 "modes_host_get_stats", "modes_host_decode", "modes_format_raw", "modes_format_raw_net",
                 "modes_format_onlyaddr", "modes_format_verbose", "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
-                "modes_block_count")
+                "modes_block_count",
+                "modes_tracker_create", "modes_tracker_destroy", "modes_tracker_receive", "modes_tracker_expire",
+                "modes_tracker_count", "modes_tracker_get", "modes_tracker_reference", "modes_format_sbs")
 
 _gpu = None
 _host = None
@@ -173,5 +183,19 @@ def host_lib():
         L.modes_compute_crc.restype = C.c_uint32
         L.modes_block_count.argtypes = [C.c_uint64]
         L.modes_block_count.restype = C.c_uint64
+        L.modes_tracker_create.restype = C.c_void_p
+        L.modes_tracker_destroy.argtypes = [C.c_void_p]
+        L.modes_tracker_destroy.restype = None
+        L.modes_tracker_receive.argtypes = [C.c_void_p, C.POINTER(ModesMessage), C.c_int, C.c_int64]
+        L.modes_tracker_receive.restype = C.POINTER(Aircraft)
+        L.modes_tracker_expire.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        L.modes_tracker_expire.restype = C.c_uint64
+        L.modes_tracker_count.argtypes = [C.c_void_p]
+        L.modes_tracker_count.restype = C.c_uint64
+        L.modes_tracker_get.argtypes = [C.c_void_p, C.c_uint64]
+        L.modes_tracker_get.restype = C.POINTER(Aircraft)
+        L.modes_tracker_reference.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.modes_tracker_reference.restype = None
+        L.modes_format_sbs.argtypes = [C.POINTER(ModesMessage), C.POINTER(Aircraft), C.c_char_p, C.c_size_t]
         _host = L
     return _host

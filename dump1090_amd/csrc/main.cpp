@@ -2,7 +2,7 @@
 //
 //   read (--ifile <file>|-)  ->  libmodes_gfx950.so (scan + demod on the GPU, many buffers per call)
 //                            ->  libmodes_host.so   (in-order resolve, decodeModesMessage, sink)
-//                            ->  stdout (--raw / --onlyaddr / --stats)
+//                            ->  stdout (--raw / --onlyaddr / --stats; --sbs / --raw-net: the lines of the reference's TCP sinks)
 //
 // It keeps the reference's spellings and defaults for the flags of this path
 // (dump1090.c:2869-2897,2922; defaults :299-319) and processes EVERY buffer the reference's
@@ -19,6 +19,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include "../../include/modes_gfx950.h"
@@ -28,7 +29,7 @@ namespace {
 
 struct Options {
     std::string filename;
-    bool loop = false, raw = false, onlyaddr = false, stats = false;
+    bool loop = false, raw = false, onlyaddr = false, stats = false, sbs = false, raw_net = false;
     int fix_errors = 1, check_crc = 1, aggressive = 0;
     int device = 0;
     uint64_t batch_blocks = 1024;          // 256 MiB of samples per GPU call
@@ -39,6 +40,7 @@ struct Sink {
     const Options *opt;
     modes_host *host;
     std::string out;
+    modes_tracker *tracker;               // --sbs: aircraft table behind the BaseStation lines
 };
 
 void show_help() {
@@ -51,6 +53,8 @@ void show_help() {
         "--aggressive             More CPU for more messages (two bits fixes, ...).\n"
         "--stats                  With --ifile print stats at exit. No other output.\n"
         "--onlyaddr               Show only ICAO addresses (testing purposes).\n"
+        "--sbs                    Print the BaseStation lines the reference serves on port 30003.\n"
+        "--raw-net                Print the raw lines the reference serves on port 30002.\n"
         "--gpu <ordinal>          HIP device to run on (default: 0).\n"
         "--batch-blocks <n>       256 KiB buffers per GPU call (default: 1024).\n"
         "--read-threads <n>       Threads reading a regular file (default: 8).\n"
@@ -63,7 +67,16 @@ void on_message(const struct modesMessage *mm, uint32_t, uint32_t, void *user) {
     if (s->opt->stats || !modes_host_wants(s->host, mm)) return;
     char line[1024];
     int n;
-    if (s->opt->onlyaddr) n = modes_format_onlyaddr(mm, line);
+    if (s->opt->sbs) {
+        // dump1090.c:1806-1808 with an SBS client connected; the wall clock stamps the CPR frames like mstime()
+        struct timeval tv;
+        gettimeofday(&tv, nullptr);
+        const modes_aircraft *a = modes_tracker_receive(s->tracker, mm, s->opt->check_crc,
+                                                        (int64_t)tv.tv_sec * 1000 + tv.tv_usec / 1000);
+        n = a ? modes_format_sbs(mm, a, line, sizeof line) : 0;
+    }
+    else if (s->opt->raw_net) n = modes_format_raw_net(mm, line);
+    else if (s->opt->onlyaddr) n = modes_format_onlyaddr(mm, line);
     else if (s->opt->raw) n = modes_format_raw(mm, line);
     else                  n = modes_format_verbose(mm, s->opt->check_crc, line, sizeof line);   // dump1090.c:1333-1450
     s->out.append(line, (size_t)n);
@@ -127,6 +140,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--no-crc-check")) opt.check_crc = 0;
         else if (!strcmp(a, "--raw")) opt.raw = true;
         else if (!strcmp(a, "--onlyaddr")) opt.onlyaddr = true;
+        else if (!strcmp(a, "--sbs")) opt.sbs = true;
+        else if (!strcmp(a, "--raw-net")) opt.raw_net = true;
         else if (!strcmp(a, "--aggressive")) opt.aggressive++;
         else if (!strcmp(a, "--stats")) opt.stats = true;
         else if (!strcmp(a, "--gpu") && more) opt.device = atoi(argv[++j]);
@@ -176,7 +191,7 @@ int main(int argc, char **argv) {
     }
     modes_host_config hcfg{opt.fix_errors, opt.aggressive ? 1 : 0, opt.check_crc, 0};
     modes_host *host = modes_host_create(&hcfg);
-    Sink sink{&opt, host, {}};
+    Sink sink{&opt, host, {}, opt.sbs ? modes_tracker_create() : nullptr};
 
     // fetch + resolve + print the batch in flight on context k
     auto finish = [&](int k) -> bool {
@@ -246,6 +261,7 @@ int main(int argc, char **argv) {
         fputs(text, stdout);
     }
     modes_host_destroy(host);
+    modes_tracker_destroy(sink.tracker);
     for (int k = 0; k < 2; k++) {
         modes_gpu_host_free(gpu[k], buf[k]);
         modes_gpu_destroy(gpu[k]);

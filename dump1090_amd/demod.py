@@ -145,6 +145,70 @@ def verbose_text(msgs) -> str:
     return "".join(m.verbose for m in msgs)
 
 
+def raw_net_text(msgs) -> str:
+    """What the reference writes to its raw-output TCP clients (port 30002, dump1090.c:2381-2393)."""
+    return "".join("*" + m.msg[: m.msgbits // 8].hex().upper() + ";\n" for m in msgs)
+
+
+def _to_struct(m: Message) -> N.ModesMessage:
+    mm = N.ModesMessage()
+    C.memmove(mm.msg, m.msg, min(len(m.msg), 14))
+    for f in ("msgbits", "msgtype", "crcok", "crc", "errorbit", "aa1", "aa2", "aa3", "phase_corrected", "iid"):
+        setattr(mm, f, getattr(m, f))
+    for f, v in m.fields.items():
+        setattr(mm, f, v.encode("ascii", "replace") if isinstance(v, str) else v)
+    return mm
+
+
+class Tracker:
+    """Aircraft table + CPR positions + SBS lines (libmodes_host.so: modes_tracker_*, modes_format_sbs):
+    the state behind the reference's useModesMessage() while an SBS client is connected
+    (dump1090.c:1806-1808, 2069-2167, 2397-2448).  No GPU needed."""
+
+    def __init__(self, check_crc: bool = True):
+        self._lib = N.host_lib()
+        self.check_crc = check_crc
+        self._h = self._lib.modes_tracker_create()
+        if not self._h:
+            raise N.ModesError(-3, "modes_tracker_create failed")
+
+    def close(self):
+        if self._h:
+            self._lib.modes_tracker_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def sbs_text(self, msgs, now_ms: int = 0) -> str:
+        """The lines port 30003 would carry for these messages, in order."""
+        out = []
+        buf = C.create_string_buffer(256)
+        for m in msgs:
+            mm = _to_struct(m)
+            a = self._lib.modes_tracker_receive(self._h, C.byref(mm), int(self.check_crc), now_ms)
+            if a and self._lib.modes_format_sbs(C.byref(mm), a, buf, 256):
+                out.append(buf.value.decode("ascii"))
+        return "".join(out)
+
+    def aircraft(self) -> list[dict]:
+        """The table, newest aircraft first."""
+        rows = []
+        for i in range(self._lib.modes_tracker_count(self._h)):
+            a = self._lib.modes_tracker_get(self._h, i).contents
+            rows.append({f: (getattr(a, f).decode("ascii", "replace") if isinstance(getattr(a, f), bytes) else getattr(a, f))
+                         for f, _ in N.Aircraft._fields_})
+        return rows
+
+    def reference_position(self):
+        lat, lon, n = C.c_double(), C.c_double(), C.c_int()
+        self._lib.modes_tracker_reference(self._h, C.byref(lat), C.byref(lon), C.byref(n))
+        return lat.value, lon.value, n.value
+
+    def expire(self, now_ms: int, ttl_ms: int = 60000) -> int:
+        return int(self._lib.modes_tracker_expire(self._h, now_ms, ttl_ms))
+
+
 def onlyaddr_text(msgs) -> str:
     return "".join(m.addr_line() for m in msgs)
 

@@ -163,6 +163,49 @@ int modes_format_verbose(const struct modesMessage *mm, int check_crc, char *buf
 /* The 9-line --stats summary (dump1090.c:2994-3005); buf >= 512 bytes. */
 int modes_format_stats(const modes_host_stats *st, char *buf);
 
+/* ---- aircraft table, CPR positions and the BaseStation (SBS) sink ------------------------------
+ * What the reference keeps behind useModesMessage() while an SBS (port 30003) or HTTP client is
+ * connected (dump1090.c:1806-1808).  Sequential host state like the ICAO whitelist; the sockets
+ * themselves, the interactive screen and the web map stay out of scope. */
+
+/* struct aircraft (dump1090.c:107-130), the list link replaced by the tracker's own index. */
+typedef struct {
+    uint32_t addr;              /* ICAO address */
+    char hexaddr[7];            /* printable ICAO address */
+    char flight[9];             /* flight number */
+    int altitude;               /* altitude */
+    int speed;                  /* velocity computed from EW and NS components */
+    int track;                  /* angle of flight */
+    int odd_cprlat, odd_cprlon; /* encoded latitude / longitude of the last odd and even CPR frame */
+    int even_cprlat, even_cprlon;
+    double lat, lon;            /* coordinates obtained from CPR encoded data */
+    int64_t odd_cprtime, even_cprtime;   /* when (ms) those frames arrived */
+    int64_t seen_ms;            /* time (ms) of the last message */
+    long messages;              /* number of Mode S messages received */
+} modes_aircraft;
+
+typedef struct modes_tracker modes_tracker;
+modes_tracker *modes_tracker_create(void);
+void           modes_tracker_destroy(modes_tracker *tr);
+/* interactiveReceiveData() (dump1090.c:2069-2167): account `mm` to its aircraft (created on first
+ * sight), update altitude / flight / speed / track and decode the CPR position (airborne pairs at
+ * most 10 s apart, dump1090.c:2120; surface frames against the running mean of the airborne
+ * positions, dump1090.c:2141-2155).  now_ms is the caller's clock (the reference reads
+ * gettimeofday).  Returns the aircraft, or NULL when check_crc is set and mm->crcok is 0
+ * (dump1090.c:2073).  The pointer stays valid until that aircraft expires. */
+const modes_aircraft *modes_tracker_receive(modes_tracker *tr, const struct modesMessage *mm, int check_crc, int64_t now_ms);
+/* interactiveRemoveStaleAircrafts() (dump1090.c:2203-2224): forget aircraft not heard for more than
+ * ttl_ms (the reference: 60 s).  Returns how many were removed. */
+uint64_t modes_tracker_expire(modes_tracker *tr, int64_t now_ms, int64_t ttl_ms);
+uint64_t modes_tracker_count(const modes_tracker *tr);
+const modes_aircraft *modes_tracker_get(const modes_tracker *tr, uint64_t i);   /* newest aircraft first */
+/* Modes.ref_lat / ref_lon / ref_count (dump1090.c:205-206). */
+void modes_tracker_reference(const modes_tracker *tr, double *lat, double *lon, int *count);
+/* modesSendSBSOutput() (dump1090.c:2397-2448): the line for `mm`, '\n'-terminated, or 0 when this
+ * message type has no SBS line.  `a` = what modes_tracker_receive returned for this message (needed
+ * for MSG,3 positions and MSG,4 speed / track).  256 bytes always suffice. */
+int modes_format_sbs(const struct modesMessage *mm, const modes_aircraft *a, char *buf, size_t cap);
+
 /* CRC helpers shared with the device code (dump1090.c:703-753). */
 uint32_t modes_checksum(const unsigned char *msg, int bits);      /* modesChecksum      */
 uint32_t modes_compute_crc(const unsigned char *msg, int bits);   /* modesComputeCRC    */

@@ -128,6 +128,22 @@ def test_cli_reproduces_reference_stdout(torch_cuda, flags, lines, md5):
     assert p2.stdout == p.stdout
 
 
+@pytest.mark.parametrize("flag,golden_file", [("--sbs", "modes1_sbs.txt"), ("--raw-net", "modes1_rawnet.txt")])
+def test_cli_network_sink_lines_match_reference_capture(torch_cuda, flag, golden_file):
+    """--sbs / --raw-net print what the reference wrote to clients of its ports 30003 / 30002 for the same
+    capture (tests/golden/make_net_golden.py).  The constant-clock interposer of the oracle pins which CPR
+    frame counts as newer, as it did for the reference when the golden was recorded."""
+    exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
+    env = dict(os.environ, LD_PRELOAD=orc.FIXED_TIME) if os.path.exists(orc.FIXED_TIME) else dict(os.environ)
+    p = subprocess.run([exe, "--ifile", os.path.join(ROOT, "tests", "golden", "modes1.bin"), flag],
+                       capture_output=True, check=True, env=env)
+    want = open(os.path.join(ROOT, "tests", "golden", golden_file), "rb").read()
+    if flag == "--sbs" and not os.path.exists(orc.FIXED_TIME):
+        assert p.stdout.count(b"\n") == want.count(b"\n")          # real clock: positions may pick the other frame
+    else:
+        assert p.stdout == want, p.stderr[-400:]
+
+
 def test_sharded_detection_equals_whole(torch_cuda, streams):
     """Buffers split over 'ranks' with only the 476-byte carry shared: same records."""
     from dump1090_amd import Demodulator, block_count, shard_blocks, shard_byte_range
