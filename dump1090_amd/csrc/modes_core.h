@@ -464,6 +464,24 @@ MODES_HD void modes_pair_flags(int k, int lo, int hi, bool *weak, bool *strong, 
     *strong = lo > hi;                             /* dump1090.c:1683 */
 }
 
+/* msg[0] >> 3 of the FIRST slicing pass (uncorrected magnitudes) from its first six bit pairs alone
+ * (dump1090.c:1669-1711): bit k of `weak` = |lo_k - hi_k| < 256, of `gt` = lo_k > hi_k, k = 0..5;
+ * eq0 = (lo_0 == hi_0).  Pair 0 never repeats (:1675, i > 0); the value 2 it takes when lo == hi (:1682)
+ * travels down a run of weak pairs and ORs into the neighbouring bit when packed (:1696-1706).
+ * Pairs 6 and 7 land in bits 1, 0 (and 2 for a value 2 of pair 6) of msg[0]: never in the DF. */
+MODES_HD int modes_df_first6(uint32_t weak, uint32_t gt, bool eq0) {
+    uint32_t b = eq0 ? 2u : (gt & 1u);
+    uint32_t m = b << 7;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 1; k < 6; k++) {
+        b = ((weak >> k) & 1u) ? b : ((gt >> k) & 1u);
+        m |= b << (7 - k);
+    }
+    return (int)((m & 0xffu) >> 3);
+}
+
 /* From the masks of one slicing pass to the packed message, dump1090.c:1669-1706.
  * `first_equal` = (lo_0 == hi_0): the reference stores the value 2 for that pair and for the
  * weak pairs that repeat it; packing ORs `2 << (7 - t)` into byte k/8 (t = k%8), i.e. sets the

@@ -309,8 +309,9 @@ constexpr uint32_t kRecChunk = 32;
 constexpr uint32_t kInvalidBlock = 0xFFFFFFFFu;
 struct RecCursor { uint32_t next, end; };   // wave-uniform
 
-constexpr int kDemodWaves = 8;        // wavefronts per demod workgroup (they share one 33 KB LUT copy in LDS)
-constexpr int kDemodGroup = 4;        // runs whose slot lists one demod wavefront walks together (power of two <= 64)
+constexpr int kDemodWaves = 8;        // wavefronts per demod workgroup (they share one 64 KB LUT copy in LDS)
+constexpr int kDemodThreads = kDemodWaves * 64;
+constexpr int kDemodGroup = 64;       // runs whose slot lists one demod workgroup walks together (one per lane of a wavefront)
 
 struct DemodParams {
     const uint8_t *iq;
@@ -638,6 +639,13 @@ __device__ __forceinline__ void store_attempt(modes_attempt *out, modes_m128 bit
     out->syndrome = f.syndrome;
 }
 
+// The delta sums of dump1090.c:1713-1717 over the first 56 and over all 112 pairs (lane L: pairs L, L + 64).
+__device__ __forceinline__ void delta_sums(int lane, int lo1, int hi1, int lo2, int hi2, int *sum56, int *sum112) {
+    const int d1 = lo1 > hi1 ? lo1 - hi1 : hi1 - lo1, d2 = lo2 > hi2 ? lo2 - hi2 : hi2 - lo2;
+    *sum112 = wave_sum(d1 + (lane < 48 ? d2 : 0));                           // < 2^23
+    *sum56 = wave_sum(lane < 56 ? d1 : 0);
+}
+
 // One slicing pass for the whole wavefront: lane L holds pairs k1 = L and k2 = L + 64.
 // Returns the packed message (wave-uniform) and, on request, the two delta sums.
 __device__ __forceinline__ modes_m128 slice_pass(int lane, int lo1, int hi1, int lo2, int hi2, uint8_t *errors,
@@ -662,7 +670,7 @@ __device__ __forceinline__ modes_m128 slice_pass(int lane, int lo1, int hi1, int
 }
 
 // Full demodulation of one preamble by the whole wavefront (both attempts) -> record.
-// sum56 / sum112: the delta sums of dump1090.c:1713-1717 (already computed by the pre-gate).
+// known56 / known112: the delta sums of dump1090.c:1713-1717 as far as the pre-test computed them.
 // Exact preamble predicate (dump1090.c:1602-1650) at buffer sample p, magnitudes from the LDS LUT.
 // Both LUT indices of a dword I0 Q0 I1 Q1 (two samples) in one packed value: the saturated powers.
 __device__ __forceinline__ uint32_t pk_lut_index(uint32_t w) { return modes_power_pair_sat(w); }
@@ -692,62 +700,56 @@ __device__ __forceinline__ bool preamble_at_fast(__amdgpu_buffer_rsrc_t rsrc, ui
     return modes_preamble_exact(Win{m});
 }
 
-// Sums of |lo-hi| over pairs gl, gl+kGateLanes, ... of the preamble at pc (one kGateLanes-lane group).
-constexpr int kGateLanes = 8;         // lanes per preamble in the gate pre-test -> 64 / 8 preambles per iteration
-template <bool GUARD>
-__device__ __forceinline__ void gate_sums(const uint8_t *iq, int64_t lo, int64_t hi, const uint16_t *s_lut, int64_t pc, int gl,
-                                          int *d56, int *d112) {
-    int s56 = 0, s112 = 0;
+// Noise-gate pre-test (dump1090.c:1713-1723): the sum of |lo - hi| over 56 consecutive bit pairs
+// (a short message, or the second half of a long one) by a group of kGateLanes = 4 lanes.
+// The 56 pairs are 224 consecutive bytes at a 2-byte aligned address; lane t of the group fetches the
+// 16-byte pieces t, t + 4, t + 8 and (t < 2) t + 12 through a raw buffer descriptor (the hardware runs
+// in unaligned-access mode; no alignment is promised to the compiler), so the four lanes consume 64
+// consecutive bytes per instruction and every line is pulled into the L1 once.  A bit pair is one
+// dword (I_lo Q_lo I_hi Q_hi); both LUT indices (saturated powers) come out of one packed
+// multiply + multiply-add.  voff = byte offset of the first pair from the descriptor's base.
+constexpr uint32_t kUnknown = 0xFFFFFFFFu;      // a delta sum the pre-test did not need
+constexpr int kGateLanes = 4;                   // lanes per preamble in the gate pre-test
+constexpr int kGatePerRound = kDemodThreads / kGateLanes;   // preambles a workgroup tests per round
+__device__ __forceinline__ void half_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, int t, u32x4 (&w)[4]) {
+    const uint32_t o = voff + 16u * (uint32_t)t;
 #pragma unroll
-    for (int i = 0; i < 112 / kGateLanes; i++) {
-        const int k = gl + kGateLanes * i;
-        const int a = mag_of(s_lut, load_sample<GUARD>(iq, pc + 16 + 2 * k, lo, hi));
-        const int b = mag_of(s_lut, load_sample<GUARD>(iq, pc + 17 + 2 * k, lo, hi));
-        const int d = a > b ? a - b : b - a;
-        s112 += d;
-        if (k < 56) s56 += d;
-    }
-    *d56 = s56;
-    *d112 = s112;
-}
-
-// gate_sums<false> for kGateLanes = 8, whole cache lines per instruction: a preamble's 112 bit pairs are
-// 448 consecutive bytes at a 2-byte aligned address; lane gl of its group fetches bytes
-// [16 gl + 128 i, + 16) for i = 0..3 (i = 3: lanes 0..3) as 16-byte loads through a raw buffer
-// descriptor (the hardware runs in unaligned-access mode; no alignment is promised to the
-// compiler), so the eight lanes of a group consume 128 consecutive bytes per instruction.  With one
-// dword per lane and instruction the same lines were pulled into the L1 four times over.
-// A bit pair is one dword (I_lo Q_lo I_hi Q_hi); both LUT indices (saturated powers) come out of one
-// packed multiply + multiply-add.  voff = byte offset of the preamble's pair 0 from the descriptor's base.
-__device__ __forceinline__ void gate_sums_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const uint16_t *s_lut, int gl,
-                                               int *d56, int *d112) {
-    static_assert(kGateLanes == 8, "lane -> byte mapping below");
-    u32x4 w[4];
-    const uint32_t o = voff + 16u * (uint32_t)gl;
-#pragma unroll
-    for (int i = 0; i < 3; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 128u * i, 0, 0);
+    for (int i = 0; i < 3; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 64u * i, 0, 0);
     w[3] = u32x4{0, 0, 0, 0};                                                // four equal bytes: a pair with |lo - hi| = 0
-    if (gl < 4) w[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 384u, 0, 0);
-    uint32_t acc[4];
+    if (t < 2) w[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 192u, 0, 0);
+}
+// Returns this lane's part of the sum.  *first: flags of the lane's first four pairs (pairs 4t .. 4t+3 of
+// the 56), bit k = |lo - hi| < 256, bit 4 + k = lo > hi, bit 8 = (lo == hi) of its first pair.
+__device__ __forceinline__ uint32_t half_eval(const u32x4 (&w)[4], const uint16_t *s_lut, uint32_t *first) {
+    uint32_t acc = 0, f = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        acc[i] = 0;
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const uint32_t idx = pk_lut_index(w[i][t]);                      // both LUT indices
+        for (int k = 0; k < 4; k++) {
+            const uint32_t idx = pk_lut_index(w[i][k]);                      // both LUT indices
             const uint32_t a = s_lut[idx & 0xffffu], b = s_lut[idx >> 16];
-            acc[i] = __builtin_amdgcn_sad_u16(a, b, acc[i]);                 // += |a - b| (high halves are zero)
+            if (i == 0 && first) {
+                const uint32_t d = __builtin_amdgcn_sad_u16(a, b, 0u);
+                f |= (d < 256u ? 1u : 0u) << k | (a > b ? 1u : 0u) << (4 + k);
+                if (k == 0) f |= (a == b ? 1u : 0u) << 8;
+                acc += d;
+            } else {
+                acc = __builtin_amdgcn_sad_u16(a, b, acc);                   // += |a - b| (high halves are zero)
+            }
         }
     }
-    // pairs 4 gl + 32 i + t: i = 0 is all short-message pairs, i = 1 those of lanes 0..5 (pairs 32..55)
-    const uint32_t s56 = acc[0] + (gl < 6 ? acc[1] : 0u);
-    *d56 = (int)s56;
-    *d112 = (int)(acc[0] + acc[1] + acc[2] + acc[3]);
+    if (first) *first = f;
+    return acc;
+}
+__device__ __forceinline__ void surv_push(uint32_t *list, uint32_t k, uint32_t p, uint32_t sum56, uint32_t sum112) {
+    list[3 * k] = p;
+    list[3 * k + 1] = sum56;
+    list[3 * k + 2] = sum112;
 }
 
 template <bool GUARD>
 __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t *s_lut, const uint32_t *s_esyn, uint32_t *wg_counts,
-                                           RecCursor &cur, int lane, int64_t pc, int sum56, int sum112) {
+                                           RecCursor &cur, int lane, int64_t pc, uint32_t known56, uint32_t known112) {
     const uint8_t *iq = P.iq;
     const int64_t lo = P.lo, hi = P.hi;
     const uint64_t g = (uint64_t)pc + P.g0;
@@ -760,9 +762,15 @@ __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t 
     const int hi2 = two ? mag_of(s_lut, load_sample<GUARD>(iq, pc + 145 + 2 * lane, lo, hi)) : 0;
     const int pre = (lane < 12) ? mag_of(s_lut, load_sample<GUARD>(iq, pc - 1 + lane, lo, hi)) : 0;
 
+    // the delta sums of dump1090.c:1713-1717: what the pre-test already has (kUnknown otherwise), the rest on demand
+    int sum56 = (int)known56, sum112 = (int)known112;
+    bool have112 = known112 != kUnknown;
+    if (known56 == kUnknown) { delta_sums(lane, lo1, hi1, lo2, hi2, &sum56, &sum112); have112 = true; }
     uint8_t err0;
     const modes_m128 bits0 = slice_pass(lane, lo1, hi1, lo2, hi2, &err0, nullptr, nullptr);
-    const bool gate0 = modes_len_by_df(df_of_bits(bits0)) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+    const bool long0 = modes_len_by_df(df_of_bits(bits0)) == 112;
+    if (long0 && !have112) { delta_sums(lane, lo1, hi1, lo2, hi2, &sum56, &sum112); have112 = true; }
+    const bool gate0 = long0 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
     if (!gate0) return;                                                      // dump1090.c:1723-1726: position ends
 
     uint8_t err1 = err0;
@@ -802,7 +810,9 @@ __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t 
         }
         bits1 = slice_pass(lane, nlo1, nhi1, nlo2, nhi2, &err1, nullptr, nullptr);
         // the gate of the retry: uncorrected deltas, the retry's own length (dump1090.c:1708-1723)
-        gate1 = modes_len_by_df(df_of_bits(bits1)) == 112 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+        const bool long1 = modes_len_by_df(df_of_bits(bits1)) == 112;
+        if (long1 && !have112) delta_sums(lane, lo1, hi1, lo2, hi2, &sum56, &sum112);
+        gate1 = long1 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
     }
     // syndromes and repair positions: the whole wavefront, both attempts (wave-uniform results)
     const AttemptFix f0 = wave_finish_attempt(bits0, true, P.maxfix, lane, s_esyn);
@@ -830,29 +840,37 @@ __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t 
 }
 
 // ------------------------------------------------------------------------------------
-// demod_kernel - persistent workgroups; a wavefront takes kDemodGroup runs at a time.
-//   stage 1: one lane per forwarded position: exact preamble predicate (dump1090.c:1602-1650)
-//            on LUT magnitudes; survivors compacted, in order, into a wave-private LDS list.
-//   stage 2: noise-gate pre-test (dump1090.c:1713-1723), 64 / kGateLanes preambles per iteration,
-//            kGateLanes lanes each: sum of |lo-hi| over the 56 and the 112 bit pairs.  A position whose sums fail
-//            the gate for BOTH message lengths ends here (that is nearly every preamble found in
-//            noise), whatever its bits are.
-//   stage 3: the wavefront demodulates the survivors one at a time, all 64 lanes cooperating
-//            (coalesced sample loads; the sequential parts of the reference become carry chains,
-//            see modes_core.h), then syndrome and repair search, again by the whole wavefront.
-//            Positions whose first noise gate passes become records.
+// demod_kernel - persistent workgroups; a workgroup takes a batch of kDemodGroup consecutive runs at a
+// time and walks the concatenation of their slot lists kDemodThreads positions per block, all eight
+// wavefronts together (the work per run varies several-fold; the sum over a batch does not):
+//   stage 1: one thread per forwarded position: exact preamble predicate (dump1090.c:1602-1650)
+//            on LUT magnitudes; survivors compacted into a workgroup list (the "valid preambles"
+//            of --stats).
+//   stage 2: noise-gate pre-test (dump1090.c:1713-1723), kGateLanes lanes per preamble:
+//            a) the first 56 bit pairs: their sum of |lo-hi|, and from the first six pairs the DF of
+//               the first slicing pass, i.e. the message length the gate is evaluated on - a short
+//               message is decided here, a long one queues for b) its other 56 pairs.
+//            A position that fails ends here (nearly every preamble found in noise).
+//   stage 3: one wavefront per survivor, all 64 lanes cooperating (coalesced sample loads; the
+//            sequential parts of the reference become carry chains, see modes_core.h): both attempts,
+//            then syndrome and repair search.  Positions whose first noise gate passes become records.
+// Lists live in LDS; appends from stages 2a/2b reserve their slots with one LDS atomic per wavefront.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80))) void demod_kernel(DemodParams P) {
+__global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80))) void demod_kernel(DemodParams P) {
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[kLutVec * 8];
-    __shared__ uint32_t s_list[kDemodWaves][64];
-    __shared__ uint32_t s_pre[kDemodWaves][kDemodGroup];
+    __shared__ uint32_t s_pre[kDemodGroup + 1];        // exclusive prefix of the batch's (clamped) run counts
+    __shared__ uint32_t s_list[kDemodThreads];         // preambles awaiting the gate pre-test
+    __shared__ uint32_t s_long[2 * kDemodThreads];     // (position, sum over the first 56 pairs) of those that decode as long
+    __shared__ uint32_t s_surv[3 * kDemodThreads];     // (position, the two delta sums or kUnknown) of those that go to stage 3
+    __shared__ uint32_t s_wc[3][kDemodWaves];          // per-wavefront counts of one stage-1 block: list, edge, candidates
+    __shared__ uint32_t s_n[2];                        // entries of s_long, s_surv
     __shared__ uint32_t s_esyn[112];
     __shared__ unsigned long long s_tot[2];
     __shared__ uint32_t s_flags[3];            // records written by this workgroup, slot-list overflow seen, slots reserved
 #ifdef MODES_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
-    stage_lut<kDemodWaves * 64>(s_lut, P.tab.lut);
+    stage_lut<kDemodThreads>(s_lut, P.tab.lut);
     if (threadIdx.x < 112) s_esyn[threadIdx.x] = P.tab.esyn[threadIdx.x];
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
     if (threadIdx.x < 3) s_flags[threadIdx.x] = 0;
@@ -861,137 +879,207 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
     const unsigned long long t_lut = wall_clock64();
 #endif
 
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint8_t *iq = P.iq;
     const int64_t lo = P.lo, hi = P.hi;
-    unsigned long long tot_fwd = 0, tot_cand = 0;
+    const uint64_t below = (1ull << lane) - 1;
+    unsigned long long tot_fwd = 0, tot_cand = 0;       // tot_fwd: per lane of wavefront 0; tot_cand: workgroup-uniform
     RecCursor cur{0, 0};
 #ifdef MODES_TRACE
-    unsigned long long tr_setup = 0, tr_s1 = 0, tr_s23 = 0, tr_it = 0;
+    unsigned long long tr_t[4] = {0, 0, 0, 0};          // batch set-up, stage 1, stage 2a, stages 2b + 3
+#define TRACE_ADD(k, since) tr_t[k] += wall_clock64() - (since)
+#else
+#define TRACE_ADD(k, since)
 #endif
 
-    // A wavefront takes kDemodGroup consecutive runs at a time and walks the concatenation of their
-    // slot lists 64 positions per iteration (dense lanes however short the individual lists are):
-    // s_pre = exclusive prefix of the runs' counts, output index o -> (run, index) by binary search.
-    const uint32_t ngroups = (P.nruns + kDemodGroup - 1) / kDemodGroup;
-    for (uint32_t group = blockIdx.x * kDemodWaves + wave; group < ngroups; group += gridDim.x * kDemodWaves) {
-        const uint32_t run0 = group * kDemodGroup;
-        TRACE_T(tg0);
-        // every position of the group is >= gbase and < gbase + 2^20 samples: 32-bit buffer offsets
-        const int64_t gbase = (int64_t)__builtin_amdgcn_readfirstlane(run0) * P.run_chunks * kChunkSamples - 64;
+    const uint32_t nbatches = (P.nruns + kDemodGroup - 1) / kDemodGroup;
+    for (uint32_t batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
+        const uint32_t run0 = batch * kDemodGroup;
+        TRACE_T(tb0);
+        // every position of the batch is >= gbase: 32-bit byte offsets from there through a raw buffer descriptor
+        const int64_t gbase = (int64_t)run0 * P.run_chunks * kChunkSamples - 64;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(iq) + 2 * gbase, 0,
                                                                               0x7fffffff, 0x00020000);
-        uint32_t cnt = 0;
-        if (lane < kDemodGroup && run0 + lane < P.nruns) {
-            const uint32_t true_count = P.counts[run0 + lane];
-            if (true_count > P.slot_cap) atomicOr(&s_flags[1], 1u);        // the scan dropped positions: the call fails
-            cnt = min(true_count, P.slot_cap);
-            tot_fwd += true_count;                                           // summed over lanes at the end
-        }
-        uint32_t incl = cnt;                                                 // inclusive scan over lanes 0..kDemodGroup-1
+        if (wave == 0) {                                                     // one run per lane
+            uint32_t cnt = 0;
+            if (run0 + lane < P.nruns) {
+                const uint32_t true_count = P.counts[run0 + lane];
+                if (true_count > P.slot_cap) atomicOr(&s_flags[1], 1u);        // the scan dropped positions: the call fails
+                cnt = min(true_count, P.slot_cap);
+                tot_fwd += true_count;
+            }
+            uint32_t incl = cnt;
 #pragma unroll
-        for (int off = 1; off < kDemodGroup; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            s_pre[lane] = incl - cnt;
+            if (lane == 63) s_pre[64] = incl;
         }
-        if (lane < kDemodGroup) s_pre[wave][lane] = incl - cnt;
-        const uint32_t n = __shfl(incl, kDemodGroup - 1, 64);                // forwarded positions of the group
-        wave_lds_fence();
+        __syncthreads();
+        const uint32_t n = s_pre[kDemodGroup];                               // forwarded positions of the batch
+        TRACE_ADD(0, tb0);
         uint32_t ncand = 0;
-        const uint64_t cand_base = (uint64_t)group * kDemodGroup * P.slot_cap;
-#ifdef MODES_TRACE
-        tr_setup += wall_clock64() - tg0;
-#endif
-        for (uint32_t base = 0; base < n; base += 64) {
+        const uint64_t cand_base = (uint64_t)batch * kDemodGroup * P.slot_cap;
+        for (uint32_t base = 0; base < n; base += kDemodThreads) {
             // ---------------- stage 1 ----------------
             TRACE_T(ts1);
-            const uint32_t e = base + lane;
+            const uint32_t e = base + (uint32_t)tid;
             const bool active = e < n;
-            uint32_t rr = 0;
+            uint32_t rr = 0;                                                 // the last run that starts at or before e
 #pragma unroll
             for (int step = kDemodGroup / 2; step >= 1; step >>= 1)
-                if (s_pre[wave][rr + step] <= e) rr += step;
-            const uint32_t p = active ? P.slots[(uint64_t)(run0 + rr) * P.slot_cap + (e - s_pre[wave][rr])] : 0u;
+                if (s_pre[rr + step] <= e) rr += step;
+            const uint32_t p = active ? P.slots[(uint64_t)(run0 + rr) * P.slot_cap + (e - s_pre[rr])] : 0u;
             // fast path when every lane's 16-sample window is inside the span (wave-uniform test)
             const bool in1 = !active || samples_inside((int64_t)p, (int64_t)p + 15, lo, hi);
             bool ok;
             if (__all(in1)) ok = active && preamble_at_fast(rsrc, (uint32_t)(2 * ((int64_t)p - gbase)), s_lut);
             else            ok = active && preamble_at_guarded(iq, lo, hi, s_lut, p);
-            const uint64_t okb = __ballot(ok);
-            const uint32_t rank = (uint32_t)__builtin_popcountll(okb & ((1ull << lane) - 1));
-            if (ok) {
-                s_list[wave][rank] = p;
-                if (P.cand_slots) P.cand_slots[cand_base + ncand + rank] = p;
+            // Preambles whose whole message window (samples p-1 .. p+239) lies inside the span go to the
+            // pre-test list; the few next to an end of the span go straight to stage 3 (guarded loads).
+            const bool whole = samples_inside((int64_t)p - 1, (int64_t)p + 239, lo, hi);
+            const uint64_t okb = __ballot(ok), listb = __ballot(ok && whole), edgeb = okb & ~listb;
+            if (lane == 0) {
+                s_wc[0][wave] = (uint32_t)__builtin_popcountll(listb);
+                s_wc[1][wave] = (uint32_t)__builtin_popcountll(edgeb);
+                s_wc[2][wave] = (uint32_t)__builtin_popcountll(okb);
             }
-            const uint32_t nlist = (uint32_t)__builtin_popcountll(okb);
-            ncand += nlist;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-#ifdef MODES_TRACE
-            const unsigned long long ts2 = wall_clock64();
-            tr_s1 += ts2 - ts1;
-            tr_it += (nlist + 64 / kGateLanes - 1) / (64 / kGateLanes);
-#endif
-            // ---------------- stage 2 + 3 ----------------
-            constexpr int kPerIter = 64 / kGateLanes;                        // preambles per iteration
-            const int grp = lane / kGateLanes, gl = lane % kGateLanes;
-            for (uint32_t c0 = 0; c0 < nlist; c0 += kPerIter) {
-                const uint32_t c = c0 + (uint32_t)grp;
-                const bool gact = c < nlist;
-                const int64_t pc = gact ? (int64_t)s_list[wave][c] : 0;
-                int d56 = 0, d112 = 0;
-                const bool in2 = !gact || samples_inside(pc - 1, pc + 239, lo, hi);
-                const bool fast = __all(in2);
-                if (gact) {
-                    if (fast) gate_sums_fast(rsrc, (uint32_t)(2 * (pc - gbase)) + 32u, s_lut, gl, &d56, &d112);
-                    else      gate_sums<true>(iq, lo, hi, s_lut, pc, gl, &d56, &d112);
-                }
+            __syncthreads();
+            uint32_t off[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
 #pragma unroll
-                for (int off = kGateLanes / 2; off >= 1; off >>= 1) {        // reduce within each group
-                    d56 += __shfl_xor(d56, off, 64);
-                    d112 += __shfl_xor(d112, off, 64);
-                }
-                const bool may_pass = gact && (d112 / 56 >= 2550 || d56 / 28 >= 2550);
-                uint64_t todo = __ballot(may_pass && gl == 0);
-                while (todo) {
-                    const int leader = __builtin_ctzll(todo);                // first lane of a group
-                    todo &= todo - 1;
-                    const int64_t pcs = (int64_t)s_list[wave][c0 + (uint32_t)(leader / kGateLanes)];
-                    const int s56 = __builtin_amdgcn_readlane(d56, leader), s112 = __builtin_amdgcn_readlane(d112, leader);
-                    if (fast) demod_full<false>(P, s_lut, s_esyn, s_flags, cur, lane, pcs, s56, s112);
-                    else      demod_full<true>(P, s_lut, s_esyn, s_flags, cur, lane, pcs, s56, s112);
+            for (int w = 0; w < kDemodWaves; w++) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t c = s_wc[k][w];
+                    if (w < wave) off[k] += c;
+                    tot[k] += c;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#ifdef MODES_TRACE
-            tr_s23 += wall_clock64() - ts2;
-#endif
+            if (ok) {
+                if (whole) s_list[off[0] + (uint32_t)__builtin_popcountll(listb & below)] = p;
+                else       surv_push(s_surv, off[1] + (uint32_t)__builtin_popcountll(edgeb & below), p, kUnknown, kUnknown);
+                if (P.cand_slots) P.cand_slots[cand_base + ncand + off[2] + (uint32_t)__builtin_popcountll(okb & below)] = p;
+            }
+            if (tid == 0) { s_n[0] = 0; s_n[1] = tot[1]; }
+            const uint32_t nlist = tot[0];
+            ncand += tot[2];
+            __syncthreads();
+
+            // ---------------- stage 2 ----------------
+            TRACE_ADD(1, ts1);
+            TRACE_T(ts2);
+            const int grp = tid / kGateLanes, t = tid % kGateLanes;
+            const int head = lane & ~(kGateLanes - 1);                       // first lane of this lane's group
+            {   // a: the next round's loads are issued before this one's sums
+                u32x4 wn[4] = {};
+                uint32_t npc = 0;
+                bool nact = false;
+                auto issue = [&](uint32_t c0) {
+                    const uint32_t c = c0 + (uint32_t)grp;
+                    nact = c < nlist;
+                    npc = nact ? s_list[c] : 0u;
+                    if (nact) half_load(rsrc, (uint32_t)(2 * ((int64_t)npc - gbase)) + 32u, t, wn);
+                };
+                if (nlist) issue(0);
+                for (uint32_t c0 = 0; c0 < nlist; c0 += kGatePerRound) {
+                    u32x4 w[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) w[i] = wn[i];
+                    const uint32_t pc = npc;
+                    const bool gact = nact;
+                    if (c0 + kGatePerRound < nlist) issue(c0 + kGatePerRound);
+                    uint32_t first;
+                    uint32_t d56 = half_eval(w, s_lut, &first);
+#pragma unroll
+                    for (int o = kGateLanes / 2; o >= 1; o >>= 1) d56 += (uint32_t)__shfl_xor((int)d56, o, 64);
+                    // lane 1 of the group holds pairs 4, 5; pairs 0..3 come from lane 0
+                    const uint32_t f0 = (uint32_t)__shfl((int)first, head, 64);
+                    const int df = modes_df_first6((f0 & 0xfu) | ((first & 0x3u) << 4), ((f0 >> 4) & 0xfu) | (((first >> 4) & 0x3u) << 4),
+                                                   ((f0 >> 8) & 1u) != 0);
+                    const bool is_long = modes_len_by_df(df) == 112;
+                    const bool mine = gact && t == 1;
+                    const bool pass = mine && !is_long && d56 / 28 >= 2550;  // dump1090.c:1717-1723, short message
+                    const bool more = mine && is_long;
+                    const uint64_t pb = __ballot(pass), mb = __ballot(more);
+                    uint32_t sbase = 0, lbase = 0;
+                    if (lane == 0) {
+                        if (pb) sbase = atomicAdd(&s_n[1], (uint32_t)__builtin_popcountll(pb));
+                        if (mb) lbase = atomicAdd(&s_n[0], (uint32_t)__builtin_popcountll(mb));
+                    }
+                    sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sbase);
+                    lbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lbase);
+                    if (pass) surv_push(s_surv, sbase + (uint32_t)__builtin_popcountll(pb & below), pc, d56, kUnknown);
+                    if (more) {
+                        const uint32_t k = lbase + (uint32_t)__builtin_popcountll(mb & below);
+                        s_long[2 * k] = pc;
+                        s_long[2 * k + 1] = d56;
+                    }
+                }
+            }
+            __syncthreads();
+            TRACE_ADD(2, ts2);
+            TRACE_T(ts3);
+            {   // b: the other 56 pairs of the long ones
+                const uint32_t nlong = s_n[0];
+                for (uint32_t c0 = 0; c0 < nlong; c0 += kGatePerRound) {
+                    const uint32_t c = c0 + (uint32_t)grp;
+                    const bool gact = c < nlong;
+                    const uint32_t pc = gact ? s_long[2 * c] : 0u;
+                    const uint32_t d56 = gact ? s_long[2 * c + 1] : 0u;
+                    uint32_t d112 = 0;
+                    if (gact) {
+                        u32x4 w[4];
+                        half_load(rsrc, (uint32_t)(2 * ((int64_t)pc - gbase)) + 32u + 224u, t, w);
+                        d112 = half_eval(w, s_lut, nullptr);
+                    }
+#pragma unroll
+                    for (int o = kGateLanes / 2; o >= 1; o >>= 1) d112 += (uint32_t)__shfl_xor((int)d112, o, 64);
+                    d112 += d56;
+                    const bool pass = gact && t == 1 && d112 / 56 >= 2550;   // dump1090.c:1717-1723, long message
+                    const uint64_t pb = __ballot(pass);
+                    uint32_t sbase = 0;
+                    if (lane == 0 && pb) sbase = atomicAdd(&s_n[1], (uint32_t)__builtin_popcountll(pb));
+                    sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sbase);
+                    if (pass) surv_push(s_surv, sbase + (uint32_t)__builtin_popcountll(pb & below), pc, d56, d112);
+                }
+            }
+            __syncthreads();
+            // ---------------- stage 3 ----------------
+            const uint32_t nsurv = s_n[1];
+            for (uint32_t k = (uint32_t)wave; k < nsurv; k += kDemodWaves) {
+                const int64_t pcs = (int64_t)s_surv[3 * k];
+                const uint32_t k56 = s_surv[3 * k + 1], k112 = s_surv[3 * k + 2];
+                if (samples_inside(pcs - 1, pcs + 239, lo, hi)) demod_full<false>(P, s_lut, s_esyn, s_flags, cur, lane, pcs, k56, k112);
+                else                                            demod_full<true>(P, s_lut, s_esyn, s_flags, cur, lane, pcs, k56, k112);
+            }
+            __syncthreads();
+            TRACE_ADD(3, ts3);
         }
         tot_cand += ncand;
-        if (lane == 0) P.cand_counts[group] = ncand;
+        if (tid == 0) P.cand_counts[batch] = ncand;
+        __syncthreads();                                                     // s_pre is rewritten by the next batch
     }
 #ifdef MODES_TRACE
-    if ((threadIdx.x & 63) == 0) {
-        const uint32_t w = blockIdx.x * kDemodWaves + (threadIdx.x >> 6);
+    if (lane == 0) {
+        const uint32_t w = blockIdx.x * kDemodWaves + (uint32_t)wave;
         if (w < 8192) {
-            unsigned long long *t = &g_trace[8 * w];
-            t[0] = t_start; t[1] = t_lut; t[2] = wall_clock64(); t[3] = tot_cand;
-            t[4] = tr_setup; t[5] = tr_s1; t[6] = tr_s23; t[7] = tr_it;
+            unsigned long long *tr = &g_trace[8 * w];
+            tr[0] = t_start; tr[1] = t_lut; tr[2] = wall_clock64(); tr[3] = tot_cand;
+            tr[4] = tr_t[0]; tr[5] = tr_t[1]; tr[6] = tr_t[2]; tr[7] = tr_t[3];
         }
     }
 #endif
     // the unused tail of this wavefront's last block of record slots
     for (uint32_t i = cur.next + (uint32_t)lane; i < cur.end; i += 64)
         if (i < P.max_records) P.records[i].block = kInvalidBlock;
-    // totals: one pair of atomics per workgroup (tot_fwd is per lane, tot_cand wave-uniform)
-    tot_fwd = (unsigned long long)wave_sum((int)tot_fwd);                    // < 2^31 per wavefront (slot lists are u32-indexed)
-    if (lane == 0) {
-        atomicAdd(&s_tot[0], tot_fwd);
-        atomicAdd(&s_tot[1], tot_cand);
+    // totals (tot_fwd: lanes of wavefront 0; tot_cand: the same number in every thread)
+    if (wave == 0) {
+        tot_fwd = (unsigned long long)wave_sum((int)tot_fwd);                // < 2^31 per workgroup and call (slot lists are u32-indexed)
+        if (lane == 0) { s_tot[0] = tot_fwd; s_tot[1] = tot_cand; }
     }
     __syncthreads();
     if (threadIdx.x == 0) P.host_totals[blockIdx.x] = WgTotals{s_tot[0], s_tot[1], s_flags[0], s_flags[2], s_flags[1], 0};
@@ -1200,7 +1288,7 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
         hipDeviceProp_t prop;
         int per_cu = 0;
         CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
-        CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel, kDemodWaves * 64, 0));
+        CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel, kDemodThreads, 0));
         ctx->demod_wgs = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, prop.multiProcessorCount);
     }
     for (auto &e : ctx->ev) CREATE_TRY(hipEventCreate(&e));
@@ -1403,8 +1491,8 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
         st2 = ctx->own_stream;
         HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev[1], 0));
     }
-    ctx->demod_grid = std::min<uint32_t>((ngroups + kDemodWaves - 1) / kDemodWaves, ctx->demod_wgs);
-    hipLaunchKernelGGL(demod_kernel, dim3(ctx->demod_grid), dim3(kDemodWaves * 64), 0, st2, dp);
+    ctx->demod_grid = std::min<uint32_t>(ngroups, ctx->demod_wgs);        // one batch of kDemodGroup runs per workgroup and turn
+    hipLaunchKernelGGL(demod_kernel, dim3(ctx->demod_grid), dim3(kDemodThreads), 0, st2, dp);
     if (ctx->cfg.keep_candidates)
         hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st2, d_cand_counts, ngroups, ctx->d_cand_offsets);
     HIP_TRY(ctx, hipGetLastError());

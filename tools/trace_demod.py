@@ -21,7 +21,6 @@ print("wavefronts", len(t))
 t0 = t[:, 0].min()
 start, lut, end, cand = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0, t[:, 3]
 print("demod_ms", d.last["demod_ms"])
-setup, s1, s23, it = t[:, 4] / 100.0, t[:, 5] / 100.0, t[:, 6] / 100.0, t[:, 7]
 for name, v in (("start", start), ("lut done", lut), ("end", end), ("life", end - start), ("work", end - lut), ("cands", cand),
-                ("setup", setup), ("stage 1", s1), ("stage 2+3", s23), ("s2 iters", it), ("us/s2 iter", s23 / np.maximum(it, 1))):
-    print("%-9s min %8.2f p10 %8.2f p50 %8.2f p90 %8.2f max %8.2f  (us)" % (name, v.min(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
+                ("batch setup", t[:, 4] / 100.0), ("stage 1", t[:, 5] / 100.0), ("stage 2a", t[:, 6] / 100.0), ("stage 2b+3", t[:, 7] / 100.0)):
+    print("%-11s min %8.2f p10 %8.2f p50 %8.2f p90 %8.2f max %8.2f  (us; cands: count)" % (name, v.min(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
