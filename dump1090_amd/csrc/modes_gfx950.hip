@@ -669,9 +669,6 @@ __device__ __forceinline__ modes_m128 slice_pass(int lane, int lo1, int hi1, int
     return bits;
 }
 
-// Full demodulation of one preamble by the whole wavefront (both attempts) -> record.
-// known56 / known112: the delta sums of dump1090.c:1713-1717 as far as the pre-test computed them.
-// Exact preamble predicate (dump1090.c:1602-1650) at buffer sample p, magnitudes from the LDS LUT.
 // Both LUT indices of a dword I0 Q0 I1 Q1 (two samples) in one packed value: the saturated powers.
 __device__ __forceinline__ uint32_t pk_lut_index(uint32_t w) { return modes_power_pair_sat(w); }
 
@@ -747,6 +744,8 @@ __device__ __forceinline__ void surv_push(uint32_t *list, uint32_t k, uint32_t p
     list[3 * k + 2] = sum112;
 }
 
+// Full demodulation of one preamble by the whole wavefront (both attempts) -> record.
+// known56 / known112: the delta sums of dump1090.c:1713-1717 as far as the pre-test computed them.
 template <bool GUARD>
 __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t *s_lut, const uint32_t *s_esyn, uint32_t *wg_counts,
                                            RecCursor &cur, int lane, int64_t pc, uint32_t known56, uint32_t known112) {

@@ -90,6 +90,19 @@ void shim_demod_both(const uint16_t *win, int with_phase, uint8_t *out) {
     memcpy(out, a, sizeof a);
 }
 
+// DF of the first slicing pass from its first six bit pairs alone (the demod kernel's gate pre-test
+// uses it to pick the message length).  win as above.
+int shim_df_first6(const uint16_t *win) {
+    uint32_t weak = 0, gt = 0;
+    for (int k = 0; k < 6; k++) {
+        const int lo = win[1 + 16 + 2 * k], hi = win[1 + 17 + 2 * k];
+        const int d = lo > hi ? lo - hi : hi - lo;
+        weak |= (d < 256 ? 1u : 0u) << k;
+        gt |= (lo > hi ? 1u : 0u) << k;
+    }
+    return modes_df_first6(weak, gt, win[1 + 16] == win[1 + 17]);
+}
+
 // The data-parallel formulation the gfx950 demod kernel uses (carry chains, modes_core.h), with the
 // 64 lanes emulated by loops: lane L owns pairs L and L+64, "ballots" become mask-building loops.
 // Mirrors demod_kernel's stage 2 statement by statement.

@@ -22,6 +22,7 @@ def shim():
     L.shim_demod_both.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.shim_demod_parallel.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.shim_preamble_exact.argtypes = [C.c_void_p]
+    L.shim_df_first6.argtypes = [C.c_void_p]
     L.shim_syndrome.argtypes = [C.c_void_p, C.c_int]
     L.shim_syndrome.restype = C.c_uint32
     L.shim_bit_syndrome.restype = C.c_uint32
@@ -252,3 +253,26 @@ def test_syndrome_and_fix_match_oracle(shim):
             rn = L.orc_fix_bit_errors(ref_msg.ctypes.data, bits, maxfix, fixed)
             assert n == rn, (trial, maxfix)
             assert [int(x) for x in pos[:n]] == [fixed[i] for i in range(rn)]
+
+
+def test_df_from_first_six_pairs_equals_df_of_the_full_slicing_pass(shim):
+    """The gate pre-test picks the message length from modes_df_first6; it must equal msg[0] >> 3 of the whole
+    first pass (dump1090.c:1669-1711) for every mix of clear, weak (|lo-hi| < 256) and equal pairs - the
+    value 2 of an equal first pair travels down runs of weak pairs and ORs into the neighbouring bit."""
+    rng = np.random.default_rng(7)
+    out = np.zeros(32, dtype=np.uint8)
+    seen = set()
+    for trial in range(20000):
+        win = rng.integers(0, 65168, size=241).astype(np.uint16)
+        kind = rng.integers(0, 4, size=8)                    # per pair: 0 clear, 1 weak, 2 equal, 3 as drawn
+        for k in range(8):
+            lo = int(win[17 + 2 * k])
+            if kind[k] == 1:
+                win[18 + 2 * k] = np.uint16(min(65167, max(0, lo + int(rng.integers(-255, 256)))))
+            elif kind[k] == 2:
+                win[18 + 2 * k] = np.uint16(lo)
+        shim.shim_demod_both(win.ctypes.data, 0, out.ctypes.data)
+        df = int(out[0]) >> 3
+        assert shim.shim_df_first6(win.ctypes.data) == df, (trial, kind[:6])
+        seen.add(df)
+    assert len(seen) == 32
