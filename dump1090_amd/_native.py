@@ -116,7 +116,7 @@ GPU_SYMBOLS = ("modes_gpu_create", "modes_gpu_destroy", "modes_gpu_last_error", 
                "modes_gpu_synth_noise", "modes_gpu_fill", "modes_gpu_abi_version")
 HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_resolve", "modes_host_resolve_to_array",
                 "modes_host_wants",
-                "modes_host_get_stats", "modes_host_decode", "modes_format_raw", "modes_format_raw_net",
+                "modes_host_get_stats", "modes_host_decode", "modes_host_decode_frame", "modes_format_raw", "modes_format_raw_net",
                 "modes_format_onlyaddr", "modes_format_verbose", "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
                 "modes_block_count",
                 "modes_tracker_create", "modes_tracker_destroy", "modes_tracker_receive", "modes_tracker_expire",
@@ -172,6 +172,8 @@ def host_lib():
         L.modes_host_get_stats.restype = None
         L.modes_host_decode.argtypes = [C.c_void_p, C.POINTER(Attempt), C.POINTER(ModesMessage)]
         L.modes_host_decode.restype = None
+        L.modes_host_decode_frame.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(ModesMessage)]
+        L.modes_host_decode_frame.restype = None
         L.modes_format_raw.argtypes = [C.POINTER(ModesMessage), C.c_char_p]
         L.modes_format_raw_net.argtypes = [C.POINTER(ModesMessage), C.c_char_p]
         L.modes_format_onlyaddr.argtypes = [C.POINTER(ModesMessage), C.c_char_p]

@@ -1418,7 +1418,10 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
 
     const uint64_t nchunks = (uint64_t)(p_end + kLookback + kChunkSamples - 1) / kChunkSamples;
     uint32_t R = ctx->cfg.run_chunks;
-    if (R == 0) R = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(32, nchunks / 8192));
+    // automatic run length: long runs amortise a run's set-up in the scan (32 chunks is enough), but the
+    // demod kernel wants at least one batch of kDemodGroup runs per resident workgroup
+    if (R == 0) R = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(32, nchunks / ((uint64_t)kDemodGroup * ctx->demod_wgs)));
+    if (R > 8192) return fail(ctx, MODES_ERR_ARG, "run_chunks=%u: at most 8192", R);
     R += R & 1;                                                   // the scan loop is unrolled by two chunks
     const uint32_t nruns = (uint32_t)std::max<uint64_t>(1, (nchunks + R - 1) / R);
     uint32_t cap = ctx->cfg.slot_cap;

@@ -101,6 +101,26 @@ static int decode_ac12(const unsigned char *msg, int *unit) {
     return 0;
 }
 
+// A frame that did not come through the GPU (the reference's raw TCP input, decodeHexMessage
+// dump1090.c:2472-2502, hands bytes straight to decodeModesMessage): syndrome and repair lookup on
+// the host with the same helpers the device uses, then the common decode.
+void modes_host_decode_frame(modes_host *h, const unsigned char *frame, struct modesMessage *mm) {
+    static uint32_t esyn[112];
+    static bool have = false;
+    if (!have) {
+        for (int p = 0; p < 112; p++) esyn[p] = modes_bit_syndrome(p);
+        have = true;
+    }
+    modes_attempt att;
+    memset(&att, 0, sizeof att);
+    memcpy(att.msg, frame, MODES_LONG_MSG_BYTES);
+    const int bits = modes_len_by_df(frame[0] >> 3);
+    att.gate_ok = 1;
+    att.syndrome = modes_syndrome(att.msg, bits / 8);
+    att.nfix = (uint8_t)modes_find_fix(att.syndrome, bits, h->cfg.fix_errors ? (h->cfg.aggressive ? 2 : 1) : 0, esyn, att.fixpos);
+    modes_host_decode(h, &att, mm);
+}
+
 void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMessage *mm) {
     static const char ais[] = "?ABCDEFGHIJKLMNOPQRSTUVWXYZ????? ???????????????0123456789??????";
     // The reference leaves the fields a message type does not use uninitialised (mm is a stack

@@ -146,6 +146,11 @@ void modes_host_get_stats(const modes_host *h, modes_host_stats *out);
  * ICAO whitelist and the repair counters exactly like the reference. */
 void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMessage *mm);
 
+/* The same for a frame that did not come through the GPU - 14 bytes as the reference's raw TCP
+ * input hands them to decodeModesMessage (decodeHexMessage, dump1090.c:2472-2502): syndrome and
+ * repair lookup happen here, with the context's fix_errors / aggressive. */
+void modes_host_decode_frame(modes_host *h, const unsigned char *frame, struct modesMessage *mm);
+
 /* Formatting of the sink's two machine-readable modes.  buf >= 40 bytes.
  *   raw:      "*<hex>;\n"   (dump1090.c:1324-1326)
  *   onlyaddr: "%02x%02x%02x\n" (dump1090.c:1319)

@@ -112,3 +112,52 @@ def test_sbs_line_per_message_type():
         "MSG,4,,,ABCDEF,,,,,,,,420,271,,,-640,,0,0,0,0\n"
     assert line(msgtype=17, metype=19, mesub=3) is None and line(msgtype=16) is None and line(msgtype=20) is None
     lib.modes_tracker_destroy(tr)
+
+
+# ---- frame-level parity: every DF / ME type, CPR all over the globe, surface positions, AP replies, bit errors ----
+# tests/golden/make_frames_golden.py sent the lines of frames_in.txt to the compiled reference's raw-input port
+# (decodeHexMessage, dump1090.c:2472-2502) and recorded its verbose stdout, its SBS port and its raw-output port.
+
+def replay_frames(flagset):
+    flags = orc.FLAGSETS[flagset]
+    lib = N.host_lib()
+    cfg = N.HostConfig(int(flags["fix"]), int(flags["aggressive"]), int(flags["check_crc"]), 0)
+    h = lib.modes_host_create(C.byref(cfg))
+    tr = lib.modes_tracker_create()
+    verbose, sbs, rawnet = [], [], []
+    vbuf, lbuf = C.create_string_buffer(1024), C.create_string_buffer(256)
+    for line in golden_text("frames_in.txt").split():
+        frame = bytes.fromhex(line[1:-1]).ljust(14, b"\0")
+        mm = N.ModesMessage()
+        lib.modes_host_decode_frame(h, frame, C.byref(mm))
+        if not lib.modes_host_wants(h, C.byref(mm)):                      # dump1090.c:1803
+            continue
+        a = lib.modes_tracker_receive(tr, C.byref(mm), int(flags["check_crc"]), 1700000000000)
+        if a and lib.modes_format_sbs(C.byref(mm), a, lbuf, 256):
+            sbs.append(lbuf.value.decode())
+        lib.modes_format_verbose(C.byref(mm), int(flags["check_crc"]), vbuf, 1024)
+        verbose.append(vbuf.value.decode())
+        lib.modes_format_raw_net(C.byref(mm), lbuf)
+        rawnet.append(lbuf.value.decode())
+    lib.modes_tracker_destroy(tr)
+    lib.modes_host_destroy(h)
+    return "".join(verbose), "".join(sbs), "".join(rawnet)
+
+
+@pytest.mark.parametrize("flagset,tag", [("default", ""), ("aggressive", "_aggressive"), ("nofix", "_nofix")])
+def test_scripted_frames_match_reference(flagset, tag):
+    verbose, sbs, rawnet = replay_frames(flagset)
+    want_raw = golden_text("frames_rawnet%s.txt" % tag)
+    assert rawnet.count("\n") == want_raw.count("\n") > 1300
+    assert rawnet == want_raw                                  # which frames are displayed, repaired bytes included
+    want_sbs = golden_text("frames_sbs%s.txt" % tag)
+    got_lines, want_lines = sbs.splitlines(), want_sbs.splitlines()
+    for k, (g, w) in enumerate(zip(got_lines, want_lines)):
+        assert g == w, "SBS line %d" % k
+    assert len(got_lines) == len(want_lines) > 800
+    assert sum("MSG,3" in ln and ln.split(",")[14] != "" for ln in got_lines) > 100     # decoded positions
+    want_verbose = golden_text("frames_verbose%s.txt" % tag)
+    got_v, want_v = verbose.splitlines(), want_verbose.splitlines()
+    for k, (g, w) in enumerate(zip(got_v, want_v)):
+        assert g == w, "verbose line %d" % k
+    assert len(got_v) == len(want_v)
