@@ -36,10 +36,12 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/modes_gfx950.h"
 #include "modes_core.h"
+#include "modes_order.h"
 
 static_assert(sizeof(modes_attempt) == 28, "modes_attempt layout");
 static_assert(sizeof(modes_record) == 64, "modes_record layout");
@@ -1165,23 +1167,6 @@ __global__ __launch_bounds__(256) void fill_kernel(uint8_t *out, uint64_t nbytes
 // host side of the ABI
 // ======================================================================================
 
-// LSD radix sort of (48-bit key, index) pairs, three 16-bit passes; std::sort below a few thousand.
-static void sort_keys48(std::vector<std::pair<uint64_t, uint32_t>> &a, std::vector<std::pair<uint64_t, uint32_t>> &tmp) {
-    const size_t n = a.size();
-    if (n < 4096) { std::sort(a.begin(), a.end()); return; }
-    tmp.resize(n);
-    std::vector<uint32_t> count(65536);
-    for (int pass = 0; pass < 3; pass++) {
-        const int shift = 16 * pass;
-        std::fill(count.begin(), count.end(), 0u);
-        for (size_t i = 0; i < n; i++) count[(a[i].first >> shift) & 0xffff]++;
-        uint32_t sum = 0;
-        for (auto &c : count) { const uint32_t t = c; c = sum; sum += t; }
-        for (size_t i = 0; i < n; i++) tmp[count[(a[i].first >> shift) & 0xffff]++] = a[i];
-        a.swap(tmp);
-    }
-}
-
 struct modes_gpu {
     modes_gpu_config cfg{};
     int maxfix = 1;
@@ -1207,7 +1192,8 @@ struct modes_gpu {
     uint32_t demod_grid = 0;          // workgroups of the demod launch in flight
     modes_record *h_records = nullptr;  // pinned, max_records
     std::vector<uint64_t> h_cands;
-    std::vector<std::pair<uint64_t, uint32_t>> sort_keys, sort_tmp;
+    modes_order_scratch order_scratch;
+    int order_threads = 1;            // threads that put a long record list in order (modes_order.h)
     std::vector<modes_record> h_sorted;
 
     uint8_t *d_stage = nullptr;       size_t stage_bytes = 0;
@@ -1272,6 +1258,7 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     modes_gpu *ctx = new (std::nothrow) modes_gpu;
     if (!ctx) return fail(nullptr, MODES_ERR_NOMEM, "out of memory");
     ctx->cfg = *cfg;
+    ctx->order_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     ctx->auto_records = ctx->cfg.max_records == 0;
     if (ctx->auto_records) ctx->cfg.max_records = 1u << 20;
     ctx->maxfix = cfg->fix_errors ? (cfg->aggressive ? 2 : 1) : 0;
@@ -1588,29 +1575,15 @@ int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
     // within a run the production scan forwards positions in queue order: restore stream order
     std::sort(ctx->h_cands.begin(), ctx->h_cands.end());
     // Records sit in the reserved slots in completion order, with invalid slots in between: put the
-    // valid ones in stream order (radix sort of 48-bit keys (buffer, offset), then one gather).
+    // valid ones in stream order (modes_order.h; long lists are partitioned and sorted by several threads).
     const modes_record *sorted = ctx->h_records;
-    {
-        std::vector<std::pair<uint64_t, uint32_t>> &keys = ctx->sort_keys;
-        keys.clear();
-        keys.reserve(hdr.n_records);
-        bool ascending = true;
-        for (uint32_t i = 0; i < (uint32_t)n_reserved; i++) {
-            const modes_record &r = ctx->h_records[i];
-            if (r.block == kInvalidBlock) continue;
-            const uint64_t k = ((uint64_t)r.block << 17) | r.j;           // j < 131072
-            if (!keys.empty() && k < keys.back().first) ascending = false;
-            keys.emplace_back(k, i);
-        }
-        if (keys.size() != hdr.n_records)
-            return fail(ctx, MODES_ERR_HIP, "record list inconsistent: %zu valid slots, %u records counted", keys.size(),
-                        hdr.n_records);
-        if (!ascending || keys.size() != n_reserved) {
-            if (!ascending) sort_keys48(keys, ctx->sort_tmp);
-            ctx->h_sorted.resize(keys.size());
-            for (size_t i = 0; i < keys.size(); i++) ctx->h_sorted[i] = ctx->h_records[keys[i].second];
-            sorted = ctx->h_sorted.data();
-        }
+    if (n_reserved) {
+        if (ctx->h_sorted.size() < n_reserved) ctx->h_sorted.resize(n_reserved);
+        const size_t n = modes_order_records(ctx->h_records, (size_t)n_reserved, kInvalidBlock, (uint32_t)ctx->last_span.first_block,
+                                             ctx->h_sorted.data(), ctx->order_scratch, ctx->order_threads);
+        if (n != hdr.n_records)
+            return fail(ctx, MODES_ERR_HIP, "record list inconsistent: %zu valid slots, %u records counted", n, hdr.n_records);
+        sorted = ctx->h_sorted.data();
     }
     res->records = sorted;
     res->n_records = hdr.n_records;

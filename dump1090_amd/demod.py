@@ -292,14 +292,15 @@ class Demodulator:
     def _unpack(self, res):
         n = int(res.n_records)
         if n:
-            recs = np.frombuffer(C.string_at(res.records, n * 64), dtype=N.RECORD_DTYPE).copy()
+            raw = (C.c_uint8 * (n * 64)).from_address(C.cast(res.records, C.c_void_p).value)
+            recs = np.frombuffer(raw, dtype=N.RECORD_DTYPE).copy()        # the library reuses its buffer on the next call
         else:
             recs = np.zeros(0, dtype=N.RECORD_DTYPE)
         cands = None
         if self.keep_candidates:
             nc = int(res.n_candidates)
-            cands = (np.frombuffer(C.string_at(res.candidates, nc * 8), dtype=np.uint64).copy() if nc
-                     else np.zeros(0, dtype=np.uint64))
+            cands = (np.frombuffer((C.c_uint8 * (nc * 8)).from_address(C.cast(res.candidates, C.c_void_p).value),
+                                   dtype=np.uint64).copy() if nc else np.zeros(0, dtype=np.uint64))
         self.last = dict(n_records=n, n_forwarded=int(res.n_forwarded), n_preambles=int(res.n_preambles),
                          scan_ms=float(res.scan_ms), demod_ms=float(res.demod_ms))
         return recs, cands, dict(self.last)
