@@ -298,8 +298,8 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanPara
 // demod_kernel parameters
 // ------------------------------------------------------------------------------------
 #ifdef MODES_TRACE
-__device__ unsigned long long g_trace[8192 * 8];      // per demod wavefront: start, LUT staged, end, preambles, then
-                                                      // summed over its groups: list set-up, stage 1, stages 2+3, stage-2 iterations
+__device__ unsigned long long g_trace[8192 * 8];      // per demod wavefront: start, table staged, end, preambles of its workgroup,
+                                                      // then summed over its batches: set-up, stage 1, stage 2a, stages 2b + 3
 #define TRACE_T(var) const unsigned long long var = wall_clock64()
 #else
 #define TRACE_T(var)
