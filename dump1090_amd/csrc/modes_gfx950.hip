@@ -378,6 +378,7 @@ __device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *q
         p0 = e[15];
     }
     const uint16_t *w = reinterpret_cast<const uint16_t *>(e);
+    const uint32_t p_begin32 = (uint32_t)P.p_begin, p_span32 = (uint32_t)(P.p_end - P.p_begin), g0_lo = (uint32_t)P.g0;
     uint64_t pending = __ballot(m8 != 0);
     while (pending) {
         bool fwd = false;
@@ -390,8 +391,10 @@ __device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *q
                            s13 = x[13], s14 = x[14];
             const uint32_t quiet = max(max(max(s4, s5), max(s11, s12)), max(s13, s14));
             p = p0 + (uint32_t)i;                                            // wraps for the 16 look-back positions of chunk 0
-            fwd = modes_level_bound(s0, s2, s7, s9, quiet) && (int64_t)p >= P.p_begin && (int64_t)p < P.p_end &&
-                  (((uint64_t)p + P.g0) & (MODES_BLOCK_STRIDE - 1)) < MODES_BLOCK_POSITIONS;   // j < 131070, :1593
+            // 32-bit forms of p_begin <= p < p_end and of the framing rule j < 131070 (:1593): positions of a call are
+            // below 2^32 - 2^15, so a wrapped look-back position fails the first test, and j only needs p + g0 mod 2^17
+            fwd = modes_level_bound(s0, s2, s7, s9, quiet) && (p - p_begin32) < p_span32 &&
+                  ((p + g0_lo) & (MODES_BLOCK_STRIDE - 1)) < MODES_BLOCK_POSITIONS;
         }
         const uint64_t fb = __ballot(fwd);
         if (fwd) {
@@ -466,7 +469,7 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
             if (any) {
                 // rank among the pushing lanes: v_mbcnt counts the mask bits below this lane
                 const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u));
-                uint32_t *e = queue + (qn + below) * kQStride;
+                uint32_t *e = queue + __umul24(qn + below, (uint32_t)kQStride);      // v_mad_u32_u24, not a 32-bit multiply
 #pragma unroll
                 for (int t = 0; t < 11; t++) e[t] = E[t];
 #pragma unroll
