@@ -105,12 +105,12 @@ static int decode_ac12(const unsigned char *msg, int *unit) {
 // dump1090.c:2472-2502, hands bytes straight to decodeModesMessage): syndrome and repair lookup on
 // the host with the same helpers the device uses, then the common decode.
 void modes_host_decode_frame(modes_host *h, const unsigned char *frame, struct modesMessage *mm) {
-    static uint32_t esyn[112];
-    static bool have = false;
-    if (!have) {
-        for (int p = 0; p < 112; p++) esyn[p] = modes_bit_syndrome(p);
-        have = true;
-    }
+    struct Table {
+        uint32_t esyn[112];
+        Table() { for (int p = 0; p < 112; p++) esyn[p] = modes_bit_syndrome(p); }
+    };
+    static const Table table;                        // initialised once, thread-safe
+    const uint32_t *esyn = table.esyn;
     modes_attempt att;
     memset(&att, 0, sizeof att);
     memcpy(att.msg, frame, MODES_LONG_MSG_BYTES);
