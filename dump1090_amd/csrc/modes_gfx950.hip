@@ -928,16 +928,23 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
         TRACE_ADD(0, tb0);
         uint32_t ncand = 0;
         const uint64_t cand_base = (uint64_t)batch * kDemodGroup * P.slot_cap;
+        // position number e of the batch: entry e - s_pre[rr] of run rr, the last run that starts at or before e
+        auto slot_of = [&](uint32_t e) -> uint32_t {
+            uint32_t rr = 0;
+#pragma unroll
+            for (int step = kDemodGroup / 2; step >= 1; step >>= 1)
+                if (s_pre[rr + step] <= e) rr += step;
+            return P.slots[(uint64_t)(run0 + rr) * P.slot_cap + (e - s_pre[rr])];
+        };
+        uint32_t p_next = (uint32_t)tid < n ? slot_of((uint32_t)tid) : 0u;
         for (uint32_t base = 0; base < n; base += kDemodThreads) {
             // ---------------- stage 1 ----------------
             TRACE_T(ts1);
             const uint32_t e = base + (uint32_t)tid;
             const bool active = e < n;
-            uint32_t rr = 0;                                                 // the last run that starts at or before e
-#pragma unroll
-            for (int step = kDemodGroup / 2; step >= 1; step >>= 1)
-                if (s_pre[rr + step] <= e) rr += step;
-            const uint32_t p = active ? P.slots[(uint64_t)(run0 + rr) * P.slot_cap + (e - s_pre[rr])] : 0u;
+            const uint32_t p = p_next;
+            // the next block's position travels through this block's stages: one dependent gather less per block
+            p_next = e + kDemodThreads < n ? slot_of(e + kDemodThreads) : 0u;
             // fast path when every lane's 16-sample window is inside the span (wave-uniform test)
             const bool in1 = !active || samples_inside((int64_t)p, (int64_t)p + 15, lo, hi);
             bool ok;
