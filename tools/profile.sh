@@ -11,7 +11,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --depth 1 $EXTRA"
+BENCH="python $R/bench.py --steps 300 --warmup 2 --no-cpu-baseline --depth 1 $EXTRA"   # the timed region dominates the --stats average
 SHORT="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --depth 1 $EXTRA"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -f csv -- $BENCH > "$OUT/kt.log" 2>&1
 echo "kt rc=$?"

@@ -46,9 +46,17 @@ for f in find("*kernel_trace.csv"):
         v.sort()
         print("  %-24s n=%4d  median %9.1f us  min %9.1f  max %9.1f   vgpr/agpr/sgpr/lds/scratch/wg/grid=%s" % (
             n, len(v), v[len(v) // 2] / 1e3, v[0] / 1e3, v[-1] / 1e3, meta[n]))
-        if n in order and len(order[n]) > 12:
-            tail = order[n][-10:]                       # the timed steps (after bench.py's settle + warmup)
-            print("  %-24s last 10 launches (the timed region): avg %9.1f us" % (n, sum(tail) / len(tail) / 1e3))
+        if n in order and len(order[n]) > 92:
+            tail = order[n][82:]                        # bench.py's timed steps (after its 80 settle + 2 warmup steps)
+            print("  %-24s the %d launches of the timed region: avg %9.1f us" % (n, len(tail), sum(tail) / len(tail) / 1e3))
+    kt_log = os.path.join(out, "kt.log")
+    if os.path.exists(kt_log):
+        import json
+        for line in open(kt_log):
+            if line.startswith("{") and "kernel_ms" in line:
+                j = json.loads(line)
+                print("  bench.py in the same run (HIP events on the launch stream, timed region): %s, ms_per_step %s" % (
+                    json.dumps(j["kernel_ms"]), j["ms_per_step"]))
 
 for f in find("*counter_collection.csv"):
     agg = defaultdict(lambda: defaultdict(list))
