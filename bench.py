@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: a step's demod kernel runs on a second stream, concurrent with the next step's scan "
                          "(measured: +3 %% value, but the scan kernel then shares the chip: -10 %% on its own time)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the detects are spread over (1: all kernels in order on one stream; "
+                         "2: the two contexts' kernels may overlap at their edges)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                                                       "the N > 1 control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,7 +166,7 @@ def main():
     n_msgs = [0]
     # the kernels go to their own stream, so that the (tiny) RCCL size exchange of step i, issued on
     # torch's current stream, does not queue behind the kernels of step i+1
-    work = torch.cuda.Stream(device=dev)
+    works = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
     def finish(d, timed):
         """fetch + (gather) + sequential host resolve of the detect in flight on context d"""
@@ -198,7 +201,7 @@ def main():
                 finish(x, step > warm)
                 if x is d:
                     break
-        d.detect(iq, stream_byte0=lo, first_block=first_block, nblocks=nblocks, stream=work)
+        d.detect(iq, stream_byte0=lo, first_block=first_block, nblocks=nblocks, stream=works[step % len(works)])
         in_flight.append(d)
     while in_flight:
         finish(in_flight.pop(0), True)
