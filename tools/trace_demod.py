@@ -1,4 +1,7 @@
-"""Per-wavefront timeline of demod_kernel (needs a -DMODES_TRACE build of the library)."""
+"""Per-wavefront timeline of demod_kernel.  Needs a -DMODES_TRACE build of the library:
+    (cd dump1090_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMODES_TRACE -I../../include -shared \
+        -o ../libmodes_gfx950_trace.so modes_gfx950.hip -lpthread)
+    python tools/trace_demod.py dump1090_amd/libmodes_gfx950_trace.so [MiB]"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
