@@ -866,8 +866,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
     __shared__ uint32_t s_list[kDemodThreads];         // preambles awaiting the gate pre-test
     __shared__ uint32_t s_long[2 * kDemodThreads];     // (position, sum over the first 56 pairs) of those that decode as long
     __shared__ uint32_t s_surv[3 * kDemodThreads];     // (position, the two delta sums or kUnknown) of those that go to stage 3
-    __shared__ uint32_t s_wc[3][kDemodWaves];          // per-wavefront counts of one stage-1 block: list, edge, candidates
-    __shared__ uint32_t s_n[2];                        // entries of s_long, s_surv
+    __shared__ uint32_t s_n[2][4];                     // list counters of the current / the next block (see stage 1)
     __shared__ uint32_t s_esyn[112];
     __shared__ unsigned long long s_tot[2];
     __shared__ uint32_t s_flags[3];            // records written by this workgroup, slot-list overflow seen, slots reserved
@@ -878,6 +877,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
     if (threadIdx.x < 112) s_esyn[threadIdx.x] = P.tab.esyn[threadIdx.x];
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
     if (threadIdx.x < 3) s_flags[threadIdx.x] = 0;
+    if (threadIdx.x < 8) s_n[threadIdx.x >> 2][threadIdx.x & 3] = 0;
     __syncthreads();
 #ifdef MODES_TRACE
     const unsigned long long t_lut = wall_clock64();
@@ -891,6 +891,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
     const uint64_t below = (1ull << lane) - 1;
     unsigned long long tot_fwd = 0, tot_cand = 0;       // tot_fwd: per lane of wavefront 0; tot_cand: workgroup-uniform
     RecCursor cur{0, 0};
+    uint32_t blk = 0;                                   // blocks processed so far: parity selects the counter set
 #ifdef MODES_TRACE
     unsigned long long tr_t[4] = {0, 0, 0, 0};          // batch set-up, stage 1, stage 2a, stages 2b + 3
 #define TRACE_ADD(k, since) tr_t[k] += wall_clock64() - (since)
@@ -954,31 +955,27 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
             // pre-test list; the few next to an end of the span go straight to stage 3 (guarded loads).
             const bool whole = samples_inside((int64_t)p - 1, (int64_t)p + 239, lo, hi);
             const uint64_t okb = __ballot(ok), listb = __ballot(ok && whole), edgeb = okb & ~listb;
+            // every wavefront claims its places in the three lists with one LDS atomic each (order within a list is free)
+            uint32_t *cn = s_n[blk & 1];                                     // [0] long, [1] stage-3 queue, [2] pre-test list, [3] candidates
+            uint32_t lbase = 0, ebase = 0, cbase = 0;
             if (lane == 0) {
-                s_wc[0][wave] = (uint32_t)__builtin_popcountll(listb);
-                s_wc[1][wave] = (uint32_t)__builtin_popcountll(edgeb);
-                s_wc[2][wave] = (uint32_t)__builtin_popcountll(okb);
+                if (listb) lbase = atomicAdd(&cn[2], (uint32_t)__builtin_popcountll(listb));
+                if (edgeb) ebase = atomicAdd(&cn[1], (uint32_t)__builtin_popcountll(edgeb));
+                if (okb) cbase = atomicAdd(&cn[3], (uint32_t)__builtin_popcountll(okb));
             }
-            __syncthreads();
-            uint32_t off[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
-#pragma unroll
-            for (int w = 0; w < kDemodWaves; w++) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const uint32_t c = s_wc[k][w];
-                    if (w < wave) off[k] += c;
-                    tot[k] += c;
-                }
-            }
+            lbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lbase);
+            ebase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ebase);
+            cbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)cbase);
             if (ok) {
-                if (whole) s_list[off[0] + (uint32_t)__builtin_popcountll(listb & below)] = p;
-                else       surv_push(s_surv, off[1] + (uint32_t)__builtin_popcountll(edgeb & below), p, kUnknown, kUnknown);
-                if (P.cand_slots) P.cand_slots[cand_base + ncand + off[2] + (uint32_t)__builtin_popcountll(okb & below)] = p;
+                if (whole) s_list[lbase + (uint32_t)__builtin_popcountll(listb & below)] = p;
+                else       surv_push(s_surv, ebase + (uint32_t)__builtin_popcountll(edgeb & below), p, kUnknown, kUnknown);
+                if (P.cand_slots) P.cand_slots[cand_base + ncand + cbase + (uint32_t)__builtin_popcountll(okb & below)] = p;
             }
-            if (tid == 0) { s_n[0] = 0; s_n[1] = tot[1]; }
-            const uint32_t nlist = tot[0];
-            ncand += tot[2];
             __syncthreads();
+            if (tid < 4) s_n[(blk + 1) & 1][tid] = 0;                        // the next block's counters (nobody reads them before two more barriers)
+            const uint32_t nlist = cn[2];
+            ncand += cn[3];
+            blk++;
 
             // ---------------- stage 2 ----------------
             TRACE_ADD(1, ts1);
@@ -1016,16 +1013,16 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
                     const bool pass = mine && !is_long && d56 / 28 >= 2550;  // dump1090.c:1717-1723, short message
                     const bool more = mine && is_long;
                     const uint64_t pb = __ballot(pass), mb = __ballot(more);
-                    uint32_t sbase = 0, lbase = 0;
+                    uint32_t sbase = 0, qbase = 0;
                     if (lane == 0) {
-                        if (pb) sbase = atomicAdd(&s_n[1], (uint32_t)__builtin_popcountll(pb));
-                        if (mb) lbase = atomicAdd(&s_n[0], (uint32_t)__builtin_popcountll(mb));
+                        if (pb) sbase = atomicAdd(&cn[1], (uint32_t)__builtin_popcountll(pb));
+                        if (mb) qbase = atomicAdd(&cn[0], (uint32_t)__builtin_popcountll(mb));
                     }
                     sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sbase);
-                    lbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lbase);
+                    qbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbase);
                     if (pass) surv_push(s_surv, sbase + (uint32_t)__builtin_popcountll(pb & below), pc, d56, kUnknown);
                     if (more) {
-                        const uint32_t k = lbase + (uint32_t)__builtin_popcountll(mb & below);
+                        const uint32_t k = qbase + (uint32_t)__builtin_popcountll(mb & below);
                         s_long[2 * k] = pc;
                         s_long[2 * k + 1] = d56;
                     }
@@ -1035,7 +1032,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
             TRACE_ADD(2, ts2);
             TRACE_T(ts3);
             {   // b: the other 56 pairs of the long ones
-                const uint32_t nlong = s_n[0];
+                const uint32_t nlong = cn[0];
                 for (uint32_t c0 = 0; c0 < nlong; c0 += kGatePerRound) {
                     const uint32_t c = c0 + (uint32_t)grp;
                     const bool gact = c < nlong;
@@ -1053,14 +1050,14 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
                     const bool pass = gact && t == 1 && d112 / 56 >= 2550;   // dump1090.c:1717-1723, long message
                     const uint64_t pb = __ballot(pass);
                     uint32_t sbase = 0;
-                    if (lane == 0 && pb) sbase = atomicAdd(&s_n[1], (uint32_t)__builtin_popcountll(pb));
+                    if (lane == 0 && pb) sbase = atomicAdd(&cn[1], (uint32_t)__builtin_popcountll(pb));
                     sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sbase);
                     if (pass) surv_push(s_surv, sbase + (uint32_t)__builtin_popcountll(pb & below), pc, d56, d112);
                 }
             }
             __syncthreads();
             // ---------------- stage 3 ----------------
-            const uint32_t nsurv = s_n[1];
+            const uint32_t nsurv = cn[1];
             for (uint32_t k = (uint32_t)wave; k < nsurv; k += kDemodWaves) {
                 const int64_t pcs = (int64_t)s_surv[3 * k];
                 const uint32_t k56 = s_surv[3 * k + 1], k112 = s_surv[3 * k + 2];
