@@ -16,6 +16,26 @@ from . import _native as N
 from .demod import shard_blocks, shard_byte_range  # noqa: F401  (re-exported)
 
 
+_SIZE_BUFFERS = {}
+
+
+def _size_buffers(device: str, world: int):
+    """(host size, device size, device sizes of all ranks, host copy of those); on the CPU the pairs coincide."""
+    import torch
+    key = (device, world)
+    if key not in _SIZE_BUFFERS:
+        if device.startswith("cuda"):
+            size_h = torch.zeros(1, dtype=torch.int64).pin_memory()
+            all_h = torch.zeros(world, dtype=torch.int64).pin_memory()
+            _SIZE_BUFFERS[key] = (size_h, torch.zeros(1, dtype=torch.int64, device=device),
+                                  torch.zeros(world, dtype=torch.int64, device=device), all_h)
+        else:
+            size = torch.zeros(1, dtype=torch.int64)
+            every = torch.zeros(world, dtype=torch.int64)
+            _SIZE_BUFFERS[key] = (size, size, every, every)
+    return _SIZE_BUFFERS[key]
+
+
 def gather_arrays(arr: np.ndarray, dst: int = 0, group=None, device="cpu"):
     """Gather variable-length 1-D numpy arrays (any dtype) to rank `dst` in rank order.
     Returns the concatenation on `dst`, None elsewhere.  Two collectives: sizes, then padded data."""
@@ -26,11 +46,18 @@ def gather_arrays(arr: np.ndarray, dst: int = 0, group=None, device="cpu"):
     rank = dist.get_rank(group)
     raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
     # sizes: one collective into one tensor, one device-to-host copy (a .item() per rank costs a
-    # synchronisation each - at 0.25 ms per step that alone would make the host the bottleneck)
-    size = torch.tensor([raw.size], dtype=torch.int64, device=device)
-    all_sizes = torch.empty(world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(all_sizes, size, group=group)
-    sizes = [int(v) for v in all_sizes.tolist()]
+    # synchronisation each - at 0.25 ms per step that alone would make the host the bottleneck);
+    # the small tensors are allocated once per (device, world size)
+    size_h, size_d, all_d, all_h = _size_buffers(str(device), world)
+    size_h[0] = raw.size
+    if size_d is size_h:                                   # CPU tensors (gloo)
+        dist.all_gather_into_tensor(all_d, size_d, group=group)
+    else:
+        size_d.copy_(size_h, non_blocking=True)
+        dist.all_gather_into_tensor(all_d, size_d, group=group)
+        all_h.copy_(all_d, non_blocking=True)
+        torch.cuda.current_stream(size_d.device).synchronize()
+    sizes = [int(v) for v in all_h.tolist()]
     maxb = max(sizes)
     if maxb == 0:
         return arr[:0].copy() if rank == dst else None
