@@ -32,7 +32,7 @@ struct Options {
     bool loop = false, raw = false, onlyaddr = false, stats = false, sbs = false, raw_net = false;
     int fix_errors = 1, check_crc = 1, aggressive = 0;
     int device = 0;
-    uint64_t batch_blocks = 1024;          // 256 MiB of samples per GPU call
+    uint64_t batch_blocks = 512;           // 128 MiB of samples per GPU call (end to end, 8 GiB file: 0.58 s; 1024: 0.67 s)
     int read_threads = 8;                  // parallel pread() slices for regular files
 };
 
@@ -56,7 +56,7 @@ void show_help() {
         "--sbs                    Print the BaseStation lines the reference serves on port 30003.\n"
         "--raw-net                Print the raw lines the reference serves on port 30002.\n"
         "--gpu <ordinal>          HIP device to run on (default: 0).\n"
-        "--batch-blocks <n>       256 KiB buffers per GPU call (default: 1024).\n"
+        "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).\n"
         "--read-threads <n>       Threads reading a regular file (default: 8).\n"
         "--help                   Show this help.\n");
 }
