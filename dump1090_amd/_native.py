@@ -120,7 +120,7 @@ HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_resolve",
                 "modes_format_onlyaddr", "modes_format_verbose", "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
                 "modes_block_count",
                 "modes_tracker_create", "modes_tracker_destroy", "modes_tracker_receive", "modes_tracker_expire",
-                "modes_tracker_count", "modes_tracker_get", "modes_tracker_reference", "modes_format_sbs")
+                "modes_tracker_count", "modes_tracker_get", "modes_tracker_reference", "modes_tracker_json", "modes_format_sbs")
 
 _gpu = None
 _host = None
@@ -198,6 +198,8 @@ def host_lib():
         L.modes_tracker_get.restype = C.POINTER(Aircraft)
         L.modes_tracker_reference.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.modes_tracker_reference.restype = None
+        L.modes_tracker_json.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+        L.modes_tracker_json.restype = C.c_size_t
         L.modes_format_sbs.argtypes = [C.POINTER(ModesMessage), C.POINTER(Aircraft), C.c_char_p, C.c_size_t]
         _host = L
     return _host

@@ -9,6 +9,7 @@
 //   cprNLFunction            dump1090.c:1868-1929   -> cpr_nl (table from 1090-WP-9-14)
 //   interactiveRemoveStaleAircrafts :2203-2224      -> modes_tracker_expire
 //   modesSendSBSOutput       dump1090.c:2397-2448   -> modes_format_sbs
+//   aircraftsToJson          dump1090.c:2505-2552   -> modes_tracker_json
 //
 // The reference keeps a linked list searched linearly and two process globals for the receiver's
 // reference position; here: a hash index over a stable array, everything inside the tracker object.
@@ -218,6 +219,39 @@ uint64_t modes_tracker_expire(modes_tracker *tr, int64_t now_ms, int64_t ttl_ms)
         }
     }
     return gone;
+}
+
+// aircraftsToJson (dump1090.c:2505-2552), the body of the reference's /data.json: the aircraft with a
+// decoded position, newest first.  Returns the length of the text (without the terminating 0); at
+// most cap - 1 characters are stored, so a return value >= cap means "call again with a larger buffer".
+size_t modes_tracker_json(const modes_tracker *tr, int metric, char *buf, size_t cap) {
+    size_t len = 0;
+    auto put = [&](const char *text, size_t n) {
+        for (size_t i = 0; i < n; i++, len++)
+            if (buf && len + 1 < cap) buf[len] = text[i];
+    };
+    put("[\n", 2);
+    bool any = false;
+    if (tr) {
+        for (size_t slot : tr->order) {
+            const modes_aircraft &a = tr->list[slot];
+            if (a.lat == 0 || a.lon == 0) continue;
+            int altitude = a.altitude, speed = a.speed;
+            if (metric) { altitude = (int)(altitude / 3.2828); speed = (int)(speed * 1.852); }   // the reference's constants
+            char line[256];
+            const int n = snprintf(line, sizeof line, "{\"hex\":\"%s\", \"flight\":\"%s\", \"lat\":%f, \"lon\":%f, \"altitude\":%d, "
+                                   "\"track\":%d, \"speed\":%d},\n", a.hexaddr, a.flight, a.lat, a.lon, altitude, a.track, speed);
+            put(line, (size_t)n);
+            any = true;
+        }
+    }
+    if (any) {                                           // the last ",\n" becomes "\n"
+        len -= 2;
+        put("\n", 1);
+    }
+    put("]\n", 2);
+    if (buf && cap) buf[len < cap ? len : cap - 1] = 0;
+    return len;
 }
 
 int modes_format_sbs(const struct modesMessage *mm, const modes_aircraft *a, char *buf, size_t cap) {

@@ -206,6 +206,10 @@ uint64_t modes_tracker_count(const modes_tracker *tr);
 const modes_aircraft *modes_tracker_get(const modes_tracker *tr, uint64_t i);   /* newest aircraft first */
 /* Modes.ref_lat / ref_lon / ref_count (dump1090.c:205-206). */
 void modes_tracker_reference(const modes_tracker *tr, double *lat, double *lon, int *count);
+/* aircraftsToJson() (dump1090.c:2505-2552), the body the reference serves as /data.json: every
+ * aircraft with a decoded position, newest first; metric = Modes.metric.  Returns the length of
+ * the text; at most cap - 1 characters (and a terminating 0) are stored. */
+size_t modes_tracker_json(const modes_tracker *tr, int metric, char *buf, size_t cap);
 /* modesSendSBSOutput() (dump1090.c:2397-2448): the line for `mm`, '\n'-terminated, or 0 when this
  * message type has no SBS line.  `a` = what modes_tracker_receive returned for this message (needed
  * for MSG,3 positions and MSG,4 speed / track).  256 bytes always suffice. */

@@ -11,6 +11,7 @@ unknown aircraft, single- and double-bit errors - feeds it to the compiled refer
     frames_verbose[_<tag>].txt   its stdout: the verbose dump of every message it displays
     frames_sbs[_<tag>].txt       what it wrote to a client of its BaseStation port
     frames_rawnet[_<tag>].txt    what it wrote to a client of its raw-output port
+    frames_aircraft[_<tag>].json the aircraft table it then served as /data.json
 so that the host decoder, the whitelist, the tracker and the formatters are pinned on inputs the one
 captured fixture (modes1.bin: a single aircraft) never produces.
 """
@@ -261,25 +262,39 @@ def run_reference(lines, flags):
         time.sleep(0.004)
     time.sleep(1.0)
     src.close()
-    time.sleep(0.5)
+    time.sleep(0.3)
+    # the aircraft table as the web map polls it (handleHTTPRequest -> aircraftsToJson, dump1090.c:2505-2552)
+    web = socket.create_connection(("127.0.0.1", PORTS["http"]), timeout=5)
+    web.sendall(b"GET /data.json HTTP/1.0\r\n\r\n")
+    web.settimeout(5)
+    reply = b""
+    while True:
+        chunk = web.recv(1 << 16)
+        if not chunk:
+            break
+        reply += chunk
+    web.close()
+    got["json"] = reply.split(b"\r\n\r\n", 1)[1]
+    time.sleep(0.2)
     stop.set()
     proc.terminate()
     proc.wait()
     for t in threads:
         t.join()
     os.close(master)
-    return got["out"].decode().replace("\r\n", "\n"), got["sbs"].decode(), got["ro"].decode()
+    return got["out"].decode().replace("\r\n", "\n"), got["sbs"].decode(), got["ro"].decode(), got["json"].decode()
 
 
 def main():
     frames = script(20260922)
     lines = ["*%s;\n" % f.hex() for f in frames]
     for tag, flags in (("", []), ("_aggressive", ["--aggressive"]), ("_nofix", ["--no-fix"])):
-        verbose, sbs, ro = run_reference(lines, flags)
+        verbose, sbs, ro, table = run_reference(lines, flags)
         open(os.path.join(HERE, "frames_in.txt"), "w").write("".join(lines))
         open(os.path.join(HERE, "frames_verbose%s.txt" % tag), "w").write(verbose)
         open(os.path.join(HERE, "frames_sbs%s.txt" % tag), "w").write(sbs)
         open(os.path.join(HERE, "frames_rawnet%s.txt" % tag), "w").write(ro)
+        open(os.path.join(HERE, "frames_aircraft%s.json" % tag), "w").write(table)
         print(tag or "default", len(lines), "frames ->", ro.count("\n"), "displayed,", sbs.count("\n"), "SBS lines,",
               verbose.count("\n"), "lines of verbose text")
 

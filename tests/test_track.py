@@ -139,14 +139,17 @@ def replay_frames(flagset):
         verbose.append(vbuf.value.decode())
         lib.modes_format_raw_net(C.byref(mm), lbuf)
         rawnet.append(lbuf.value.decode())
+    n = lib.modes_tracker_json(tr, 0, None, 0)                           # length first, then the text
+    jbuf = C.create_string_buffer(n + 1)
+    assert lib.modes_tracker_json(tr, 0, jbuf, n + 1) == n
     lib.modes_tracker_destroy(tr)
     lib.modes_host_destroy(h)
-    return "".join(verbose), "".join(sbs), "".join(rawnet)
+    return "".join(verbose), "".join(sbs), "".join(rawnet), jbuf.value.decode()
 
 
 @pytest.mark.parametrize("flagset,tag", [("default", ""), ("aggressive", "_aggressive"), ("nofix", "_nofix")])
 def test_scripted_frames_match_reference(flagset, tag):
-    verbose, sbs, rawnet = replay_frames(flagset)
+    verbose, sbs, rawnet, table = replay_frames(flagset)
     want_raw = golden_text("frames_rawnet%s.txt" % tag)
     assert rawnet.count("\n") == want_raw.count("\n") > 1300
     assert rawnet == want_raw                                  # which frames are displayed, repaired bytes included
@@ -161,3 +164,15 @@ def test_scripted_frames_match_reference(flagset, tag):
     for k, (g, w) in enumerate(zip(got_v, want_v)):
         assert g == w, "verbose line %d" % k
     assert len(got_v) == len(want_v)
+    # the aircraft table the reference then served as /data.json (aircraftsToJson, dump1090.c:2505-2552)
+    assert table == golden_text("frames_aircraft%s.json" % tag)
+    assert table.count("\"hex\"") >= 10
+
+
+def test_tracker_json_of_an_empty_table_and_short_buffers():
+    lib = N.host_lib()
+    tr = lib.modes_tracker_create()
+    buf = C.create_string_buffer(64)
+    assert lib.modes_tracker_json(tr, 0, buf, 64) == 4 and buf.value == b"[\n]\n"
+    assert lib.modes_tracker_json(tr, 1, buf, 3) == 4 and buf.value == b"[\n"        # truncated, still terminated
+    lib.modes_tracker_destroy(tr)
