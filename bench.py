@@ -92,7 +92,9 @@ def main():
     ap.add_argument("--cpu-mib", type=int, default=1024, help="MiB of the workload timed on the CPU baseline")
     ap.add_argument("--run-chunks", type=int, default=0)
     ap.add_argument("--scan-variant", type=int, default=0, help="0 = production scan kernel, 1 = fused single-pass scan")
-    ap.add_argument("--depth", type=int, default=2, help="detect calls in flight (contexts used alternately)")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="detect calls in flight (contexts used alternately); default 2, 3 with several ranks "
+                         "(the record gather adds host time per step: one more step of slack)")
     ap.add_argument("--settle", type=int, default=80,
                     help="extra untimed steps before the W warmup steps: the chip's power management needs ~40 "
                          "back-to-back steps (13 ms) to settle - the scan kernel runs 0.22, 0.27, 0.21 ms at steps "
@@ -148,7 +150,7 @@ def main():
     # and resolved, so the GPU never waits for the host (the C host double-buffers the same way).
     # Every step still does all of its work; K steps = K detects + K fetches + K resolves.
     demods = [Demodulator(device=local, fix=False, run_chunks=args.run_chunks, scan_variant=args.scan_variant,
-                          overlap=bool(args.overlap)) for _ in range(max(1, args.depth))]
+                          overlap=bool(args.overlap)) for _ in range(args.depth if args.depth > 0 else (2 if world == 1 else 3))]
     demod = demods[0]
     iq = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
     demod.synth_noise(iq, first_byte=lo, seed=20260922, sigma_q16=941)
