@@ -23,7 +23,8 @@
 // scan_fused_kernel (scan_variant 1) is the single-pass first version, kept as an
 // independent implementation the tests compare the production kernel with.
 //
-// No MFMA (integer scan, HBM-bound), no CUDA compatibility layer, wave64 only.
+// No MFMA (integer scan: the roofline is HBM, the limiter in practice VALU issue - DESIGN.md 3.1),
+// no CUDA compatibility layer, wave64 only.
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
