@@ -114,7 +114,7 @@ GPU_SYMBOLS = ("modes_gpu_create", "modes_gpu_destroy", "modes_gpu_last_error", 
                "modes_gpu_detect", "modes_gpu_fetch", "modes_gpu_demod_host", "modes_gpu_submit_host",
                "modes_gpu_host_alloc", "modes_gpu_host_free", "modes_gpu_compute_power",
                "modes_gpu_synth_noise", "modes_gpu_fill", "modes_gpu_abi_version")
-HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_resolve", "modes_host_resolve_to_array",
+HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_set_time", "modes_host_resolve", "modes_host_resolve_to_array",
                 "modes_host_wants",
                 "modes_host_get_stats", "modes_host_decode", "modes_host_decode_frame", "modes_format_raw", "modes_format_raw_net",
                 "modes_format_onlyaddr", "modes_format_verbose", "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
@@ -161,6 +161,8 @@ def host_lib():
         L.modes_host_create.restype = C.c_void_p
         L.modes_host_destroy.argtypes = [C.c_void_p]
         L.modes_host_destroy.restype = None
+        L.modes_host_set_time.argtypes = [C.c_void_p, C.c_int64]
+        L.modes_host_set_time.restype = None
         L.modes_host_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, SINK_FN,
                                          C.c_void_p]
         L.modes_host_resolve.restype = C.c_uint64

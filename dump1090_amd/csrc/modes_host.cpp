@@ -18,6 +18,7 @@
 namespace {
 
 constexpr uint32_t kIcaoSlots = 1024;                  // MODES_ICAO_CACHE_LEN, :65
+constexpr int64_t kIcaoTtl = 60;                       // MODES_ICAO_CACHE_TTL, :66 (seconds)
 
 // ICAOCacheHashAddress, :898-905.
 inline uint32_t icao_slot(uint32_t a) {
@@ -27,28 +28,56 @@ inline uint32_t icao_slot(uint32_t a) {
     return a & (kIcaoSlots - 1);
 }
 
+// x^(111-p) mod G for the 112 frame positions, and the remainders of the 256 byte values (byte-wise long division)
+struct Tables {
+    uint32_t esyn[112];
+    uint32_t byte_rem[256];
+    Tables() {
+        for (int p = 0; p < 112; p++) esyn[p] = modes_bit_syndrome(p);
+        for (uint32_t b = 0; b < 256; b++) {
+            uint32_t r = b << 16;                                   // b * x^16, then 8 more shifts: b * x^24 mod G
+            for (int t = 0; t < 8; t++) {
+                r <<= 1;
+                if (r & 0x1000000u) r ^= MODES_CRC_POLY;
+            }
+            byte_rem[b] = r & 0xFFFFFFu;
+        }
+    }
+};
+const Tables kTables;
+
+// modes_syndrome (modes_core.h) a byte at a time: r <- (r * x^8 + byte) mod G
+inline uint32_t syndrome_bytes(const unsigned char *msg, int nbytes) {
+    uint32_t r = 0;
+    for (int b = 0; b < nbytes; b++) r = ((r << 8) & 0xFFFFFFu) ^ kTables.byte_rem[r >> 16] ^ msg[b];
+    return r;
+}
+
 }  // namespace
 
 struct modes_host {
     modes_host_config cfg{};
     modes_host_stats st{};
     // Recently-seen ICAO addresses (:896-925).  The reference stamps entries with time(NULL) and
-    // expires them after 60 s of WALL CLOCK; a file run on the GPU finishes in milliseconds, so
-    // within one run entries never expire - the same semantics the parity oracle gets from the
-    // constant-clock interposer (DESIGN.md "ICAO cache TTL").
+    // expires them after 60 s of WALL CLOCK.  The clock here is the caller's (modes_host_set_time): a
+    // file run on the GPU finishes in milliseconds and never advances it, so nothing expires - the
+    // semantics the parity oracle gets from the constant-clock interposer; a host on a live pipe
+    // (--ifile -, --loop) advances it once per batch and gets the reference's 60 s.
     uint32_t icao[kIcaoSlots] = {};
+    int64_t icao_seen[kIcaoSlots] = {};   // caller's clock (modes_host_set_time) when the address was last validated
+    int64_t now_s = 0;                    // never advanced by a file run: nothing expires (the default)
     bool have_candidates = false;
 };
 
 extern "C" {
 
-uint32_t modes_checksum(const unsigned char *msg, int bits) { return modes_syndrome(msg, bits / 8); }
+uint32_t modes_checksum(const unsigned char *msg, int bits) { return syndrome_bytes(msg, bits / 8); }
 
 // modesComputeCRC (:703-719) = parity of the data bits only = syndrome XOR received parity.
 uint32_t modes_compute_crc(const unsigned char *msg, int bits) {
     const int n = bits / 8;
     const uint32_t rx = ((uint32_t)msg[n - 3] << 16) | ((uint32_t)msg[n - 2] << 8) | msg[n - 1];
-    return modes_syndrome(msg, n) ^ rx;
+    return syndrome_bytes(msg, n) ^ rx;
 }
 
 int modes_message_len_by_type(int type) { return modes_len_by_df(type); }
@@ -64,6 +93,8 @@ modes_host *modes_host_create(const modes_host_config *cfg) {
 
 void modes_host_destroy(modes_host *h) { delete h; }
 
+void modes_host_set_time(modes_host *h, int64_t now_seconds) { if (h) h->now_s = now_seconds; }
+
 void modes_host_get_stats(const modes_host *h, modes_host_stats *out) {
     *out = h->st;
     if (!h->have_candidates) out->valid_preamble = -1;
@@ -73,8 +104,15 @@ int modes_host_wants(const modes_host *h, const struct modesMessage *mm) {
     return h->cfg.check_crc == 0 || mm->crcok;                                    // :1803
 }
 
-static void icao_remember(modes_host *h, uint32_t addr) { h->icao[icao_slot(addr)] = addr; }           // :910
-static bool icao_known(const modes_host *h, uint32_t addr) { return addr != 0 && h->icao[icao_slot(addr)] == addr; }  // :919
+static void icao_remember(modes_host *h, uint32_t addr) {                                             // :910-914
+    const uint32_t s = icao_slot(addr);
+    h->icao[s] = addr;
+    h->icao_seen[s] = h->now_s;
+}
+static bool icao_known(const modes_host *h, uint32_t addr) {                                            // :919-925
+    const uint32_t s = icao_slot(addr);
+    return addr != 0 && h->icao[s] == addr && h->now_s - h->icao_seen[s] <= kIcaoTtl;
+}
 
 // decodeAC13Field, :988-1012.
 static int decode_ac13(const unsigned char *msg, int *unit) {
@@ -105,18 +143,13 @@ static int decode_ac12(const unsigned char *msg, int *unit) {
 // dump1090.c:2472-2502, hands bytes straight to decodeModesMessage): syndrome and repair lookup on
 // the host with the same helpers the device uses, then the common decode.
 void modes_host_decode_frame(modes_host *h, const unsigned char *frame, struct modesMessage *mm) {
-    struct Table {
-        uint32_t esyn[112];
-        Table() { for (int p = 0; p < 112; p++) esyn[p] = modes_bit_syndrome(p); }
-    };
-    static const Table table;                        // initialised once, thread-safe
-    const uint32_t *esyn = table.esyn;
+    const uint32_t *esyn = kTables.esyn;
     modes_attempt att;
     memset(&att, 0, sizeof att);
     memcpy(att.msg, frame, MODES_LONG_MSG_BYTES);
     const int bits = modes_len_by_df(frame[0] >> 3);
     att.gate_ok = 1;
-    att.syndrome = modes_syndrome(att.msg, bits / 8);
+    att.syndrome = syndrome_bytes(att.msg, bits / 8);
     att.nfix = (uint8_t)modes_find_fix(att.syndrome, bits, h->cfg.fix_errors ? (h->cfg.aggressive ? 2 : 1) : 0, esyn, att.fixpos);
     modes_host_decode(h, &att, mm);
 }
@@ -141,8 +174,12 @@ void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMess
         const int maxfix = h->cfg.aggressive ? 2 : 1;
         const int nfixed = att->nfix <= maxfix ? att->nfix : 0;
         if (nfixed > 0) {
-            for (int i = 0; i < nfixed; i++) msg[att->fixpos[i] >> 3] ^= (unsigned char)(0x80u >> (att->fixpos[i] & 7));
-            mm->crc = modes_checksum(msg, mm->msgbits);
+            // the syndrome is linear in the message bits: flipping message bit k (frame position k + 112 - msgbits)
+            // XORs that position's single-bit syndrome in - same value as modesChecksum() of the repaired frame (:1119)
+            for (int i = 0; i < nfixed; i++) {
+                msg[att->fixpos[i] >> 3] ^= (unsigned char)(0x80u >> (att->fixpos[i] & 7));
+                mm->crc ^= kTables.esyn[att->fixpos[i] + 112 - mm->msgbits];
+            }
             mm->crcok = (mm->crc == 0);
             mm->errorbit = att->fixpos[0];
             if (nfixed == 1) h->st.single_bit_fix++; else h->st.two_bits_fix++;  // :1122-1126
@@ -170,7 +207,9 @@ void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMess
         const int t = mm->msgtype;
         if (t == 0 || t == 4 || t == 5 || t == 16 || t == 20 || t == 21 || t == 24) {
             const int last = mm->msgbits / 8 - 1;
-            const uint32_t crc = modes_compute_crc(msg, mm->msgbits);
+            // modesComputeCRC (:703-719) = syndrome XOR received parity; these types are never repaired, so the
+            // syndrome is the one the GPU computed
+            const uint32_t crc = att->syndrome ^ (((uint32_t)msg[last - 2] << 16) | ((uint32_t)msg[last - 1] << 8) | msg[last]);
             const uint32_t b0 = msg[last] ^ (crc & 0xff), b1 = msg[last - 1] ^ ((crc >> 8) & 0xff),
                            b2 = msg[last - 2] ^ ((crc >> 16) & 0xff);
             if (icao_known(h, b0 | (b1 << 8) | (b2 << 16))) {

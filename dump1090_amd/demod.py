@@ -100,6 +100,10 @@ class HostResolver:
 
     __del__ = close
 
+    def set_time(self, now_seconds: int):
+        """Advance the clock behind the ICAO whitelist's 60 s TTL (dump1090.c:913,924); a file run never does."""
+        self._lib.modes_host_set_time(self._h, int(now_seconds))
+
     def resolve(self, records: np.ndarray, candidates: np.ndarray | None = None) -> list[Message]:
         """Records (RECORD_DTYPE, ascending (block, j)) -> messages that pass the display filter."""
         records = np.ascontiguousarray(records, dtype=N.RECORD_DTYPE)

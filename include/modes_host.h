@@ -113,6 +113,10 @@ typedef struct modes_host modes_host;   /* resolve state: config, ICAO cache, st
 
 modes_host *modes_host_create(const modes_host_config *cfg);
 void        modes_host_destroy(modes_host *h);
+/* The clock behind the ICAO whitelist's 60 s TTL (the reference reads time(NULL), dump1090.c:913,924).
+ * Never called: the clock stands still and nothing expires inside a run (file input; what the
+ * parity tests pin).  A host on a live stream calls it with its wall clock before every resolve. */
+void        modes_host_set_time(modes_host *h, int64_t now_seconds);
 
 /* Sequential in-order resolve of one batch of records (ascending (block, j), as
  * modes_gpu_fetch returns them).  `candidates` (framed g, ascending) is optional:

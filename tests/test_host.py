@@ -124,3 +124,28 @@ def test_raw_net_line_is_the_raw_line_in_upper_case(streams):
         lib.modes_format_raw_net(C.byref(out[i].mm), b)
         assert b.value == a.value.upper() and b.value != a.value or a.value.upper() == a.value
     lib.modes_host_destroy(h)
+
+
+def test_icao_whitelist_ttl_follows_the_callers_clock(streams, golden):
+    """dump1090.c:913,924: whitelist entries die after 60 s of the caller's clock.  A file run never advances
+    it (nothing expires: the goldens above).  Advanced by 100 s per record, every entry is expired by the
+    time it is looked up - the reference run under a clock that advances 100 s per time() call prints
+    223 lines, md5 9069aad8... (hard part 3: every AP-validated message is lost)."""
+    import hashlib
+    data = streams["modes1"]
+    recs, _ = oracle_records(data, 1)
+    r = HostResolver()
+    got = []
+    for i in range(recs.size):
+        r.set_time(100 * i)
+        got += r.resolve(recs[i:i + 1], None)
+    text = raw_text(got)
+    assert text.count("\n") == 223 and hashlib.md5(text.encode()).hexdigest().startswith("9069aad8")
+    r.close()
+    r = HostResolver()
+    kept = []
+    for i in range(recs.size):
+        r.set_time(i // 100)                                                # well inside the TTL: nothing expires
+        kept += r.resolve(recs[i:i + 1], None)
+    assert raw_text(kept) == golden["modes1"]["raw"]["default"]["text"]
+    r.close()
