@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
 """bench.py - IQ Msamples/s demodulated on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of HBM-resident synthetic input:
-scan kernel + demod kernel + record fetch (+ gather of records to rank 0 when N > 1) + the
-sequential host resolve on rank 0.  Workload = BASELINE.json configs[1]: 1 GiB of synthetic
-uint8 I/Q in 2 Msps file format (sigma = 3 integer noise, tests/synth.py), --no-fix, PER GPU
-(weak scaling: the stream is sharded into per-GPU buffer ranges, each rank's shard is 1 GiB).
+A "step" is one pass of the hot path over one batch of HBM-resident synthetic input: scan kernel + demod
+kernel + order kernel + record fetch (+ gather of the device-resident record lists to rank 0 over RCCL when
+N > 1) + the sequential host resolve and --raw formatting on rank 0.
+
+HEADLINE (the JSON line's metric/value/roofline): BASELINE.json configs[1]: 1 GiB of synthetic uint8 I/Q in
+2 Msps file format (sigma = 3 integer noise, tests/synth.py), --no-fix, PER GPU (weak scaling: the stream is
+sharded into per-GPU buffer ranges, each rank's shard is 1 GiB).
+
+SECOND LEG (object "frames" in the same line): BASELINE.json configs[2] at N = 1 / configs[3] at N = 8: 8 GiB
+per GPU of the same noise with DF11/DF17 frames at known offsets (about one per 65,536 samples, 10 % with a
+flipped bit, some on the buffer seams), --fix.  The record lists are non-empty here: at N > 1 the RCCL gather
+carries real payload, and rank 0 checks the gathered listing against the analytic expectation (every testable
+frame, in stream order) before the leg's numbers are reported.  `--workload frames` makes it the only leg.
+
+THIRD LEG (object "end_to_end", N = 1): the headline workload again, but starting in pinned HOST memory:
+modes_gpu_submit_host (H2D over PCIe + kernels) in rotating contexts - the PCIe-inclusive rate, never `value`.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Before the W warmup steps the bench runs `--settle` (80) more untimed steps: the chip's power management
-needs ~40 back-to-back steps to reach its sustained clocks (tools/scan_steps.py: the scan kernel takes 0.22,
-0.27 and 0.21 ms at steps 1, 10 and 60 of an uninterrupted run); the K timed steps are therefore the
-sustained rate, which is what a stream of many batches sees.
+Before the W warmup steps the headline leg runs `--settle` (80) more untimed steps: the chip's power management
+needs ~40 back-to-back steps to reach its sustained clocks (tools/scan_steps.py); the K timed steps are
+therefore the sustained rate, which is what a stream of many batches sees.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the scan kernel (the only stage that reads
-every sample): algorithmic bytes = 2 per sample, duration = HIP events recorded around the kernel
-on its launch stream inside libmodes_gfx950.so.  `cpu_baseline` (N == 1 only) times the compiled
-reference (oracle/_ref) - or the C restatement if that binary is absent - on the host.
+Prints ONE JSON line on rank 0.  `roofline` is for the scan kernel (the only stage that reads every sample):
+algorithmic bytes = 2 per sample, duration = HIP events recorded around the kernel on its launch stream inside
+libmodes_gfx950.so.  `cpu_baseline` (N == 1 only) times the compiled reference (oracle/_ref) - or the C
+restatement if that binary is absent - on the host.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -34,19 +45,34 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+KERNEL_SOURCES = ("dump1090_amd/csrc/modes_gfx950.hip", "dump1090_amd/csrc/modes_core.h")
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(mib):
-    """HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/traffic_latest.json,
-    written by tools/profile.sh on this same default workload); None for any other workload."""
+    """(HBM bytes per scan launch, note) from the committed rocprofv3 PMC passes (profiles/traffic_latest.json,
+    written by tools/profile.sh on this same default workload).  The file is stamped with the hash of the kernel
+    sources it was measured on: a different hash means the counters are stale and `traffic` is reported as null."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if mib != 1024 or not os.path.exists(path):
-        return None
+        return None, "no PMC pass for this workload"
     try:
         with open(path) as f:
-            return int(json.load(f)["scan_kernel"]["hbm_read_bytes_per_launch"])
+            t = json.load(f)
+        if t.get("kernel_source_sha256_16") != kernel_source_hash():
+            return None, "stale: PMC pass was taken on kernel sources %s, these are %s" % (
+                t.get("kernel_source_sha256_16"), kernel_source_hash())
+        return int(t["scan_kernel"]["hbm_read_bytes_per_launch"]), "rocprofv3 FETCH_SIZE pass %s (%s)" % (
+            t.get("tag", "?"), t.get("kernel_source_sha256_16"))
     except (KeyError, ValueError):
-        return None
+        return None, "unreadable"
 
 
 def cpu_baseline(iq, nbytes_sample):
@@ -83,37 +109,98 @@ def cpu_baseline(iq, nbytes_sample):
                 what, dt, lines, os.cpu_count() or 0)}
 
 
+def build_frames_shard(torch, dev, total_blocks, lo, hi, seed):
+    """Bytes [lo, hi) of the configs[2]/[3] stream (tests/synth.py:config3_stream over total_blocks buffers) in HBM,
+    built from this rank's frames only.  -> (tensor, [(sample, clean frame bytes)] of the frames this rank's
+    buffers can decode, ascending)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    from dump1090_amd import Demodulator
+    st = synth.config3_stream(seed, total_blocks, only_samples=(lo // 2, (hi + 1) // 2))
+    d = Demodulator(device=dev.index)
+    iq = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
+    d.synth_noise(iq, lo, seed=st.seed, sigma_q16=st.sigma_q16)
+    first, data = st.patches()
+    if len(first):
+        idx = torch.from_numpy(first).to(dev)[:, None] + torch.arange(data.shape[1], device=dev)[None, :]
+        val = torch.from_numpy(data).to(dev)
+        keep = (idx >= lo) & (idx < hi)
+        iq[(idx[keep] - lo)] = val[keep]
+    if hi == st.nbytes:
+        d.fill(iq[-480:], 127)
+    torch.cuda.synchronize(dev)
+    d.close()
+    return iq, st
+
+
+def frames_expectation(st, first_block, nblocks):
+    """The lines this rank's buffers must contribute: every frame whose preamble offset lies in one of the rank's
+    buffers at a tested offset (j < 131070, dump1090.c:1593), in stream order."""
+    import synth
+    want = []
+    for sample, fb, amp, phase, smear in st.placements:
+        g = sample + synth.CARRY
+        blk, j = divmod(g, synth.BLOCK_STRIDE)
+        if first_block <= blk < first_block + nblocks and j < 131070:
+            want.append("*" + st.clean[sample].hex() + ";")
+    return want
+
+
+def check_listing(listing: bytes, expected: list[str]):
+    """Rank 0: the gathered, resolved --raw listing against the analytic expectation.  Raises on failure."""
+    lines = listing.decode().split()
+    listed = set(lines)
+    missing = sum(1 for e in expected if e not in listed)
+    assert missing <= len(expected) // 200, "%d of %d injected frames are not in the listing" % (missing, len(expected))
+    assert 0.99 * len(expected) <= len(lines) <= 1.02 * len(expected) + 64, "%d lines for %d frames" % (len(lines), len(expected))
+    # stream order: the expected frames that were listed appear in the order of their offsets
+    pos, at = {}, 0
+    for i, ln in enumerate(lines):
+        pos.setdefault(ln, i)
+    for e in expected:
+        p = pos.get(e)
+        if p is None:
+            continue
+        assert p >= at, "the listing is not in stream order around %s" % e
+        at = p
+    return {"lines": len(lines), "expected_frames": len(expected), "missing": missing,
+            "md5": hashlib.md5(listing).hexdigest()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mib", type=int, default=1024, help="MiB of I/Q per GPU (default: the 1 GiB workload)")
+    ap.add_argument("--workload", default="all", choices=("all", "noise", "frames"),
+                    help="noise: the headline leg only; frames: the configs[2]/[3] leg only (its numbers then fill the headline "
+                         "fields); all (default): both, frames as a secondary object")
+    ap.add_argument("--mib", type=int, default=1024, help="MiB of I/Q per GPU of the noise leg (default: the 1 GiB workload)")
+    ap.add_argument("--frames-mib", type=int, default=8192, help="MiB of I/Q per GPU of the frames leg (default: 8 GiB)")
+    ap.add_argument("--frames-steps", type=int, default=6)
     ap.add_argument("--cpu-mib", type=int, default=1024, help="MiB of the workload timed on the CPU baseline")
     ap.add_argument("--run-chunks", type=int, default=0)
     ap.add_argument("--scan-variant", type=int, default=0, help="0 = production scan kernel, 1 = fused single-pass scan")
-    ap.add_argument("--depth", type=int, default=0,
-                    help="detect calls in flight (contexts used alternately); default 2, 3 with several ranks "
-                         "(the record gather adds host time per step: one more step of slack)")
+    ap.add_argument("--depth", type=int, default=3, help="detect calls in flight (contexts used in rotation)")
     ap.add_argument("--settle", type=int, default=80,
                     help="extra untimed steps before the W warmup steps: the chip's power management needs ~40 "
                          "back-to-back steps (13 ms) to settle - the scan kernel runs 0.22, 0.27, 0.21 ms at steps "
                          "1, 10, 60 of a sustained run (tools/scan_steps.py)")
-    ap.add_argument("--overlap", type=int, default=0,
-                    help="1: a step's demod kernel runs on a second stream, concurrent with the next step's scan "
-                         "(measured: +3 %% value, but the scan kernel then shares the chip: -10 %% on its own time)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the detects are spread over (1: all kernels in order on one stream; "
-                         "2: the two contexts' kernels may overlap at their edges)")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="1 (default): a step's demod and order kernels run on the context's own stream, concurrent with "
+                         "the next step's scan (a demod workgroup fits on a CU next to the scan's); 0: everything in order "
+                         "on one stream (per-kernel durations then add up to the step)")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the scans are spread over")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                                                       "the N > 1 control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from dump1090_amd import Demodulator, HostResolver, block_count, shard_blocks, shard_byte_range
-    from dump1090_amd.distributed import gather_records
+    from dump1090_amd import Demodulator, block_count, shard_blocks, shard_byte_range
+    from dump1090_amd.pipeline import run_steps, split_calls
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -136,115 +223,186 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    # the global stream = world x (--mib) MiB; this rank demodulates its contiguous buffer range and
-    # holds exactly the bytes that range needs (its buffers + the 476-byte carry in front).
-    per_gpu = args.mib << 20
-    total = per_gpu * world
-    nblocks_total = block_count(total)
-    first_block, nblocks = shard_blocks(nblocks_total - 1, world, rank)     # the EOF buffer goes to the last rank
-    if rank == world - 1:
-        nblocks += 1
-    lo, hi = shard_byte_range(first_block, nblocks, total)
+    def shard(total_bytes):
+        """this rank's contiguous buffer range of a world x per-GPU stream, and the bytes it needs (476-byte carry in front)"""
+        nblocks_total = block_count(total_bytes)
+        first_block, nblocks = shard_blocks(nblocks_total - 1, world, rank)   # the EOF buffer goes to the last rank
+        if rank == world - 1:
+            nblocks += 1
+        lo, hi = shard_byte_range(first_block, nblocks, total_bytes)
+        return first_block, nblocks, lo, hi
 
-    # Two contexts, used alternately: step i+1's kernels are queued before step i's records are fetched
-    # and resolved, so the GPU never waits for the host (the C host double-buffers the same way).
-    # Every step still does all of its work; K steps = K detects + K fetches + K resolves.
-    demods = [Demodulator(device=local, fix=False, run_chunks=args.run_chunks, scan_variant=args.scan_variant,
-                          overlap=bool(args.overlap)) for _ in range(args.depth if args.depth > 0 else (2 if world == 1 else 3))]
-    demod = demods[0]
-    iq = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
-    demod.synth_noise(iq, first_byte=lo, seed=20260922, sigma_q16=941)
-    if hi == total:
-        demod.fill(iq[-480:], 127)                  # oracle-safe tail
-    torch.cuda.synchronize(dev)
-
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    scan_ms, demod_ms, n_pre, n_fwd = [], [], 0, 0
-    n_msgs = [0]
-    # the kernels go to their own stream, so that the (tiny) RCCL size exchange of step i, issued on
-    # torch's current stream, does not queue behind the kernels of step i+1
     works = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
-    def finish(d, timed):
-        """fetch + (gather) + sequential host resolve of the detect in flight on context d"""
-        nonlocal n_pre, n_fwd
-        recs, cands, info = d.fetch()
+    def leg(iq, lo, calls, flags, steps, warm, cap_records):
+        """K timed steps over this rank's HBM-resident shard (dump1090_amd/pipeline.py)"""
+        def make():
+            return Demodulator(device=local, run_chunks=args.run_chunks, scan_variant=args.scan_variant,
+                               overlap=bool(args.overlap), max_records=cap_records if world > 1 else 0, **flags)
+        return run_steps(make, iq, lo, calls, flags, steps, warm, args.depth, world=world, rank=rank, dist=dist,
+                         coll_device=coll_dev, cap_records=cap_records, streams=works,
+                         device_sync=lambda: torch.cuda.synchronize(dev))
+
+    line = {}
+    noise = None
+    iq_noise = None
+    if args.workload in ("all", "noise"):
+        per_gpu = args.mib << 20
+        total = per_gpu * world
+        first_block, nblocks, lo, hi = shard(total)
+        gen = Demodulator(device=local, fix=False)
+        iq_noise = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
+        gen.synth_noise(iq_noise, first_byte=lo, seed=20260922, sigma_q16=941)
+        if hi == total:
+            gen.fill(iq_noise[-480:], 127)              # oracle-safe tail (SURVEY.md 3.4)
+        torch.cuda.synchronize(dev)
+        gen.close()
+        calls = split_calls(first_block, nblocks, 1, lo, total)
+        noise = leg(iq_noise, lo, calls, dict(fix=False, aggressive=False), args.steps, args.settle + args.warmup, 1 << 16)
+        noise.update(total=total, span=hi - lo, per_gpu=per_gpu)
+
+    frames = None
+    if args.workload in ("all", "frames"):
+        per_gpu = args.frames_mib << 20
+        total = per_gpu * world
+        first_block, nblocks, lo, hi = shard(total)
+        iq_f, st = build_frames_shard(torch, dev, total // 262144, lo, hi, seed=3 if world == 1 else 4)
+        mine = frames_expectation(st, first_block, nblocks)
+        # one detect call holds at most 8 GiB - 64 KiB of samples: an 8 GiB shard (+ carry, + the EOF buffer on the last
+        # rank) is two calls per step, the same number on every rank (the collectives pair up)
+        max_blocks = (total // 262144) // world + 1
+        calls = split_calls(first_block, nblocks, (max_blocks + 32766) // 32767, lo, total)
+        fsteps = args.frames_steps if args.workload == "all" else args.steps
+        frames = leg(iq_f, lo, calls, dict(fix=True, aggressive=False), fsteps, 6, 1 << 17)
+        frames.update(total=total, span=hi - lo, per_gpu=per_gpu)
+        expected = mine
         if world > 1:
-            recs, cands = gather_records(recs, cands, dst=0, device=coll_dev)
+            parts = [None] * world if rank == 0 else None
+            dist.gather_object(mine, parts, dst=0)
+            if rank == 0:
+                expected = [e for p in parts for e in p]
         if rank == 0:
-            res = HostResolver(fix=False)
-            m = res.count(recs, cands)
-            res.close()
-            if timed:
-                n_msgs[0] += m
-        if timed:
-            scan_ms.append(info["scan_ms"])
-            demod_ms.append(info["demod_ms"])
-        n_pre, n_fwd = info["n_preambles"], info.get("n_forwarded", 0)
+            frames["check"] = check_listing(frames["listing"], expected)
+            gold = os.path.join(ROOT, "tests", "golden", "config2_listing.json")
+            if world == 1 and args.frames_mib == 8192 and os.path.exists(gold):
+                # the reference binary's own listing of this very stream (recorded by tests/test_gpu_fullsize.py)
+                with open(gold) as f:
+                    want = json.load(f)
+                assert (frames["check"]["lines"], frames["check"]["md5"]) == (want["lines"], want["md5"]), \
+                    "the listing differs from the reference's: %s vs %s" % (frames["check"], want)
+                frames["check"]["equals_reference_md5"] = True
+        del iq_f
 
-    in_flight = []                                  # contexts with a detect queued, oldest first
-    t0 = None
-    warm = args.settle + args.warmup
-    for step in range(warm + args.steps):
-        if step == warm:
-            while in_flight:
-                finish(in_flight.pop(0), False)
-            sync_all()
-            t0 = time.perf_counter()
-        d = demods[step % len(demods)]
-        if d in in_flight:                          # its previous detect must be fetched first
-            while in_flight:
-                x = in_flight.pop(0)
-                finish(x, step > warm)
-                if x is d:
-                    break
-        d.detect(iq, stream_byte0=lo, first_block=first_block, nblocks=nblocks, stream=works[step % len(works)])
-        in_flight.append(d)
-    while in_flight:
-        finish(in_flight.pop(0), True)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    n_msgs = n_msgs[0]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def leg_summary(leg, steps, name):
+        samples_per_step = leg["total"] // 2
+        el = leg["elapsed"]
+        d = {"workload": name, "Msamples_per_s": round(samples_per_step * steps / el / 1e6, 1),
+             "ms_per_step": round(el / steps * 1e3, 4),
+             "kernel_ms": {"scan": round(leg["scan_ms"], 4), "demod": round(leg["demod_ms"], 4), "order": round(leg["order_ms"], 4)},
+             "records_per_step_rank0": int(leg["last"].get("n_records", 0))}
+        if rank == 0:
+            d["msgs_per_s"] = round(leg["msgs"] / el, 1)
+            d["msgs_per_step"] = int(leg["lines"])
+        return d
 
-    samples_per_step = total // 2
-    value = samples_per_step * args.steps / elapsed / 1e6
-    scan_avg_ms = float(np.mean(scan_ms))
-    achieved = (2.0 * (hi - lo) / 2) / (scan_avg_ms * 1e-3) / 1e9       # this rank's launch: 2 B per sample
+    head = noise if noise is not None else frames
+    head_steps = head["steps"]
+    head_name = ("%d MiB synthetic uint8 IQ @ 2 Msps format per GPU (sigma=3 integer noise, seed 20260922), --no-fix, "
+                 "HBM-resident; BASELINE.json configs[1]" % args.mib) if noise is not None else (
+        "%d MiB per GPU of sigma=3 noise + DF11/DF17 frames, --fix; BASELINE.json configs[%d]" % (args.frames_mib, 2 if world == 1 else 3))
+    samples_per_step = head["total"] // 2                                     # the whole stream: every rank's shard
+    value = samples_per_step * head_steps / head["elapsed"] / 1e6
+    achieved = head["call_bytes"] / (head["scan_ms"] * 1e-3) / 1e9           # this rank's launches: 2 B per sample
+    traffic, traffic_note = measured_traffic(args.mib) if noise is not None else (None, "no PMC pass for this workload")
     line = {
         "metric": "IQ Msamples/s demodulated", "value": round(value, 1), "unit": "Msamples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "n_gpus": world, "steps": head_steps, "warmup": args.warmup,
+        "ms_per_step": round(head["elapsed"] / head_steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-        "config": {"workload": "%d MiB synthetic uint8 IQ @ 2 Msps format per GPU (sigma=3 integer noise, seed "
-                               "20260922), --no-fix, HBM-resident; BASELINE.json configs[1]" % args.mib,
-                   "bytes_per_gpu": per_gpu, "flags": "--raw --no-fix", "sharding": "buffers over %d rank(s)" % world,
-                   "settle_steps": args.settle,
-                   "step": "scan + demod kernels, record fetch%s, host resolve; %d detect(s) in flight" % (
-                       ", RCCL gather to rank 0" if world > 1 else "", len(demods))},
-        "msgs_per_s": round(n_msgs / elapsed, 2),
-        "preambles_per_step_rank0": int(n_pre), "forwarded_per_step_rank0": int(n_fwd),
-        "kernel_ms": {"scan": round(scan_avg_ms, 4), "demod_finalize": round(float(np.mean(demod_ms)), 4)},
+        "config": {"workload": head_name, "bytes_per_gpu": head["per_gpu"],
+                   "flags": "--raw --no-fix" if noise is not None else "--raw",
+                   "sharding": "buffers over %d rank(s)" % world, "settle_steps": args.settle if noise is not None else 6,
+                   "step": "scan + demod + order kernels, record fetch%s, host resolve + --raw formatting on a second thread; "
+                           "%d detect(s) in flight; overlap=%d" % (
+                               ", device-resident lists gathered to rank 0 over %s (counts all_gather + exact-size send/recv)" % (
+                                   "RCCL" if args.backend == "nccl" else args.backend) if world > 1 else "",
+                               head["depth"], args.overlap)},
+        "msgs_per_s": round(head.get("msgs", 0) / head["elapsed"], 2) if rank == 0 else None,
+        "preambles_per_step_rank0": int(head["last"].get("n_preambles", 0)),
+        "forwarded_per_step_rank0": int(head["last"].get("n_forwarded", 0)),
+        "kernel_ms": {"scan": round(head["scan_ms"], 4), "demod": round(head["demod_ms"], 4), "order": round(head["order_ms"], 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.mib),
-                     "kernel": "scan_kernel", "algorithmic_bytes_per_launch": int(hi - lo)},
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
+                     "kernel": "scan_kernel", "algorithmic_bytes_per_launch": int(head["call_bytes"])},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(iq, min(args.cpu_mib << 20, (hi - lo) // 262144 * 262144))
+    if frames is not None and noise is not None:
+        f = leg_summary(frames, frames["steps"], "BASELINE.json configs[%d]: %d MiB per GPU, sigma=3 noise + DF11/DF17 frames "
+                        "(1 per 65,536 samples, 10 %% with a flipped bit, seam offsets), --fix" % (2 if world == 1 else 3, args.frames_mib))
+        if rank == 0:
+            f["listing_check"] = frames["check"]
+        f["wall_over_kernels"] = round(f["ms_per_step"] / (frames["scan_ms"] + frames["demod_ms"] + frames["order_ms"]), 3)
+        line["frames"] = f
+    elif frames is not None and rank == 0:
+        line["listing_check"] = frames["check"]
+
+    if rank == 0 and world == 1 and noise is not None and not args.no_end_to_end:
+        line["end_to_end"] = end_to_end(torch, dev, iq_noise, args)
+    if rank == 0 and world == 1 and noise is not None and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(iq_noise, min(args.cpu_mib << 20, noise["span"] // 262144 * 262144))
     if rank == 0:
         print(json.dumps(line), flush=True)
-    for d in demods:
-        d.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def end_to_end(torch, dev, iq, args, batch_blocks=1024, passes=6):
+    """The noise workload starting in pinned HOST memory: batches of `batch_blocks` buffers through
+    modes_gpu_submit_host (H2D + kernels, asynchronous) in three rotating contexts, fetch + resolve in order - the
+    loop of dump1090_amd/csrc/main.cpp without the file reads.  PCIe-inclusive; never the headline."""
+    from dump1090_amd import Demodulator, HostResolver, block_count
+    n = iq.numel()
+    total_blocks = block_count(n)
+    demods = [Demodulator(device=dev.index, fix=False) for _ in range(3)]
+    batches = []
+    for b0 in range(0, total_blocks, batch_blocks):
+        nb = min(batch_blocks, total_blocks - b0)
+        lo = max(0, b0 * 262144 - 476)
+        hi = min(n, (b0 + nb) * 262144)
+        buf = demods[0].host_alloc(hi - lo)
+        buf[:] = iq[lo:hi].cpu().numpy()
+        batches.append((buf, lo, b0, nb))
+    res = HostResolver(fix=False)
+
+    def one_pass():
+        inflight = []
+        for i, (buf, lo, b0, nb) in enumerate(batches):
+            d = demods[i % 3]
+            if len(inflight) == 3:
+                x = inflight.pop(0)
+                recs, _, _ = x.fetch(copy=False)
+                res.raw_listing(recs, None)
+            d.submit_host(buf, stream_byte0=lo, first_block=b0, nblocks=nb)
+            inflight.append(d)
+        for x in inflight:
+            recs, _, _ = x.fetch(copy=False)
+            res.raw_listing(recs, None)
+
+    one_pass()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        one_pass()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    for buf, *_ in batches:
+        demods[0].host_free(buf)
+    res.close()
+    for d in demods:
+        d.close()
+    return {"Msamples_per_s": round(n / 2 * passes / dt / 1e6, 1), "GB_per_s": round(n * passes / dt / 1e9, 2),
+            "what": "%d MiB of the headline workload in pinned host memory -> modes_gpu_submit_host in %d-buffer batches, 3 contexts "
+                    "in rotation, fetch + resolve in order; %d passes, %.3f s (PCIe-inclusive; the C host adds the file reads: "
+                    "tools/e2e_cli.py)" % (n >> 20, batch_blocks, passes, dt)}
 
 
 if __name__ == "__main__":

@@ -35,7 +35,10 @@ class GpuConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("fix_errors", C.c_int32), ("aggressive", C.c_int32),
                 ("keep_candidates", C.c_int32), ("run_chunks", C.c_uint32), ("slot_cap", C.c_uint32),
                 ("max_records", C.c_uint32), ("scan_variant", C.c_uint32), ("overlap", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32), ("direct_records", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+GPU_NO_RETRY = 1
 
 
 class Attempt(C.Structure):
@@ -62,7 +65,7 @@ class GpuResult(C.Structure):
     _fields_ = [("records", C.POINTER(Record)), ("n_records", C.c_uint64),
                 ("candidates", C.POINTER(C.c_uint64)), ("n_candidates", C.c_uint64),
                 ("n_forwarded", C.c_uint64), ("n_preambles", C.c_uint64),
-                ("scan_ms", C.c_float), ("demod_ms", C.c_float)]
+                ("scan_ms", C.c_float), ("demod_ms", C.c_float), ("order_ms", C.c_float), ("reserved", C.c_float)]
 
 
 class HostConfig(C.Structure):
@@ -111,11 +114,11 @@ SINK_FN = C.CFUNCTYPE(None, C.POINTER(ModesMessage), C.c_uint32, C.c_uint32, C.c
 
 # every symbol include/*.h declares (tests/test_abi.py checks the libraries export them)
 GPU_SYMBOLS = ("modes_gpu_create", "modes_gpu_destroy", "modes_gpu_last_error", "modes_gpu_compute_magnitude",
-               "modes_gpu_detect", "modes_gpu_fetch", "modes_gpu_demod_host", "modes_gpu_submit_host",
+               "modes_gpu_detect", "modes_gpu_fetch", "modes_gpu_fetch_device", "modes_gpu_set_output", "modes_gpu_stream_wait", "modes_gpu_demod_host", "modes_gpu_submit_host",
                "modes_gpu_host_alloc", "modes_gpu_host_free", "modes_gpu_compute_power",
                "modes_gpu_synth_noise", "modes_gpu_fill", "modes_gpu_abi_version")
 HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_set_time", "modes_host_resolve", "modes_host_resolve_to_array",
-                "modes_host_wants",
+                "modes_host_resolve_raw", "modes_host_wants",
                 "modes_host_get_stats", "modes_host_decode", "modes_host_decode_frame", "modes_format_raw", "modes_format_raw_net",
                 "modes_format_onlyaddr", "modes_format_verbose", "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
                 "modes_block_count",
@@ -142,6 +145,13 @@ def gpu_lib():
         L.modes_gpu_compute_power.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.modes_gpu_detect.argtypes = [C.c_void_p, C.POINTER(Span), C.c_void_p]
         L.modes_gpu_fetch.argtypes = [C.c_void_p, C.POINTER(GpuResult)]
+        L.modes_gpu_fetch_device.argtypes = [C.c_void_p, C.POINTER(GpuResult)]
+        L.modes_gpu_stream_wait.argtypes = [C.c_void_p, C.c_void_p]
+        L.modes_gpu_set_output.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.modes_gpu_submit_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.modes_gpu_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.modes_gpu_host_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.modes_gpu_host_free.restype = None
         L.modes_gpu_demod_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                            C.POINTER(GpuResult)]
         L.modes_gpu_synth_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
@@ -169,6 +179,9 @@ def host_lib():
         L.modes_host_resolve_to_array.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                                   C.POINTER(Emitted), C.c_uint64]
         L.modes_host_resolve_to_array.restype = C.c_uint64
+        L.modes_host_resolve_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                             C.POINTER(C.c_uint64)]
+        L.modes_host_resolve_raw.restype = C.c_uint64
         L.modes_host_wants.argtypes = [C.c_void_p, C.POINTER(ModesMessage)]
         L.modes_host_get_stats.argtypes = [C.c_void_p, C.POINTER(HostStats)]
         L.modes_host_get_stats.restype = None

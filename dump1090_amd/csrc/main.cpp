@@ -1,6 +1,6 @@
 // dump1090_amd - the C/C++ host of the reference's --ifile path on top of the two libraries:
 //
-//   read (--ifile <file>|-)  ->  libmodes_gfx950.so (scan + demod on the GPU, many buffers per call)
+//   read (--ifile <file>|-)  ->  libmodes_gfx950.so (scan + demod + order on the GPU(s), many buffers per call)
 //                            ->  libmodes_host.so   (in-order resolve, decodeModesMessage, sink)
 //                            ->  stdout (--raw / --onlyaddr / --stats; --sbs / --raw-net: the lines of the reference's TCP sinks)
 //
@@ -8,11 +8,27 @@
 // (dump1090.c:2869-2897,2922; defaults :299-319) and processes EVERY buffer the reference's
 // reader publishes (the reference itself drops the last one most of the time: SURVEY.md 3.4).
 // Live radio, networking, interactive mode and the debug dumps are out of scope.
+//
+// Structure (the reference's reader thread / main thread pair, dump1090.c:460-527 and 2965-2990, widened):
+//
+//   reader (main thread + a pool of pread workers)          resolver thread
+//   batch b -> lane b mod L: pinned buffer, GPU context  -> fetch(lane) in batch order, modes_host_resolve,
+//   on device b mod N; submit = async H2D + kernels         print; the lane is free again
+//
+// A batch is a contiguous range of 256 KiB buffers plus the 476-byte carry in front (dump1090.c:481), so
+// batches - and therefore GPUs (--gpus N: batch b runs on device b mod N, one context per lane) - share nothing
+// but those 476 input bytes; the record lists come back per batch, already in stream order, and are resolved
+// strictly in batch order by the one thread that owns the ICAO whitelist.
 
 #include <cerrno>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <algorithm>
 #include <thread>
@@ -29,11 +45,12 @@ namespace {
 
 struct Options {
     std::string filename;
-    bool loop = false, raw = false, onlyaddr = false, stats = false, sbs = false, raw_net = false;
+    bool loop = false, raw = false, onlyaddr = false, stats = false, sbs = false, raw_net = false, timing = false;
     int fix_errors = 1, check_crc = 1, aggressive = 0;
-    int device = 0;
-    uint64_t batch_blocks = 512;           // 128 MiB of samples per GPU call (end to end, 8 GiB file: 0.58 s; 1024: 0.67 s)
-    int read_threads = 8;                  // parallel pread() slices for regular files
+    std::vector<int> devices;              // HIP ordinals, one per "GPU" of the split (the same ordinal may repeat)
+    uint64_t batch_blocks = 512;           // 128 MiB of samples per GPU call
+    int read_threads = 16;                 // parallel pread() slices for regular files
+    int depth = 3;                         // batches in flight per device (lanes = depth x devices)
 };
 
 struct Sink {
@@ -56,8 +73,12 @@ void show_help() {
         "--sbs                    Print the BaseStation lines the reference serves on port 30003.\n"
         "--raw-net                Print the raw lines the reference serves on port 30002.\n"
         "--gpu <ordinal>          HIP device to run on (default: 0).\n"
+        "--gpus <n>               Split the stream over HIP devices 0..n-1 (batch b runs on device b mod n).\n"
+        "--gpu-list <a,b,...>     The same with explicit ordinals; an ordinal may repeat (several contexts on one device).\n"
         "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).\n"
-        "--read-threads <n>       Threads reading a regular file (default: 8).\n"
+        "--depth <n>              Batches in flight per device (default: 3).\n"
+        "--read-threads <n>       Threads reading a regular file (default: 16).\n"
+        "--timing                 Print a JSON line with the phase times to stderr.\n"
         "--help                   Show this help.\n");
 }
 
@@ -82,35 +103,75 @@ void on_message(const struct modesMessage *mm, uint32_t, uint32_t, void *user) {
     s->out.append(line, (size_t)n);
 }
 
+// A fixed set of worker threads that run fn(0..n-1) and wait: the slices of one parallel file read.
+class Pool {
+public:
+    explicit Pool(int n) {
+        for (int t = 0; t < n; t++) workers_.emplace_back([this] { work(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    void run(int n, const std::function<void(int)> &fn) {
+        std::unique_lock<std::mutex> g(m_);
+        fn_ = &fn; next_ = 0; total_ = n; left_ = n;
+        cv_.notify_all();
+        done_.wait(g, [this] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+    int size() const { return (int)workers_.size(); }
+private:
+    void work() {
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [this] { return stop_ || (fn_ && next_ < total_); });
+            if (stop_) return;
+            const int i = next_++;
+            const std::function<void(int)> *fn = fn_;
+            g.unlock();
+            (*fn)(i);
+            g.lock();
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int next_ = 0, total_ = 0, left_ = 0;
+    bool stop_ = false;
+};
+
 // A regular file is read by several threads at once (pread on disjoint slices): one thread copying
-// out of the page cache is ~10x slower than the PCIe link that follows.  Falls back to read() for
-// pipes / stdin.  *got < want only at end of file.
-bool read_parallel(int fd, off_t *pos, uint8_t *dst, size_t want, size_t *got, int nthreads) {
+// out of the page cache is ~10x slower than the PCIe link that follows.  *got < want only at end of file.
+bool read_parallel(Pool &pool, int fd, off_t *pos, uint8_t *dst, size_t want, size_t *got) {
     *got = 0;
     if (want == 0) return true;
-    const size_t slice = (want / (size_t)nthreads + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
-    std::vector<ssize_t> done((size_t)nthreads, 0);
-    for (int t = 0; t < nthreads; t++) {
+    const int nslices = pool.size();
+    const size_t slice = (want / (size_t)nslices + 4095) & ~(size_t)4095;
+    std::vector<ssize_t> done((size_t)nslices, 0);
+    const off_t pos0 = *pos;
+    pool.run(nslices, [&](int t) {
+        const size_t lo = (size_t)t * slice;
+        if (lo >= want) return;
+        const size_t n = std::min(slice, want - lo);
+        size_t have = 0;
+        while (have < n) {
+            ssize_t r = pread(fd, dst + lo + have, n - have, pos0 + (off_t)(lo + have));
+            if (r < 0) { if (errno == EINTR) continue; done[(size_t)t] = -1; return; }
+            if (r == 0) break;
+            have += (size_t)r;
+        }
+        done[(size_t)t] = (ssize_t)have;
+    });
+    for (int t = 0; t < nslices; t++) {
         const size_t lo = (size_t)t * slice;
         if (lo >= want) break;
-        const size_t n = std::min(slice, want - lo);
-        th.emplace_back([=, &done] {
-            size_t have = 0;
-            while (have < n) {
-                ssize_t r = pread(fd, dst + lo + have, n - have, *pos + (off_t)(lo + have));
-                if (r < 0) { if (errno == EINTR) continue; done[(size_t)t] = -1; return; }
-                if (r == 0) break;
-                have += (size_t)r;
-            }
-            done[(size_t)t] = (ssize_t)have;
-        });
-    }
-    for (auto &x : th) x.join();
-    for (size_t t = 0; t < th.size(); t++) {
-        if (done[t] < 0) return false;
-        *got += (size_t)done[t];
-        if ((size_t)done[t] < std::min(slice, want - t * slice)) break;       // end of file inside this slice
+        if (done[(size_t)t] < 0) return false;
+        *got += (size_t)done[(size_t)t];
+        if ((size_t)done[(size_t)t] < std::min(slice, want - lo)) break;      // end of file inside this slice
     }
     *pos += (off_t)*got;
     return true;
@@ -127,10 +188,20 @@ bool read_full(int fd, uint8_t *dst, size_t want, size_t *got) {
     return true;
 }
 
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Lane {
+    modes_gpu *gpu = nullptr;
+    uint8_t *buf = nullptr;
+    int device = 0;
+};
+
 }  // namespace
 
 int main(int argc, char **argv) {
+    const double t_start = now_s();
     Options opt;
+    int single_device = 0, ngpus = 0;
     for (int j = 1; j < argc; j++) {
         const bool more = j + 1 < argc;
         const char *a = argv[j];
@@ -144,8 +215,20 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--raw-net")) opt.raw_net = true;
         else if (!strcmp(a, "--aggressive")) opt.aggressive++;
         else if (!strcmp(a, "--stats")) opt.stats = true;
-        else if (!strcmp(a, "--gpu") && more) opt.device = atoi(argv[++j]);
+        else if (!strcmp(a, "--timing")) opt.timing = true;
+        else if (!strcmp(a, "--gpu") && more) single_device = atoi(argv[++j]);
+        else if (!strcmp(a, "--gpus") && more) ngpus = atoi(argv[++j]);
+        else if (!strcmp(a, "--gpu-list") && more) {
+            opt.devices.clear();
+            for (const char *p = argv[++j]; *p;) {
+                char *end;
+                opt.devices.push_back((int)strtol(p, &end, 10));
+                if (end == p) { fprintf(stderr, "--gpu-list: bad ordinal in '%s'\n", argv[j]); return 1; }
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
         else if (!strcmp(a, "--batch-blocks") && more) opt.batch_blocks = strtoull(argv[++j], nullptr, 10);
+        else if (!strcmp(a, "--depth") && more) opt.depth = std::max(1, atoi(argv[++j]));
         else if (!strcmp(a, "--read-threads") && more) opt.read_threads = std::max(1, atoi(argv[++j]));
         else if (!strcmp(a, "--help")) { show_help(); return 0; }
         else {
@@ -159,6 +242,10 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (opt.batch_blocks == 0) opt.batch_blocks = 1;
+    if (opt.devices.empty()) {
+        if (ngpus > 0) for (int d = 0; d < ngpus; d++) opt.devices.push_back(d);
+        else opt.devices.push_back(single_device);
+    }
 
     int fd = 0;
     if (opt.filename != "-" && (fd = open(opt.filename.c_str(), O_RDONLY)) == -1) {
@@ -166,62 +253,106 @@ int main(int argc, char **argv) {
         return 1;
     }
 
-    modes_gpu_config gcfg{};
-    gcfg.device = opt.device;
-    gcfg.fix_errors = opt.fix_errors;
-    gcfg.aggressive = opt.aggressive ? 1 : 0;
-    gcfg.keep_candidates = opt.stats ? 1 : 0;
-    // Two GPU contexts and two pinned host buffers, used alternately: while batch b is copied to HBM
-    // and demodulated, batch b+1 is read from the file - the job of the reference's reader thread
-    // (dump1090.c:460-527, 2965-2990).  Results are resolved strictly in batch order.
-    modes_gpu *gpu[2] = {nullptr, nullptr};
-    uint8_t *buf[2] = {nullptr, nullptr};
+    // One lane = one GPU context + one pinned buffer; lane l lives on device l mod N, so that batch b (lane
+    // b mod L, L a multiple of N) runs on device b mod N.  The contexts of different devices are created
+    // concurrently (HIP initialises each device on first use).
+    const int ndev = (int)opt.devices.size();
+    const int nlanes = ndev * opt.depth;
     const size_t batch_bytes = (size_t)opt.batch_blocks * MODES_DATA_LEN;
-    for (int k = 0; k < 2; k++) {
-        if (modes_gpu_create(&gcfg, &gpu[k]) != MODES_OK) {
-            fprintf(stderr, "GPU init failed: %s\n", modes_gpu_last_error(nullptr));
-            return 1;
-        }
-        void *p = nullptr;
-        if (modes_gpu_host_alloc(gpu[k], MODES_CARRY_BYTES + batch_bytes, &p) != MODES_OK) {
-            fprintf(stderr, "pinned buffer: %s\n", modes_gpu_last_error(gpu[k]));
-            return 1;
-        }
-        buf[k] = static_cast<uint8_t *>(p);
+    std::vector<Lane> lanes((size_t)nlanes);
+    {
+        std::vector<std::string> errs((size_t)nlanes);
+        auto make = [&](int l) {
+            modes_gpu_config gcfg{};
+            gcfg.device = opt.devices[(size_t)(l % ndev)];
+            gcfg.fix_errors = opt.fix_errors;
+            gcfg.aggressive = opt.aggressive ? 1 : 0;
+            gcfg.keep_candidates = opt.stats ? 1 : 0;
+            lanes[(size_t)l].device = gcfg.device;
+            if (modes_gpu_create(&gcfg, &lanes[(size_t)l].gpu) != MODES_OK) {
+                errs[(size_t)l] = std::string("GPU init failed: ") + modes_gpu_last_error(nullptr);
+                return;
+            }
+            void *p = nullptr;
+            if (modes_gpu_host_alloc(lanes[(size_t)l].gpu, MODES_CARRY_BYTES + batch_bytes, &p) != MODES_OK) {
+                errs[(size_t)l] = std::string("pinned buffer: ") + modes_gpu_last_error(lanes[(size_t)l].gpu);
+                return;
+            }
+            lanes[(size_t)l].buf = static_cast<uint8_t *>(p);
+        };
+        std::vector<std::thread> th;
+        for (int d = 0; d < ndev; d++)
+            th.emplace_back([&, d] { for (int l = d; l < nlanes; l += ndev) make(l); });
+        for (auto &t : th) t.join();
+        for (auto &e : errs)
+            if (!e.empty()) { fprintf(stderr, "%s\n", e.c_str()); return 1; }
     }
     modes_host_config hcfg{opt.fix_errors, opt.aggressive ? 1 : 0, opt.check_crc, 0};
     modes_host *host = modes_host_create(&hcfg);
+    if (!host) { fprintf(stderr, "modes_host_create failed\n"); return 1; }
     Sink sink{&opt, host, {}, opt.sbs ? modes_tracker_create() : nullptr};
+    const bool live = opt.loop || fd == 0;               // a pipe or an endless replay: the whitelist TTL follows the wall clock
+    const double t_ready = now_s();
 
-    // fetch + resolve + print the batch in flight on context k
-    auto finish = [&](int k) -> bool {
-        modes_gpu_result res{};
-        if (modes_gpu_fetch(gpu[k], &res) != MODES_OK) {
-            fprintf(stderr, "GPU demodulation failed: %s\n", modes_gpu_last_error(gpu[k]));
-            return false;
+    // ---- hand-off between the reader (this thread) and the resolver ----
+    std::mutex m;
+    std::condition_variable cv;
+    uint64_t submitted = 0, resolved = 0;                // batches
+    bool reader_done = false, failed = false;
+    uint64_t n_messages_out = 0;
+
+    std::thread resolver([&] {
+        for (uint64_t b = 0;; b++) {
+            {
+                std::unique_lock<std::mutex> g(m);
+                cv.wait(g, [&] { return submitted > b || reader_done || failed; });
+                if (failed || (submitted <= b && reader_done)) return;
+            }
+            Lane &ln = lanes[(size_t)(b % (uint64_t)nlanes)];
+            modes_gpu_result res{};
+            if (modes_gpu_fetch(ln.gpu, &res) != MODES_OK) {
+                fprintf(stderr, "GPU demodulation failed: %s\n", modes_gpu_last_error(ln.gpu));
+                std::lock_guard<std::mutex> g(m);
+                failed = true;
+                cv.notify_all();
+                return;
+            }
+            if (live) modes_host_set_time(host, (int64_t)time(nullptr));          // dump1090.c:913,924
+            n_messages_out += modes_host_resolve(host, res.records, res.n_records, res.candidates, res.n_candidates, on_message, &sink);
+            if (!sink.out.empty()) {
+                fwrite(sink.out.data(), 1, sink.out.size(), stdout);
+                fflush(stdout);
+                sink.out.clear();
+            }
+            {
+                std::lock_guard<std::mutex> g(m);
+                resolved = b + 1;
+            }
+            cv.notify_all();
         }
-        modes_host_resolve(host, res.records, res.n_records, res.candidates, res.n_candidates, on_message, &sink);
-        if (!sink.out.empty()) {
-            fwrite(sink.out.data(), 1, sink.out.size(), stdout);
-            fflush(stdout);
-            sink.out.clear();
-        }
-        return true;
-    };
+    });
 
     // Batch b covers buffers [first, first+n): host bytes = 476-byte carry + n*262144 new bytes.
     // --loop replays a file forever through the sequential path; a plain regular file is read in parallel
     const bool seekable = !opt.loop && fd != 0 && lseek(fd, 0, SEEK_CUR) != (off_t)-1;
+    Pool pool(seekable ? opt.read_threads : 1);
     off_t file_pos = 0;
-    uint64_t first_block = 0;
+    uint64_t first_block = 0, total_bytes = 0;
     size_t carry = 0;                       // valid carry bytes at the front of the current buffer (0 for the first batch)
+    uint8_t carry_bytes[MODES_CARRY_BYTES];
     bool eof = false;
-    int rc = 0, cur = 0;
-    bool pending = false;                   // a batch is in flight on context 1-cur
-    while (!eof) {
+    int rc = 0;
+    for (uint64_t b = 0; !eof; b++) {
+        {   // the lane of batch b is free once batch b - nlanes has been resolved
+            std::unique_lock<std::mutex> g(m);
+            cv.wait(g, [&] { return failed || b < resolved + (uint64_t)nlanes; });
+            if (failed) { rc = 1; break; }
+        }
+        Lane &ln = lanes[(size_t)(b % (uint64_t)nlanes)];
+        if (carry) memcpy(ln.buf, carry_bytes, MODES_CARRY_BYTES);               // dump1090.c:481
         size_t got = 0;
-        uint8_t *dst = buf[cur] + carry;
-        const bool ok = seekable ? read_parallel(fd, &file_pos, dst, batch_bytes, &got, opt.read_threads)
+        uint8_t *dst = ln.buf + carry;
+        const bool ok = seekable ? read_parallel(pool, fd, &file_pos, dst, batch_bytes, &got)
                                  : read_full(fd, dst, batch_bytes, &got);
         if (!ok) { perror("read"); rc = 1; break; }
         while (got < batch_bytes && opt.loop && fd != 0 && !seekable) { // dump1090.c:488-494
@@ -231,27 +362,38 @@ int main(int argc, char **argv) {
             if (more == 0) break;                                      // empty file
             got += more;
         }
+        if (rc) break;
+        total_bytes += got;
         // The reader publishes one buffer per full 262144 bytes and one more at EOF
         // (dump1090.c:484-510): a short batch ends the stream with floor(got/262144)+1 buffers.
         uint64_t nblocks = got / MODES_DATA_LEN;
         if (got < batch_bytes) { eof = true; nblocks += 1; }
         const uint64_t byte0 = first_block * (uint64_t)MODES_DATA_LEN - carry;
-        if (modes_gpu_submit_host(gpu[cur], buf[cur], carry + got, byte0, first_block, nblocks) != MODES_OK) {
-            fprintf(stderr, "GPU demodulation failed: %s\n", modes_gpu_last_error(gpu[cur]));
+        if (modes_gpu_submit_host(ln.gpu, ln.buf, carry + got, byte0, first_block, nblocks) != MODES_OK) {
+            fprintf(stderr, "GPU demodulation failed: %s\n", modes_gpu_last_error(ln.gpu));
             rc = 1;
             break;
         }
-        if (pending && !finish(1 - cur)) { rc = 1; pending = false; break; }
-        pending = true;
-        // carry the last 476 bytes into the next batch's buffer (dump1090.c:481)
-        if (!eof) {
-            memcpy(buf[1 - cur], buf[cur] + carry + got - MODES_CARRY_BYTES, MODES_CARRY_BYTES);
+        if (!eof) {                                                     // the last 476 bytes travel to the next batch
+            memcpy(carry_bytes, ln.buf + carry + got - MODES_CARRY_BYTES, MODES_CARRY_BYTES);
             carry = MODES_CARRY_BYTES;
             first_block += nblocks;
-            cur = 1 - cur;
         }
+        {
+            std::lock_guard<std::mutex> g(m);
+            submitted = b + 1;
+        }
+        cv.notify_all();
     }
-    if (pending && rc == 0 && !finish(cur)) rc = 1;
+    {
+        std::lock_guard<std::mutex> g(m);
+        reader_done = true;
+        if (rc) failed = true;
+    }
+    cv.notify_all();
+    resolver.join();
+    if (failed) rc = 1;
+    const double t_end = now_s();
 
     if (rc == 0 && opt.stats) {                                        // dump1090.c:2993-3006
         modes_host_stats st;
@@ -260,11 +402,20 @@ int main(int argc, char **argv) {
         modes_format_stats(&st, text);
         fputs(text, stdout);
     }
+    if (opt.timing) {
+        const double stream_s = t_end - t_ready;
+        fprintf(stderr,
+                "{\"bytes\": %llu, \"devices\": %d, \"lanes\": %d, \"init_s\": %.4f, \"stream_s\": %.4f, \"total_s\": %.4f, "
+                "\"stream_GBps\": %.2f, \"stream_Msamples_per_s\": %.1f, \"sink_calls\": %llu}\n",
+                (unsigned long long)total_bytes, ndev, nlanes, t_ready - t_start, stream_s, t_end - t_start,
+                stream_s > 0 ? total_bytes / stream_s / 1e9 : 0.0, stream_s > 0 ? total_bytes / 2 / stream_s / 1e6 : 0.0,
+                (unsigned long long)n_messages_out);
+    }
     modes_host_destroy(host);
     modes_tracker_destroy(sink.tracker);
-    for (int k = 0; k < 2; k++) {
-        modes_gpu_host_free(gpu[k], buf[k]);
-        modes_gpu_destroy(gpu[k]);
+    for (auto &ln : lanes) {
+        modes_gpu_host_free(ln.gpu, ln.buf);
+        modes_gpu_destroy(ln.gpu);
     }
     if (fd > 0) close(fd);
     return rc;

@@ -42,7 +42,6 @@
 
 #include "../../include/modes_gfx950.h"
 #include "modes_core.h"
-#include "modes_order.h"
 
 static_assert(sizeof(modes_attempt) == 28, "modes_attempt layout");
 static_assert(sizeof(modes_record) == 64, "modes_record layout");
@@ -181,23 +180,21 @@ __global__ __launch_bounds__(256) void power_kernel(const uint8_t *__restrict__ 
 // synchronisation, no atomics; forwarded positions go to the run's private slot list in
 // ascending order, so the concatenation over runs is already sorted.
 // ------------------------------------------------------------------------------------
-// Totals of one detect call.  On the device only n_records is live (the record append counter, zeroed
-// by the scan kernel); the host fills the rest by summing the per-workgroup WgTotals.
+// Device-side state of one detect call, zeroed by the scan kernel.
 struct ResultHeader {
-    unsigned long long n_forwarded;   // positions forwarded by the scan
-    unsigned long long n_preambles;   // positions where the full predicate holds
-    uint32_t n_records;               // records appended
-    uint32_t overflow;                // some run overflowed its slots
+    uint32_t n_records;               // staging slots reserved so far = records (exact reservation: no holes)
+    uint32_t done;                    // demod workgroups retired; the last one turns the batch counts into offsets
+    uint32_t pad[2];
 };
 
 // What one demod workgroup found, written straight to pinned host memory when the workgroup retires
 // (plain stores, visible to the host once the kernel has completed): no totals atomics on the device
-// and no result-copy kernel behind demod_kernel.
+// and no result-copy kernel.
 struct WgTotals {
     unsigned long long n_forwarded, n_preambles;
     uint32_t n_records;      // records written
-    uint32_t n_reserved;     // record slots reserved (whole kRecChunk blocks; the unused ones are marked invalid)
-    uint32_t overflow, pad;
+    uint32_t flags;          // bit 0: a run overflowed its slot list; bit 1: internal inconsistency (pre-test vs full gate)
+    uint32_t pad[2];
 };
 
 struct ScanParams {
@@ -221,7 +218,7 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanPara
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t run = blockIdx.x * kScanWaves + wave;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *P.hdr = ResultHeader{0, 0, 0, 0};   // demod_kernel accumulates into it
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.hdr = ResultHeader{0, 0, {0, 0}};   // demod_kernel accumulates into it
     if (run >= P.nruns) return;
     uint32_t *ring = ring_all[wave];
 
@@ -305,14 +302,17 @@ __device__ unsigned long long g_trace[8192 * 8];      // per demod wavefront: st
 #else
 #define TRACE_T(var)
 #endif
-// Record slots are reserved kRecChunk at a time per wavefront: one global atomic per 32 records.
-// (One atomic per record saturates a single counter at ~88 per microsecond: 8.7 ms per GiB on the
-// reference's own message-dense capture.)  Unused slots of a wavefront's last block get block = ~0.
-constexpr uint32_t kRecChunk = 32;
-constexpr uint32_t kInvalidBlock = 0xFFFFFFFFu;
-struct RecCursor { uint32_t next, end; };   // wave-uniform
+// Records: a workgroup reserves the staging slots of one block of positions with ONE global atomic (it knows
+// the number of records of the block before it writes any: the noise-gate pre-test is exact) and writes them
+// ranked by position; every slot also gets a key (batch, rank inside the batch).  order_kernel then moves the
+// records to (exclusive prefix of the batch counts) + rank: the final list is in stream order on the DEVICE -
+// no holes, no host sort - ready for a device-to-host copy or for a gather over RCCL.
+constexpr uint32_t kNoPos = 0xFFFFFFFFu;          // a survivor whose first gate failed after all (edge of the span)
+constexpr uint64_t kNoKey = ~0ull;
 
-constexpr int kDemodWaves = 8;        // wavefronts per demod workgroup (they share one 64 KB LUT copy in LDS)
+constexpr int kDemodWaves = 4;        // wavefronts per demod workgroup: 4 waves, < 10 KiB of LDS and the magnitude table read
+                                      // through L1/L2, so that one fits on a CU NEXT TO the scan kernel's 12 workgroups
+                                      // (153,600 of 163,840 B of LDS, 24 of 32 wave slots) - DESIGN.md 3.2
 constexpr int kDemodThreads = kDemodWaves * 64;
 constexpr int kDemodGroup = 64;       // runs whose slot lists one demod workgroup walks together (one per lane of a wavefront)
 
@@ -328,9 +328,13 @@ struct DemodParams {
     DeviceTables tab;
     int maxfix;                // 0 = --no-fix, 1 = default, 2 = --aggressive   (dump1090.c:1115)
     uint32_t *cand_slots;      // [nruns][slot_cap] or nullptr
-    uint32_t *cand_counts;     // [nruns]
-    modes_record *records;
-    ResultHeader *hdr;         // device: record append counter (zeroed by the scan kernel)
+    uint32_t *cand_counts;     // [nbatches]
+    modes_record *staging;     // records in completion order
+    uint64_t *keys;            // per staging slot: batch << 32 | rank of the record inside its batch
+    uint32_t *batch_count;     // [nbatches] records of each batch
+    uint32_t *batch_off;       // [nbatches] exclusive prefix of batch_count (written by the last workgroup to retire)
+    uint32_t nbatches;
+    ResultHeader *hdr;         // device: slot reservation counter, retirement ticket (zeroed by the scan kernel)
     WgTotals *host_totals;     // device view of the pinned per-workgroup totals, [gridDim.x]
     uint32_t max_records;
 };
@@ -352,8 +356,7 @@ struct DemodParams {
 // loop-invariant VGPRs, the prefetched chunk lives in the registers it was loaded into (no
 // rotation moves), and global addresses are SGPR base + constant lane offset.
 //
-// Forwarded positions of a run are not in ascending order (the host sorts the candidate list
-// when it is requested; records are sorted anyway).
+// Forwarded positions of a run ARE in ascending order (scan_beta), and so is the concatenation over runs.
 // ------------------------------------------------------------------------------------
 constexpr int kQCap = 64;             // queue entries per wavefront: one beta pass
 constexpr int kQStride = 17;          // dwords per entry: 11 window + 4 results + 1 position + 1 pad (odd: no bank conflicts)
@@ -380,31 +383,42 @@ __device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *q
     }
     const uint16_t *w = reinterpret_cast<const uint16_t *>(e);
     const uint32_t p_begin32 = (uint32_t)P.p_begin, p_span32 = (uint32_t)(P.p_end - P.p_begin), g0_lo = (uint32_t)P.g0;
-    uint64_t pending = __ballot(m8 != 0);
-    while (pending) {
-        bool fwd = false;
-        uint32_t p = 0;
-        if (m8) {
-            const int i = __builtin_ctz(m8);
-            m8 &= m8 - 1;
-            const uint16_t *x = w + i;
-            const uint32_t s0 = x[0], s2 = x[2], s4 = x[4], s5 = x[5], s7 = x[7], s9 = x[9], s11 = x[11], s12 = x[12],
-                           s13 = x[13], s14 = x[14];
-            const uint32_t quiet = max(max(max(s4, s5), max(s11, s12)), max(s13, s14));
-            p = p0 + (uint32_t)i;                                            // wraps for the 16 look-back positions of chunk 0
-            // 32-bit forms of p_begin <= p < p_end and of the framing rule j < 131070 (:1593): positions of a call are
-            // below 2^32 - 2^15, so a wrapped look-back position fails the first test, and j only needs p + g0 mod 2^17
-            fwd = modes_level_bound(s0, s2, s7, s9, quiet) && (p - p_begin32) < p_span32 &&
-                  ((p + g0_lo) & (MODES_BLOCK_STRIDE - 1)) < MODES_BLOCK_POSITIONS;
-        }
-        const uint64_t fb = __ballot(fwd);
-        if (fwd) {
-            const uint32_t idx = count + (uint32_t)__builtin_popcountll(fb & ((1ull << lane) - 1));
-            if (idx < P.slot_cap) my_slots[idx] = p;
-        }
-        count += (uint32_t)__builtin_popcountll(fb);
-        pending = __ballot(m8 != 0);
+    uint32_t fwd8 = 0;                                                       // bit i: position p0 + i is forwarded
+    while (m8) {                                                             // lanes with alpha survivors only
+        const int i = __builtin_ctz(m8);
+        m8 &= m8 - 1;
+        const uint16_t *x = w + i;
+        const uint32_t s0 = x[0], s2 = x[2], s4 = x[4], s5 = x[5], s7 = x[7], s9 = x[9], s11 = x[11], s12 = x[12],
+                       s13 = x[13], s14 = x[14];
+        const uint32_t quiet = max(max(max(s4, s5), max(s11, s12)), max(s13, s14));
+        const uint32_t p = p0 + (uint32_t)i;                                 // wraps for the 16 look-back positions of chunk 0
+        // 32-bit forms of p_begin <= p < p_end and of the framing rule j < 131070 (:1593): positions of a call are
+        // below 2^32 - 2^15, so a wrapped look-back position fails the first test, and j only needs p + g0 mod 2^17
+        const bool fwd = modes_level_bound(s0, s2, s7, s9, quiet) && (p - p_begin32) < p_span32 &&
+                         ((p + g0_lo) & (MODES_BLOCK_STRIDE - 1)) < MODES_BLOCK_POSITIONS;
+        fwd8 |= (fwd ? 1u : 0u) << i;
     }
+    // Entries were queued in ascending p0 and own disjoint 8-position windows, so (lane, bit) order is position
+    // order: the slot list of a run is ASCENDING, and so is the concatenation over runs - the demod kernel ranks
+    // its records by position without a sort.  Exclusive prefix over the lanes of a count <= 8: one ballot per bit.
+    const uint32_t cnt = (uint32_t)__builtin_popcount(fwd8);
+    uint32_t excl = 0, total = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const uint64_t bb = __ballot(((cnt >> b) & 1u) != 0);
+        if (bb) {                                                            // wave-uniform
+            excl += __builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u)) << b;
+            total += (uint32_t)__builtin_popcountll(bb) << b;
+        }
+    }
+    uint32_t idx = count + excl;
+    while (fwd8) {
+        const int i = __builtin_ctz(fwd8);
+        fwd8 &= fwd8 - 1;
+        if (idx < P.slot_cap) my_slots[idx] = p0 + (uint32_t)i;
+        idx++;
+    }
+    count += total;
 }
 
 // GUARD: the run touches an end of the span (byte-wise bounds checks on every load).  Otherwise
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(kScan2Waves * kWave) void scan_kernel(ScanParams P)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: addresses stay in SGPRs
     const uint32_t run = blockIdx.x * kScan2Waves + wave;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *P.hdr = ResultHeader{0, 0, 0, 0};   // demod_kernel accumulates into it
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.hdr = ResultHeader{0, 0, {0, 0}};   // demod_kernel accumulates into it
     if (run >= P.nruns) return;
     // Runs whose loads (chunks c0-1 .. c1+1, the prefetch runs two chunks ahead) all lie inside the
     // span take the unguarded instantiation; that is every run except the first and the last few.
@@ -545,9 +559,18 @@ __device__ __forceinline__ uint32_t load_sample(const uint8_t *iq, int64_t sampl
 __device__ __forceinline__ bool samples_inside(int64_t first, int64_t last, int64_t lo, int64_t hi) {
     return 2 * first >= lo && 2 * last + 2 <= hi;
 }
+// The magnitude table in global memory (64 KiB), read through a raw buffer descriptor: SGPR base + one
+// VGPR byte offset per gather (no 64-bit address arithmetic in the vector unit).  The hot entries - the small
+// powers of noise - stay in the CU's L1, the rest in L2.
+struct Lut {
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ uint32_t operator[](uint32_t idx) const {
+        return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, idx * 2u, 0, 0);
+    }
+};
 // magnitude of a sample packed as I | Q << 8 (low 16 bits)
-__device__ __forceinline__ int mag_of(const uint16_t *s_lut, uint32_t iq16) {
-    return s_lut[modes_lut_index(iq16 & 0xff, (iq16 >> 8) & 0xff)];
+__device__ __forceinline__ int mag_of(const Lut lut, uint32_t iq16) {
+    return lut[modes_lut_index(iq16 & 0xff, (iq16 >> 8) & 0xff)];
 }
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -680,24 +703,24 @@ __device__ __forceinline__ uint32_t pk_lut_index(uint32_t w) { return modes_powe
 
 // Exact preamble predicate (dump1090.c:1602-1650) at buffer sample p, magnitudes from the LDS LUT.
 // Guarded form: 2-byte loads, bytes outside the span read as 127.
-__device__ __forceinline__ bool preamble_at_guarded(const uint8_t *iq, int64_t lo, int64_t hi, const uint16_t *s_lut, uint32_t p) {
+__device__ __forceinline__ bool preamble_at_guarded(const uint8_t *iq, int64_t lo, int64_t hi, const Lut lut, uint32_t p) {
     int m[15];
 #pragma unroll
-    for (int t = 0; t < 15; t++) m[t] = mag_of(s_lut, load_sample<true>(iq, (int64_t)p + t, lo, hi));
+    for (int t = 0; t < 15; t++) m[t] = mag_of(lut, load_sample<true>(iq, (int64_t)p + t, lo, hi));
     struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
     return modes_preamble_exact(Win{m});
 }
 // Fast form: the 15 samples are two 16-byte loads at a 2-byte aligned address (unaligned-access mode, raw buffer
 // descriptor); voff = byte offset of sample p from the descriptor's base.
-__device__ __forceinline__ bool preamble_at_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const uint16_t *s_lut) {
+__device__ __forceinline__ bool preamble_at_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const Lut lut) {
     const u32x4 wa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0), wb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16u, 0, 0);
     const uint32_t w[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
     int m[16];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t idx = pk_lut_index(w[i]);
-        m[2 * i] = s_lut[idx & 0xffffu];
-        m[2 * i + 1] = s_lut[idx >> 16];
+        m[2 * i] = lut[idx & 0xffffu];
+        m[2 * i + 1] = lut[idx >> 16];
     }
     struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
     return modes_preamble_exact(Win{m});
@@ -723,14 +746,14 @@ __device__ __forceinline__ void half_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
 }
 // Returns this lane's part of the sum.  *first: flags of the lane's first four pairs (pairs 4t .. 4t+3 of
 // the 56), bit k = |lo - hi| < 256, bit 4 + k = lo > hi, bit 8 = (lo == hi) of its first pair.
-__device__ __forceinline__ uint32_t half_eval(const u32x4 (&w)[4], const uint16_t *s_lut, uint32_t *first) {
+__device__ __forceinline__ uint32_t half_eval(const u32x4 (&w)[4], const Lut lut, uint32_t *first) {
     uint32_t acc = 0, f = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t idx = pk_lut_index(w[i][k]);                      // both LUT indices
-            const uint32_t a = s_lut[idx & 0xffffu], b = s_lut[idx >> 16];
+            const uint32_t a = lut[idx & 0xffffu], b = lut[idx >> 16];
             if (i == 0 && first) {
                 const uint32_t d = __builtin_amdgcn_sad_u16(a, b, 0u);
                 f |= (d < 256u ? 1u : 0u) << k | (a > b ? 1u : 0u) << (4 + k);
@@ -745,42 +768,63 @@ __device__ __forceinline__ uint32_t half_eval(const u32x4 (&w)[4], const uint16_
     return acc;
 }
 __device__ __forceinline__ void surv_push(uint32_t *list, uint32_t k, uint32_t p, uint32_t sum56, uint32_t sum112) {
-    list[3 * k] = p;
-    list[3 * k + 1] = sum56;
-    list[3 * k + 2] = sum112;
+    list[4 * k] = p;                                                         // [4k + 3]: the rank, filled in by stage 3
+    list[4 * k + 1] = sum56;
+    list[4 * k + 2] = sum112;
 }
 
-// Full demodulation of one preamble by the whole wavefront (both attempts) -> record.
-// known56 / known112: the delta sums of dump1090.c:1713-1717 as far as the pre-test computed them.
+// First half of the demodulation of one preamble by the whole wavefront: magnitudes, the delta sums of
+// dump1090.c:1713-1717 as far as they are needed, the first slicing pass and its noise gate.
+// known56 / known112: the sums the pre-test already has (kUnknown otherwise).  lut: the magnitude table in
+// global memory (64 KiB, read through L1/L2: the hot entries - small powers - stay in the CU's L1).
+struct Front {
+    int lo1, hi1, lo2, hi2, pre;
+    int sum56, sum112;
+    bool have112, gate0;
+    modes_m128 bits0;
+    uint8_t err0;
+};
 template <bool GUARD>
-__device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t *s_lut, const uint32_t *s_esyn, uint32_t *wg_counts,
-                                           RecCursor &cur, int lane, int64_t pc, uint32_t known56, uint32_t known112) {
+__device__ __forceinline__ Front demod_front(const DemodParams &P, const Lut lut, int lane, int64_t pc, uint32_t known56,
+                                             uint32_t known112) {
     const uint8_t *iq = P.iq;
     const int64_t lo = P.lo, hi = P.hi;
+    const bool two = lane < 48;
+    Front f;
+    // lane L: pairs k1 = L, k2 = L+64 -> samples 16+2k, 17+2k; lanes 0..11 also m[-1..10]
+    f.lo1 = mag_of(lut, load_sample<GUARD>(iq, pc + 16 + 2 * lane, lo, hi));
+    f.hi1 = mag_of(lut, load_sample<GUARD>(iq, pc + 17 + 2 * lane, lo, hi));
+    f.lo2 = two ? mag_of(lut, load_sample<GUARD>(iq, pc + 144 + 2 * lane, lo, hi)) : 0;
+    f.hi2 = two ? mag_of(lut, load_sample<GUARD>(iq, pc + 145 + 2 * lane, lo, hi)) : 0;
+    f.pre = (lane < 12) ? mag_of(lut, load_sample<GUARD>(iq, pc - 1 + lane, lo, hi)) : 0;
+    f.sum56 = (int)known56;
+    f.sum112 = (int)known112;
+    f.have112 = known112 != kUnknown;
+    if (known56 == kUnknown) { delta_sums(lane, f.lo1, f.hi1, f.lo2, f.hi2, &f.sum56, &f.sum112); f.have112 = true; }
+    f.bits0 = slice_pass(lane, f.lo1, f.hi1, f.lo2, f.hi2, &f.err0, nullptr, nullptr);
+    const bool long0 = modes_len_by_df(df_of_bits(f.bits0)) == 112;
+    if (long0 && !f.have112) { delta_sums(lane, f.lo1, f.hi1, f.lo2, f.hi2, &f.sum56, &f.sum112); f.have112 = true; }
+    f.gate0 = long0 ? (f.sum112 / 56 >= 2550) : (f.sum56 / 28 >= 2550);     // dump1090.c:1717-1723
+    return f;
+}
+
+// Full demodulation (both attempts) -> the record in staging slot `slot`, keyed `key`.  Returns false when the first
+// noise gate fails after all (then nothing is written; the caller has already ruled that out for its entries).
+template <bool GUARD>
+__device__ __forceinline__ bool demod_full(const DemodParams &P, const Lut lut, const uint32_t *s_esyn, int lane, int64_t pc,
+                                           uint32_t known56, uint32_t known112, uint32_t slot, uint64_t key) {
     const uint64_t g = (uint64_t)pc + P.g0;
     const uint32_t j = (uint32_t)(g & (MODES_BLOCK_STRIDE - 1));
     const bool two = lane < 48;
-    // lane L: pairs k1 = L, k2 = L+64 -> samples 16+2k, 17+2k; lanes 0..11 also m[-1..10]
-    const int lo1 = mag_of(s_lut, load_sample<GUARD>(iq, pc + 16 + 2 * lane, lo, hi));
-    const int hi1 = mag_of(s_lut, load_sample<GUARD>(iq, pc + 17 + 2 * lane, lo, hi));
-    const int lo2 = two ? mag_of(s_lut, load_sample<GUARD>(iq, pc + 144 + 2 * lane, lo, hi)) : 0;
-    const int hi2 = two ? mag_of(s_lut, load_sample<GUARD>(iq, pc + 145 + 2 * lane, lo, hi)) : 0;
-    const int pre = (lane < 12) ? mag_of(s_lut, load_sample<GUARD>(iq, pc - 1 + lane, lo, hi)) : 0;
-
-    // the delta sums of dump1090.c:1713-1717: what the pre-test already has (kUnknown otherwise), the rest on demand
-    int sum56 = (int)known56, sum112 = (int)known112;
-    bool have112 = known112 != kUnknown;
-    if (known56 == kUnknown) { delta_sums(lane, lo1, hi1, lo2, hi2, &sum56, &sum112); have112 = true; }
-    uint8_t err0;
-    const modes_m128 bits0 = slice_pass(lane, lo1, hi1, lo2, hi2, &err0, nullptr, nullptr);
-    const bool long0 = modes_len_by_df(df_of_bits(bits0)) == 112;
-    if (long0 && !have112) { delta_sums(lane, lo1, hi1, lo2, hi2, &sum56, &sum112); have112 = true; }
-    const bool gate0 = long0 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
-    if (!gate0) return;                                                      // dump1090.c:1723-1726: position ends
+    Front f = demod_front<GUARD>(P, lut, lane, pc, known56, known112);
+    if (!f.gate0) return false;                                              // dump1090.c:1723-1726: position ends
+    const int lo1 = f.lo1, hi1 = f.hi1, lo2 = f.lo2, hi2 = f.hi2, pre = f.pre;
+    const modes_m128 bits0 = f.bits0;
+    const uint8_t err0 = f.err0;
 
     uint8_t err1 = err0;
     modes_m128 bits1 = bits0;
-    bool gate1 = gate0;
+    bool gate1 = true;
     if (j != 0) {                                                            // dump1090.c:1660
         uint32_t up, dn;
         const bool backward = modes_phase_factors(
@@ -816,68 +860,61 @@ __device__ __forceinline__ void demod_full(const DemodParams &P, const uint16_t 
         bits1 = slice_pass(lane, nlo1, nhi1, nlo2, nhi2, &err1, nullptr, nullptr);
         // the gate of the retry: uncorrected deltas, the retry's own length (dump1090.c:1708-1723)
         const bool long1 = modes_len_by_df(df_of_bits(bits1)) == 112;
-        if (long1 && !have112) delta_sums(lane, lo1, hi1, lo2, hi2, &sum56, &sum112);
-        gate1 = long1 ? (sum112 / 56 >= 2550) : (sum56 / 28 >= 2550);
+        if (long1 && !f.have112) delta_sums(lane, lo1, hi1, lo2, hi2, &f.sum56, &f.sum112);
+        gate1 = long1 ? (f.sum112 / 56 >= 2550) : (f.sum56 / 28 >= 2550);
     }
     // syndromes and repair positions: the whole wavefront, both attempts (wave-uniform results)
     const AttemptFix f0 = wave_finish_attempt(bits0, true, P.maxfix, lane, s_esyn);
     const AttemptFix f1 = wave_finish_attempt(bits1, gate1, P.maxfix, lane, s_esyn);
-    if (cur.next == cur.end) {                                               // wave-uniform: reserve the next block
-        uint32_t base = 0;
-        if (lane == 0) {
-            base = atomicAdd(&P.hdr->n_records, kRecChunk);
-            atomicAdd(&wg_counts[2], kRecChunk);
-        }
-        cur.next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        cur.end = cur.next + kRecChunk;
+    if (lane == 0 && slot < P.max_records) {
+        modes_record *rec = &P.staging[slot];
+        rec->block = (uint32_t)(g / MODES_BLOCK_STRIDE);
+        rec->j = j;
+        store_attempt(&rec->att[0], bits0, err0, true, f0);
+        store_attempt(&rec->att[1], bits1, err1, gate1, f1);
+        P.keys[slot] = key;
     }
-    const uint32_t idx = cur.next++;
-    if (lane == 0) {
-        atomicAdd(&wg_counts[0], 1u);
-        if (idx < P.max_records) {
-            modes_record *rec = &P.records[idx];
-            rec->block = (uint32_t)(g / MODES_BLOCK_STRIDE);
-            rec->j = j;
-            store_attempt(&rec->att[0], bits0, err0, true, f0);
-            store_attempt(&rec->att[1], bits1, err1, gate1, f1);
-        }
-    }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------
 // demod_kernel - persistent workgroups; a workgroup takes a batch of kDemodGroup consecutive runs at a
-// time and walks the concatenation of their slot lists kDemodThreads positions per block, all eight
-// wavefronts together (the work per run varies several-fold; the sum over a batch does not):
+// time and walks the concatenation of their (ascending) slot lists kDemodThreads positions per block,
+// all its wavefronts together (the work per run varies several-fold; the sum over a batch does not):
 //   stage 1: one thread per forwarded position: exact preamble predicate (dump1090.c:1602-1650)
-//            on LUT magnitudes; survivors compacted into a workgroup list (the "valid preambles"
+//            on table magnitudes; survivors compacted into a workgroup list (the "valid preambles"
 //            of --stats).
 //   stage 2: noise-gate pre-test (dump1090.c:1713-1723), kGateLanes lanes per preamble:
 //            a) the first 56 bit pairs: their sum of |lo-hi|, and from the first six pairs the DF of
 //               the first slicing pass, i.e. the message length the gate is evaluated on - a short
 //               message is decided here, a long one queues for b) its other 56 pairs.
 //            A position that fails ends here (nearly every preamble found in noise).
-//   stage 3: one wavefront per survivor, all 64 lanes cooperating (coalesced sample loads; the
-//            sequential parts of the reference become carry chains, see modes_core.h): both attempts,
-//            then syndrome and repair search.  Positions whose first noise gate passes become records.
+//   stage 3: the survivors ARE the records of the block (the few next to an end of the span get their
+//            gate decided first, with guarded loads).  They are ranked by position, their staging slots
+//            reserved with one global atomic, then one wavefront per survivor, all 64 lanes cooperating
+//            (coalesced sample loads; the sequential parts of the reference become carry chains, see
+//            modes_core.h): both attempts, syndrome and repair search -> record + (batch, rank) key.
 // Lists live in LDS; appends from stages 2a/2b reserve their slots with one LDS atomic per wavefront.
+// The workgroup that retires last turns the per-batch record counts into offsets for order_kernel.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80))) void demod_kernel(DemodParams P) {
-    __shared__ __attribute__((aligned(16))) uint16_t s_lut[kLutVec * 8];
+__global__ __launch_bounds__(kDemodThreads) void demod_kernel(DemodParams P) {
     __shared__ uint32_t s_pre[kDemodGroup + 1];        // exclusive prefix of the batch's (clamped) run counts
     __shared__ uint32_t s_list[kDemodThreads];         // preambles awaiting the gate pre-test
     __shared__ uint32_t s_long[2 * kDemodThreads];     // (position, sum over the first 56 pairs) of those that decode as long
-    __shared__ uint32_t s_surv[3 * kDemodThreads];     // (position, the two delta sums or kUnknown) of those that go to stage 3
+    __shared__ uint32_t s_surv[4 * kDemodThreads];     // (position, the two delta sums or kUnknown, rank) of those that go to stage 3
     __shared__ uint32_t s_n[2][4];                     // list counters of the current / the next block (see stage 1)
+    __shared__ uint32_t s_blk[4];                      // [0] survivors dropped by the edge gate, [1] staging base, [2] records of the block
     __shared__ uint32_t s_esyn[112];
     __shared__ unsigned long long s_tot[2];
-    __shared__ uint32_t s_flags[3];            // records written by this workgroup, slot-list overflow seen, slots reserved
+    __shared__ uint32_t s_flags[2];                    // records written by this workgroup, WgTotals.flags
+    __shared__ uint32_t s_last;
 #ifdef MODES_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
-    stage_lut<kDemodThreads>(s_lut, P.tab.lut);
     if (threadIdx.x < 112) s_esyn[threadIdx.x] = P.tab.esyn[threadIdx.x];
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
-    if (threadIdx.x < 3) s_flags[threadIdx.x] = 0;
+    if (threadIdx.x < 2) s_flags[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_blk[threadIdx.x] = 0;
     if (threadIdx.x < 8) s_n[threadIdx.x >> 2][threadIdx.x & 3] = 0;
     __syncthreads();
 #ifdef MODES_TRACE
@@ -888,10 +925,11 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint8_t *iq = P.iq;
+    const Lut lut{__builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(P.tab.lut), 0, MODES_LUT_ENTRIES * 2, 0x00020000)};
     const int64_t lo = P.lo, hi = P.hi;
     const uint64_t below = (1ull << lane) - 1;
     unsigned long long tot_fwd = 0, tot_cand = 0;       // tot_fwd: per lane of wavefront 0; tot_cand: workgroup-uniform
-    RecCursor cur{0, 0};
+    uint32_t tot_rec = 0;                               // workgroup-uniform
     uint32_t blk = 0;                                   // blocks processed so far: parity selects the counter set
 #ifdef MODES_TRACE
     unsigned long long tr_t[4] = {0, 0, 0, 0};          // batch set-up, stage 1, stage 2a, stages 2b + 3
@@ -900,8 +938,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
 #define TRACE_ADD(k, since)
 #endif
 
-    const uint32_t nbatches = (P.nruns + kDemodGroup - 1) / kDemodGroup;
-    for (uint32_t batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
+    for (uint32_t batch = blockIdx.x; batch < P.nbatches; batch += gridDim.x) {
         const uint32_t run0 = batch * kDemodGroup;
         TRACE_T(tb0);
         // every position of the batch is >= gbase: 32-bit byte offsets from there through a raw buffer descriptor
@@ -929,6 +966,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
         const uint32_t n = s_pre[kDemodGroup];                               // forwarded positions of the batch
         TRACE_ADD(0, tb0);
         uint32_t ncand = 0;
+        uint32_t prior = 0;                                                  // records of the batch's earlier blocks
         const uint64_t cand_base = (uint64_t)batch * kDemodGroup * P.slot_cap;
         // position number e of the batch: entry e - s_pre[rr] of run rr, the last run that starts at or before e
         auto slot_of = [&](uint32_t e) -> uint32_t {
@@ -950,8 +988,8 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
             // fast path when every lane's 16-sample window is inside the span (wave-uniform test)
             const bool in1 = !active || samples_inside((int64_t)p, (int64_t)p + 15, lo, hi);
             bool ok;
-            if (__all(in1)) ok = active && preamble_at_fast(rsrc, (uint32_t)(2 * ((int64_t)p - gbase)), s_lut);
-            else            ok = active && preamble_at_guarded(iq, lo, hi, s_lut, p);
+            if (__all(in1)) ok = active && preamble_at_fast(rsrc, (uint32_t)(2 * ((int64_t)p - gbase)), lut);
+            else            ok = active && preamble_at_guarded(iq, lo, hi, lut, p);
             // Preambles whose whole message window (samples p-1 .. p+239) lies inside the span go to the
             // pre-test list; the few next to an end of the span go straight to stage 3 (guarded loads).
             const bool whole = samples_inside((int64_t)p - 1, (int64_t)p + 239, lo, hi);
@@ -1002,7 +1040,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
                     const bool gact = nact;
                     if (c0 + kGatePerRound < nlist) issue(c0 + kGatePerRound);
                     uint32_t first;
-                    uint32_t d56 = half_eval(w, s_lut, &first);
+                    uint32_t d56 = half_eval(w, lut, &first);
 #pragma unroll
                     for (int o = kGateLanes / 2; o >= 1; o >>= 1) d56 += (uint32_t)__shfl_xor((int)d56, o, 64);
                     // lane 1 of the group holds pairs 4, 5; pairs 0..3 come from lane 0
@@ -1043,7 +1081,7 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
                     if (gact) {
                         u32x4 w[4];
                         half_load(rsrc, (uint32_t)(2 * ((int64_t)pc - gbase)) + 32u + 224u, t, w);
-                        d112 = half_eval(w, s_lut, nullptr);
+                        d112 = half_eval(w, lut, nullptr);
                     }
 #pragma unroll
                     for (int o = kGateLanes / 2; o >= 1; o >>= 1) d112 += (uint32_t)__shfl_xor((int)d112, o, 64);
@@ -1059,17 +1097,64 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
             __syncthreads();
             // ---------------- stage 3 ----------------
             const uint32_t nsurv = cn[1];
-            for (uint32_t k = (uint32_t)wave; k < nsurv; k += kDemodWaves) {
-                const int64_t pcs = (int64_t)s_surv[3 * k];
-                const uint32_t k56 = s_surv[3 * k + 1], k112 = s_surv[3 * k + 2];
-                if (samples_inside(pcs - 1, pcs + 239, lo, hi)) demod_full<false>(P, s_lut, s_esyn, s_flags, cur, lane, pcs, k56, k112);
-                else                                            demod_full<true>(P, s_lut, s_esyn, s_flags, cur, lane, pcs, k56, k112);
+            if (nsurv) {                                                     // workgroup-uniform
+                // a) survivors that skipped the pre-test: first gate now (guarded loads); a failure drops the entry
+                for (uint32_t k = (uint32_t)wave; k < nsurv; k += kDemodWaves) {
+                    if (s_surv[4 * k + 1] != kUnknown) continue;             // wave-uniform
+                    const Front f = demod_front<true>(P, lut, lane, (int64_t)s_surv[4 * k], kUnknown, kUnknown);
+                    if (lane == 0) {
+                        if (f.gate0) {
+                            s_surv[4 * k + 1] = (uint32_t)f.sum56;
+                            s_surv[4 * k + 2] = f.have112 ? (uint32_t)f.sum112 : kUnknown;
+                        } else {
+                            s_surv[4 * k] = kNoPos;
+                            atomicAdd(&s_blk[0], 1u);
+                        }
+                    }
+                }
+                __syncthreads();
+                // b) rank by position (the block's records in stream order), one global atomic for their staging slots
+                if ((uint32_t)tid < nsurv) {
+                    const uint32_t mine = s_surv[4 * tid];
+                    uint32_t r = 0;
+                    for (uint32_t k = 0; k < nsurv; k++) r += s_surv[4 * k] < mine ? 1u : 0u;   // kNoPos is never below a live one
+                    s_surv[4 * tid + 3] = r;
+                }
+                if (tid == 0) {
+                    const uint32_t live = nsurv - s_blk[0];
+                    s_blk[0] = 0;
+                    s_blk[2] = live;
+                    s_blk[1] = live ? atomicAdd(&P.hdr->n_records, live) : 0u;
+                }
+                __syncthreads();
+                // c) one wavefront per record
+                const uint32_t sbase = s_blk[1], live = s_blk[2];
+                for (uint32_t k = (uint32_t)wave; k < nsurv; k += kDemodWaves) {
+                    const uint32_t pk = s_surv[4 * k];
+                    if (pk == kNoPos) continue;
+                    const int64_t pcs = (int64_t)pk;
+                    const uint32_t k56 = s_surv[4 * k + 1], k112 = s_surv[4 * k + 2], rank = s_surv[4 * k + 3];
+                    const uint32_t slot = sbase + rank;
+                    const uint64_t key = ((uint64_t)batch << 32) | (uint64_t)(prior + rank);
+                    bool done;
+                    if (samples_inside(pcs - 1, pcs + 239, lo, hi)) done = demod_full<false>(P, lut, s_esyn, lane, pcs, k56, k112, slot, key);
+                    else                                            done = demod_full<true>(P, lut, s_esyn, lane, pcs, k56, k112, slot, key);
+                    if (!done && lane == 0) {                                // cannot happen: the pre-test IS the first gate
+                        if (slot < P.max_records) P.keys[slot] = kNoKey;
+                        atomicOr(&s_flags[1], 2u);
+                    }
+                }
+                prior += live;
+                __syncthreads();
             }
-            __syncthreads();
             TRACE_ADD(3, ts3);
         }
         tot_cand += ncand;
-        if (tid == 0) P.cand_counts[batch] = ncand;
+        tot_rec += prior;
+        if (tid == 0) {
+            P.cand_counts[batch] = ncand;
+            P.batch_count[batch] = prior;
+        }
         __syncthreads();                                                     // s_pre is rewritten by the next batch
     }
 #ifdef MODES_TRACE
@@ -1082,16 +1167,72 @@ __global__ __launch_bounds__(kDemodThreads) __attribute__((amdgpu_num_sgpr(80)))
         }
     }
 #endif
-    // the unused tail of this wavefront's last block of record slots
-    for (uint32_t i = cur.next + (uint32_t)lane; i < cur.end; i += 64)
-        if (i < P.max_records) P.records[i].block = kInvalidBlock;
-    // totals (tot_fwd: lanes of wavefront 0; tot_cand: the same number in every thread)
+    // totals (tot_fwd: lanes of wavefront 0; tot_cand, tot_rec: the same number in every thread)
     if (wave == 0) {
         tot_fwd = (unsigned long long)wave_sum((int)tot_fwd);                // < 2^31 per workgroup and call (slot lists are u32-indexed)
         if (lane == 0) { s_tot[0] = tot_fwd; s_tot[1] = tot_cand; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) P.host_totals[blockIdx.x] = WgTotals{s_tot[0], s_tot[1], s_flags[0], s_flags[2], s_flags[1], 0};
+    if (tid == 0) {
+        P.host_totals[blockIdx.x] = WgTotals{s_tot[0], s_tot[1], tot_rec, s_flags[1], {0, 0}};
+        __threadfence();                                                     // this workgroup's batch counts before its ticket
+        s_last = atomicAdd(&P.hdr->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && wave == 0) {
+        // every workgroup has retired: batch_count is complete (read past the L1: other CUs wrote it)
+        __threadfence();
+        uint32_t running = 0;
+        for (uint32_t b0 = 0; b0 < P.nbatches; b0 += 64) {
+            const uint32_t b = b0 + (uint32_t)lane;
+            const uint32_t c = b < P.nbatches ? __hip_atomic_load(&P.batch_count[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            if (b < P.nbatches) P.batch_off[b] = running + incl - c;
+            running += (uint32_t)__shfl((int)incl, 63, 64);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// order_kernel - staging (completion order) -> the final list in stream order: record of key (batch, rank)
+// goes to batch_off[batch] + rank.  Four lanes per record (16 bytes each).  Lists of at most direct_cap
+// records are ALSO written straight to the host's pinned copy, so that a sparse call needs no copy
+// operation (and no second synchronisation) at all; d_count receives the number of records on the device
+// (what a gather over RCCL exchanges first).
+// ------------------------------------------------------------------------------------
+struct OrderParams {
+    const ResultHeader *hdr;
+    const modes_record *staging;
+    const uint64_t *keys;
+    const uint32_t *batch_off;
+    modes_record *out;             // device, max_records
+    modes_record *host_out;        // device view of the pinned host list, or nullptr
+    unsigned long long *d_count;   // optional
+    uint32_t max_records;
+    uint32_t direct_cap;
+};
+__global__ __launch_bounds__(256) void order_kernel(OrderParams P) {
+    const uint32_t total = P.hdr->n_records;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.d_count) *P.d_count = total;
+    const uint32_t n = min(total, P.max_records);
+    const bool direct = P.host_out != nullptr && total <= P.direct_cap;
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.staging);
+    uint4 *dst = reinterpret_cast<uint4 *>(P.out), *hdst = reinterpret_cast<uint4 *>(P.host_out);
+    const uint64_t npieces = 4ull * n;
+    for (uint64_t piece = (uint64_t)blockIdx.x * 256 + threadIdx.x; piece < npieces; piece += (uint64_t)gridDim.x * 256) {
+        const uint64_t key = P.keys[piece >> 2];
+        if (key == kNoKey) continue;
+        const uint64_t dest = (uint64_t)P.batch_off[key >> 32] + (uint32_t)key;
+        if (dest >= P.max_records) continue;
+        const uint4 v = src[piece];
+        dst[4 * dest + (piece & 3)] = v;
+        if (direct) hdst[4 * dest + (piece & 3)] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1180,7 +1321,7 @@ struct modes_gpu {
     int maxfix = 1;
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // before / after the scan kernel, results on the host
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // before / after the scan kernel, after the demod kernel, results ready
     std::string err;
 
     uint16_t *d_lut = nullptr;
@@ -1189,20 +1330,23 @@ struct modes_gpu {
     // per-detect scratch (grown on demand)
     uint32_t *d_slots = nullptr;      size_t slots_bytes = 0;
     uint32_t *d_cand_slots = nullptr; size_t cand_slots_bytes = 0;
-    uint32_t *d_counts = nullptr;     size_t counts_elems = 0;       // counts | cand_counts
+    uint32_t *d_counts = nullptr;     size_t counts_elems = 0;       // counts | cand_counts | batch_count | batch_off
     uint64_t *d_cand_offsets = nullptr;
     uint64_t *d_cand_dense = nullptr; size_t cand_dense_elems = 0;
-    modes_record *d_records = nullptr;
+    modes_record *d_staging = nullptr;  // records in completion order + their keys
+    uint64_t *d_keys = nullptr;
+    modes_record *d_records = nullptr;  // the ordered list (own allocation; unused while the caller supplies one)
+    modes_record *d_user_records = nullptr;   // modes_gpu_set_output
+    unsigned long long *d_user_count = nullptr;
+    uint32_t list_cap = 0;              // capacity of d_staging / d_keys / d_records / h_records
     ResultHeader *d_hdr = nullptr;
 
     WgTotals *h_totals = nullptr;     // pinned + mapped, one per demod workgroup
     WgTotals *h_totals_dev = nullptr;
     uint32_t demod_grid = 0;          // workgroups of the demod launch in flight
-    modes_record *h_records = nullptr;  // pinned, max_records
+    modes_record *h_records = nullptr;  // pinned + mapped, list_cap
+    modes_record *h_records_dev = nullptr;
     std::vector<uint64_t> h_cands;
-    modes_order_scratch order_scratch;
-    int order_threads = 1;            // threads that put a long record list in order (modes_order.h)
-    std::vector<modes_record> h_sorted;
 
     uint8_t *d_stage = nullptr;       size_t stage_bytes = 0;
 
@@ -1213,11 +1357,12 @@ struct modes_gpu {
 
     // geometry of the detect in flight
     bool in_flight = false;
-    uint32_t nruns = 0, slot_cap = 0;
+    uint32_t nruns = 0, slot_cap = 0, nbatches = 0;
     uint64_t g0 = 0;
 };
 
-static std::string g_create_error;
+// text of the last failed create: per thread, so that hosts which create one context per thread (one per GPU) do not race
+static thread_local char g_create_error[512] = "";
 
 static int fail(modes_gpu *ctx, int code, const char *fmt, ...) {
     char buf[512];
@@ -1225,7 +1370,8 @@ static int fail(modes_gpu *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf; else g_create_error = buf;
+    if (ctx) ctx->err = buf;
+    else { strncpy(g_create_error, buf, sizeof g_create_error - 1); g_create_error[sizeof g_create_error - 1] = 0; }
     return code;
 }
 
@@ -1250,11 +1396,28 @@ static int grid_for(uint64_t items, int per_block) {
     return (int)std::max<uint64_t>(1, std::min<uint64_t>(b, 256 * 8));
 }
 
+// (re)allocate the record lists for `cap` records: staging + keys + the ordered list on the device, the pinned host copy
+static int alloc_lists(modes_gpu *ctx, uint32_t cap) {
+    if (ctx->d_staging) (void)hipFree(ctx->d_staging);
+    if (ctx->d_keys) (void)hipFree(ctx->d_keys);
+    if (ctx->d_records) (void)hipFree(ctx->d_records);
+    if (ctx->h_records) (void)hipHostFree(ctx->h_records);
+    ctx->d_staging = nullptr; ctx->d_keys = nullptr; ctx->d_records = nullptr; ctx->h_records = nullptr; ctx->h_records_dev = nullptr;
+    ctx->list_cap = 0;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_staging), (size_t)cap * sizeof(modes_record)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_keys), (size_t)cap * sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_records), (size_t)cap * sizeof(modes_record)));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_records), (size_t)cap * sizeof(modes_record), hipHostMallocMapped));
+    HIP_TRY(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_records_dev), ctx->h_records, 0));
+    ctx->list_cap = cap;
+    return MODES_OK;
+}
+
 extern "C" {
 
 int modes_gpu_abi_version(void) { return MODES_GFX950_ABI; }
 
-const char *modes_gpu_last_error(const modes_gpu *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *modes_gpu_last_error(const modes_gpu *ctx) { return ctx ? ctx->err.c_str() : g_create_error; }
 
 int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     if (!cfg || !out) return fail(nullptr, MODES_ERR_ARG, "modes_gpu_create: null argument");
@@ -1266,11 +1429,11 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     modes_gpu *ctx = new (std::nothrow) modes_gpu;
     if (!ctx) return fail(nullptr, MODES_ERR_NOMEM, "out of memory");
     ctx->cfg = *cfg;
-    ctx->order_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     ctx->auto_records = ctx->cfg.max_records == 0;
-    if (ctx->auto_records) ctx->cfg.max_records = 1u << 20;
+    if (ctx->auto_records) ctx->cfg.max_records = 1u << 18;          // 16 MiB of records; grows on demand
+    if (ctx->cfg.direct_records == 0) ctx->cfg.direct_records = 4096;
     ctx->maxfix = cfg->fix_errors ? (cfg->aggressive ? 2 : 1) : 0;
-    auto bail = [&](int rc) { g_create_error = ctx->err; modes_gpu_destroy(ctx); return rc; };
+    auto bail = [&](int rc) { fail(nullptr, rc, "%s", ctx->err.c_str()); modes_gpu_destroy(ctx); return rc; };
 #define CREATE_TRY(call)                                                                              \
     do {                                                                                              \
         hipError_t e_ = (call);                                                                       \
@@ -1298,13 +1461,11 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_esyn), sizeof esyn));
     CREATE_TRY(hipMemcpy(ctx->d_lut, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(ctx->d_esyn, esyn, sizeof esyn, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_records), (size_t)ctx->cfg.max_records * sizeof(modes_record)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hdr), sizeof(ResultHeader)));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_totals), sizeof(WgTotals) * ctx->demod_wgs, hipHostMallocMapped));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_totals_dev), ctx->h_totals, 0));
-    CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_records), (size_t)ctx->cfg.max_records * sizeof(modes_record),
-                             hipHostMallocDefault));
 #undef CREATE_TRY
+    if (alloc_lists(ctx, ctx->cfg.max_records) != MODES_OK) return bail(MODES_ERR_NOMEM);
     *out = ctx;
     return MODES_OK;
 }
@@ -1312,10 +1473,10 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
 void modes_gpu_destroy(modes_gpu *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
-    if (ctx->in_flight && ctx->ev[2]) (void)hipEventSynchronize(ctx->ev[2]);   // kernels of a detect nobody fetched
+    if (ctx->in_flight && ctx->ev[3]) (void)hipEventSynchronize(ctx->ev[3]);   // kernels of a detect nobody fetched
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     void *dev[] = {ctx->d_lut, ctx->d_esyn, ctx->d_slots, ctx->d_cand_slots, ctx->d_counts, ctx->d_cand_offsets,
-                   ctx->d_cand_dense, ctx->d_records, ctx->d_hdr, ctx->d_stage};
+                   ctx->d_cand_dense, ctx->d_staging, ctx->d_keys, ctx->d_records, ctx->d_hdr, ctx->d_stage};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
@@ -1324,6 +1485,24 @@ void modes_gpu_destroy(modes_gpu *ctx) {
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+int modes_gpu_set_output(modes_gpu *ctx, void *d_records, uint64_t capacity, void *d_count) {
+    if (!ctx) return MODES_ERR_ARG;
+    if (ctx->in_flight) return fail(ctx, MODES_ERR_STATE, "set_output: a detect is in flight on this context");
+    if (d_records && (capacity == 0 || capacity > 0xFFFFFFFFull || (reinterpret_cast<uintptr_t>(d_records) & 15)))
+        return fail(ctx, MODES_ERR_ARG, "set_output: the list must be 16-byte aligned and hold 1 .. 2^32-1 records");
+    if (d_count && (reinterpret_cast<uintptr_t>(d_count) & 7)) return fail(ctx, MODES_ERR_ARG, "set_output: d_count must be 8-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    ctx->d_user_records = static_cast<modes_record *>(d_records);
+    ctx->d_user_count = static_cast<unsigned long long *>(d_count);
+    if (d_records) {
+        // the caller's list cannot grow: its capacity is the capacity of the call
+        ctx->auto_records = false;
+        ctx->cfg.max_records = (uint32_t)capacity;
+        if (ctx->list_cap < capacity) { int rc = alloc_lists(ctx, (uint32_t)capacity); if (rc != MODES_OK) return rc; }
+    }
+    return MODES_OK;
 }
 
 // `stream` is a hipStream_t; NULL is HIP's default stream (which is also what torch's default
@@ -1378,6 +1557,7 @@ int modes_gpu_fill(modes_gpu *ctx, void *d_out, uint64_t nbytes, uint8_t value, 
 int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     if (!ctx) return MODES_ERR_ARG;
     if (!span || !span->iq) return fail(ctx, MODES_ERR_ARG, "detect: null span");
+    if (ctx->in_flight) return fail(ctx, MODES_ERR_STATE, "detect: a detect is already in flight on this context (fetch it first)");
     if (span->nblocks == 0) return fail(ctx, MODES_ERR_ARG, "detect: nblocks == 0");
     if ((reinterpret_cast<uintptr_t>(span->iq) & 1) != 0) return fail(ctx, MODES_ERR_ARG, "detect: iq must be 2-byte aligned");
     if (span->stream_byte0 & 1) return fail(ctx, MODES_ERR_ARG, "detect: stream_byte0 must be even");
@@ -1413,7 +1593,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
 
     const uint64_t nchunks = (uint64_t)(p_end + kLookback + kChunkSamples - 1) / kChunkSamples;
     uint32_t R = ctx->cfg.run_chunks;
-    // automatic run length: long runs amortise a run's set-up in the scan (32 chunks is enough), but the
+    // automatic run length: long runs amortise a run's set-up in the scan (16 chunks is enough), but the
     // demod kernel wants at least one batch of kDemodGroup runs per resident workgroup
     if (R == 0) R = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(32, nchunks / ((uint64_t)kDemodGroup * ctx->demod_wgs)));
     if (R > 8192) return fail(ctx, MODES_ERR_ARG, "run_chunks=%u: at most 8192", R);
@@ -1424,19 +1604,21 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     if (cap > R * (uint32_t)kChunkSamples) cap = R * kChunkSamples;
 
     int rc;
-    const uint32_t ngroups = (nruns + kDemodGroup - 1) / kDemodGroup;       // demod_kernel's unit of work and of candidate lists
-    size_t want = (size_t)ngroups * kDemodGroup * cap * sizeof(uint32_t);
+    const uint32_t nbatches = (nruns + kDemodGroup - 1) / kDemodGroup;      // demod_kernel's unit of work, of candidate lists and of record order
+    size_t want = (size_t)nbatches * kDemodGroup * cap * sizeof(uint32_t);
     if ((rc = grow(ctx, &ctx->d_slots, &ctx->slots_bytes, want)) != MODES_OK) return rc;
     if (ctx->cfg.keep_candidates && (rc = grow(ctx, &ctx->d_cand_slots, &ctx->cand_slots_bytes, want)) != MODES_OK) return rc;
     if (ctx->counts_elems < nruns) {
         if (ctx->d_counts) (void)hipFree(ctx->d_counts);
         if (ctx->d_cand_offsets) (void)hipFree(ctx->d_cand_offsets);
         ctx->d_counts = nullptr; ctx->d_cand_offsets = nullptr; ctx->counts_elems = 0;
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_counts), (size_t)nruns * 2 * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_counts), (size_t)nruns * 4 * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_cand_offsets), (size_t)nruns * sizeof(uint64_t)));
         ctx->counts_elems = nruns;
     }
-    uint32_t *d_counts = ctx->d_counts, *d_cand_counts = ctx->d_counts + nruns;
+    // counts [nruns] | cand_counts | batch_count | batch_off (nbatches <= nruns each)
+    uint32_t *d_counts = ctx->d_counts, *d_cand_counts = ctx->d_counts + nruns, *d_batch_count = ctx->d_counts + 2 * (size_t)nruns,
+             *d_batch_off = ctx->d_counts + 3 * (size_t)nruns;
 
     ScanParams sp{};
     sp.iq = base;
@@ -1467,13 +1649,28 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     dp.maxfix = ctx->maxfix;
     dp.cand_slots = ctx->cfg.keep_candidates ? ctx->d_cand_slots : nullptr;
     dp.cand_counts = d_cand_counts;
-    dp.records = ctx->d_records;
+    dp.staging = ctx->d_staging;
+    dp.keys = ctx->d_keys;
+    dp.batch_count = d_batch_count;
+    dp.batch_off = d_batch_off;
+    dp.nbatches = nbatches;
     dp.hdr = ctx->d_hdr;
     dp.host_totals = ctx->h_totals_dev;
     dp.max_records = ctx->cfg.max_records;
 
-    // The header is zeroed by the scan kernel itself, so a detect is exactly: scan, demod, (prefix,)
-    // 24-byte copy.  Events: around the scan (the roofline kernel) and after the copy.
+    OrderParams op{};
+    op.hdr = ctx->d_hdr;
+    op.staging = ctx->d_staging;
+    op.keys = ctx->d_keys;
+    op.batch_off = d_batch_off;
+    op.out = ctx->d_user_records ? ctx->d_user_records : ctx->d_records;
+    op.host_out = ctx->h_records_dev;
+    op.d_count = ctx->d_user_count;
+    op.max_records = ctx->cfg.max_records;
+    op.direct_cap = std::min(ctx->cfg.direct_records, ctx->cfg.max_records);
+
+    // The header is zeroed by the scan kernel itself, so a detect is exactly: scan, demod, order (, prefix).
+    // Events: around the scan (the roofline kernel), after the demod kernel, and when the results are complete.
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     if (ctx->cfg.scan_variant == 1)
         hipLaunchKernelGGL(scan_fused_kernel, dim3((nruns + kScanWaves - 1) / kScanWaves), dim3(kScanWaves * kWave), 0, st, sp);
@@ -1481,127 +1678,143 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
         hipLaunchKernelGGL(scan_kernel, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st, sp);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     // cfg.overlap: everything after the scan moves to the context's own stream (ordered behind the
-    // scan by ev[1]), so the next kernel on the caller's stream - typically another context's scan,
-    // which is issue-bound - runs concurrently with this latency-bound tail.
+    // scan by ev[1]), so the next kernel on the caller's stream - typically another context's scan -
+    // runs concurrently with this latency-bound tail: a demod workgroup (4 waves, < 10 KiB of LDS) fits on a
+    // CU next to the scan kernel's workgroups.
     hipStream_t st2 = st;
     if (ctx->cfg.overlap && st != ctx->own_stream) {
         st2 = ctx->own_stream;
         HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev[1], 0));
     }
-    ctx->demod_grid = std::min<uint32_t>(ngroups, ctx->demod_wgs);        // one batch of kDemodGroup runs per workgroup and turn
+    ctx->demod_grid = std::min<uint32_t>(nbatches, ctx->demod_wgs);        // one batch of kDemodGroup runs per workgroup and turn
     hipLaunchKernelGGL(demod_kernel, dim3(ctx->demod_grid), dim3(kDemodThreads), 0, st2, dp);
-    if (ctx->cfg.keep_candidates)
-        hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st2, d_cand_counts, ngroups, ctx->d_cand_offsets);
-    HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st2));
+    hipLaunchKernelGGL(order_kernel, dim3(512), dim3(256), 0, st2, op);
+    if (ctx->cfg.keep_candidates)
+        hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st2, d_cand_counts, nbatches, ctx->d_cand_offsets);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st2));
 
     ctx->last_stream = st;
     ctx->last_span = *span;
     ctx->in_flight = true;
     ctx->nruns = nruns;
+    ctx->nbatches = nbatches;
     ctx->slot_cap = cap;
     ctx->g0 = g0;
     return MODES_OK;
 }
 
-int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
-    if (!ctx) return MODES_ERR_ARG;
+// Common part of fetch / fetch_device: waits for the detect, handles the two overflow cases (which repeat the
+// call unless MODES_GPU_NO_RETRY), fills the counters of *res.  On return *n_out = records of the call.
+static int finish_detect(modes_gpu *ctx, modes_gpu_result *res, bool to_host) {
     if (!res) return fail(ctx, MODES_ERR_ARG, "fetch: null result");
     if (!ctx->in_flight) return fail(ctx, MODES_ERR_STATE, "fetch: no detect in flight");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     // Wait for THIS detect only (other work may already be queued behind it on the caller's stream);
     // what follows runs on the context's own stream.
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
     hipStream_t st = ctx->own_stream;
     ctx->in_flight = false;
     memset(res, 0, sizeof *res);
-    ResultHeader hdr{0, 0, 0, 0};
-    uint64_t n_reserved = 0;                                  // record slots handed out (>= records written)
+    uint64_t n_forwarded = 0, n_preambles = 0, n_records = 0;
+    uint32_t flags = 0;
     for (uint32_t b = 0; b < ctx->demod_grid; b++) {
         const WgTotals &t = ctx->h_totals[b];
-        hdr.n_forwarded += t.n_forwarded;
-        hdr.n_preambles += t.n_preambles;
-        hdr.n_records += t.n_records;
-        hdr.overflow |= t.overflow;
-        n_reserved += t.n_reserved;
+        n_forwarded += t.n_forwarded;
+        n_preambles += t.n_preambles;
+        n_records += t.n_records;
+        flags |= t.flags;
     }
-    if (hdr.overflow) {
+    const bool no_retry = (ctx->cfg.flags & MODES_GPU_NO_RETRY) != 0;
+    if (flags & 2u) return fail(ctx, MODES_ERR_HIP, "internal: the noise-gate pre-test and the full demodulation disagree");
+    if (flags & 1u) {
         // More than slot_cap positions of one run look like preambles (the automatic cap is 1/16 of
         // the positions; only a periodic, preamble-like signal gets there).  Nothing may be dropped:
         // with the automatic cap, repeat the call with worst-case lists and keep them from now on.
-        if (ctx->cfg.slot_cap != 0 || ctx->full_slots)
-            return fail(ctx, MODES_ERR_OVERFLOW, "scan forwarded more than slot_cap=%u positions in one run; raise slot_cap",
-                        ctx->slot_cap);
+        if (ctx->cfg.slot_cap != 0 || ctx->full_slots || no_retry) {
+            const bool can_grow = ctx->cfg.slot_cap == 0 && !ctx->full_slots;
+            ctx->full_slots = ctx->full_slots || can_grow;              // a resubmitted call gets the big lists
+            return fail(ctx, MODES_ERR_OVERFLOW, "scan forwarded more than slot_cap=%u positions in one run%s", ctx->slot_cap,
+                        can_grow ? "; resubmit the call (the lists are worst-case sized now)" : "; raise slot_cap");
+        }
         ctx->full_slots = true;
         const modes_gpu_span again = ctx->last_span;
         int rc = modes_gpu_detect(ctx, &again, ctx->last_stream);
         if (rc != MODES_OK) return rc;
-        return modes_gpu_fetch(ctx, res);
+        return finish_detect(ctx, res, to_host);
     }
-    if (n_reserved > ctx->cfg.max_records) {
-        // n_reserved is what the call needs (the counter keeps counting past the capacity).  With the
-        // automatic capacity, grow the list with some slack and repeat the call; nothing may be dropped.
-        const uint64_t want = n_reserved + (n_reserved >> 2) + 65536;
+    if (n_records > ctx->cfg.max_records) {
+        // With the automatic capacity, grow the lists with some slack and repeat the call; nothing may be dropped.
+        const uint64_t want = n_records + (n_records >> 2) + 65536;
+        res->n_records = n_records;                                     // what the call needs
         if (!ctx->auto_records || want > 0xFFFFFFFFull)
-            return fail(ctx, MODES_ERR_OVERFLOW, "%llu record slots exceed max_records=%u", (unsigned long long)n_reserved,
-                        ctx->cfg.max_records);
-        (void)hipFree(ctx->d_records); ctx->d_records = nullptr;
-        (void)hipHostFree(ctx->h_records); ctx->h_records = nullptr;
+            return fail(ctx, MODES_ERR_OVERFLOW, "%llu records exceed max_records=%u", (unsigned long long)n_records, ctx->cfg.max_records);
         ctx->cfg.max_records = (uint32_t)want;
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_records), (size_t)want * sizeof(modes_record)));
-        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_records), (size_t)want * sizeof(modes_record),
-                                   hipHostMallocDefault));
-        const modes_gpu_span again = ctx->last_span;
-        int rc = modes_gpu_detect(ctx, &again, ctx->last_stream);
+        int rc = alloc_lists(ctx, (uint32_t)want);
         if (rc != MODES_OK) return rc;
-        return modes_gpu_fetch(ctx, res);
+        if (no_retry)
+            return fail(ctx, MODES_ERR_OVERFLOW, "%llu records exceeded the list; it holds %llu now: resubmit the call",
+                        (unsigned long long)n_records, (unsigned long long)want);
+        const modes_gpu_span again = ctx->last_span;
+        rc = modes_gpu_detect(ctx, &again, ctx->last_stream);
+        if (rc != MODES_OK) return rc;
+        return finish_detect(ctx, res, to_host);
     }
-    if (n_reserved) {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_records, ctx->d_records, (size_t)n_reserved * sizeof(modes_record),
-                                    hipMemcpyDeviceToHost, st));
+    const modes_record *d_list = ctx->d_user_records ? ctx->d_user_records : ctx->d_records;
+    const uint32_t direct_cap = std::min(ctx->cfg.direct_records, ctx->cfg.max_records);
+    if (to_host && n_records > direct_cap) {                            // short lists are on the host already (order_kernel)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_records, d_list, (size_t)n_records * sizeof(modes_record), hipMemcpyDeviceToHost, st));
     }
-    if (ctx->cfg.keep_candidates && hdr.n_preambles) {
-        if (ctx->cand_dense_elems < hdr.n_preambles) {
+    if (ctx->cfg.keep_candidates && n_preambles) {
+        if (ctx->cand_dense_elems < n_preambles) {
             if (ctx->d_cand_dense) (void)hipFree(ctx->d_cand_dense);
             ctx->d_cand_dense = nullptr; ctx->cand_dense_elems = 0;
-            const size_t want = (size_t)hdr.n_preambles + (hdr.n_preambles >> 2) + 1024;
+            const size_t want = (size_t)n_preambles + (n_preambles >> 2) + 1024;
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_cand_dense), want * sizeof(uint64_t)));
             ctx->cand_dense_elems = want;
         }
-        const uint32_t ngroups = (ctx->nruns + kDemodGroup - 1) / kDemodGroup;
-        hipLaunchKernelGGL(compact_candidates_kernel, dim3((ngroups + 3) / 4), dim3(256), 0, st, ctx->d_cand_slots,
-                           ctx->d_counts + ctx->nruns, ctx->d_cand_offsets, ngroups, ctx->slot_cap * kDemodGroup, ctx->g0,
+        hipLaunchKernelGGL(compact_candidates_kernel, dim3((ctx->nbatches + 3) / 4), dim3(256), 0, st, ctx->d_cand_slots,
+                           ctx->d_counts + ctx->nruns, ctx->d_cand_offsets, ctx->nbatches, ctx->slot_cap * kDemodGroup, ctx->g0,
                            ctx->d_cand_dense);
         HIP_TRY(ctx, hipGetLastError());
-        ctx->h_cands.resize(hdr.n_preambles);
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cands.data(), ctx->d_cand_dense, (size_t)hdr.n_preambles * sizeof(uint64_t),
+        ctx->h_cands.resize(n_preambles);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cands.data(), ctx->d_cand_dense, (size_t)n_preambles * sizeof(uint64_t),
                                     hipMemcpyDeviceToHost, st));
     } else {
         ctx->h_cands.clear();
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    // within a run the production scan forwards positions in queue order: restore stream order
+    // candidates: the workgroup lists keep no order inside a block of positions
     std::sort(ctx->h_cands.begin(), ctx->h_cands.end());
-    // Records sit in the reserved slots in completion order, with invalid slots in between: put the
-    // valid ones in stream order (modes_order.h; long lists are partitioned and sorted by several threads).
-    const modes_record *sorted = ctx->h_records;
-    if (n_reserved) {
-        if (ctx->h_sorted.size() < n_reserved) ctx->h_sorted.resize(n_reserved);
-        const size_t n = modes_order_records(ctx->h_records, (size_t)n_reserved, kInvalidBlock, (uint32_t)ctx->last_span.first_block,
-                                             ctx->h_sorted.data(), ctx->order_scratch, ctx->order_threads);
-        if (n != hdr.n_records)
-            return fail(ctx, MODES_ERR_HIP, "record list inconsistent: %zu valid slots, %u records counted", n, hdr.n_records);
-        sorted = ctx->h_sorted.data();
-    }
-    res->records = sorted;
-    res->n_records = hdr.n_records;
+    res->records = to_host ? ctx->h_records : d_list;
+    res->n_records = n_records;
     res->candidates = ctx->h_cands.empty() ? nullptr : ctx->h_cands.data();
     res->n_candidates = ctx->h_cands.size();
-    res->n_forwarded = hdr.n_forwarded;
-    res->n_preambles = hdr.n_preambles;
+    res->n_forwarded = n_forwarded;
+    res->n_preambles = n_preambles;
     (void)hipEventElapsedTime(&res->scan_ms, ctx->ev[0], ctx->ev[1]);
-    (void)hipEventElapsedTime(&res->demod_ms, ctx->ev[1], ctx->ev[2]);      // demod (+ prefix) + header copy
+    (void)hipEventElapsedTime(&res->demod_ms, ctx->ev[1], ctx->ev[2]);
+    (void)hipEventElapsedTime(&res->order_ms, ctx->ev[2], ctx->ev[3]);      // order (+ candidate prefix)
     return MODES_OK;
+}
+
+int modes_gpu_stream_wait(modes_gpu *ctx, void *stream) {
+    if (!ctx) return MODES_ERR_ARG;
+    if (!ctx->in_flight) return fail(ctx, MODES_ERR_STATE, "stream_wait: no detect in flight");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamWaitEvent(static_cast<hipStream_t>(stream), ctx->ev[3], 0));
+    return MODES_OK;
+}
+
+int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res) {
+    if (!ctx) return MODES_ERR_ARG;
+    return finish_detect(ctx, res, true);
+}
+
+int modes_gpu_fetch_device(modes_gpu *ctx, modes_gpu_result *res) {
+    if (!ctx) return MODES_ERR_ARG;
+    return finish_detect(ctx, res, false);
 }
 
 int modes_gpu_submit_host(modes_gpu *ctx, const uint8_t *iq, uint64_t nbytes, uint64_t stream_byte0, uint64_t first_block,

@@ -377,6 +377,32 @@ uint64_t modes_host_resolve_to_array(modes_host *h, const modes_record *recs, ui
     return s.n;
 }
 
+namespace {
+struct RawSink {
+    modes_host *h;
+    char *out;
+    uint64_t cap, n, msgs;
+};
+void raw_sink(const struct modesMessage *mm, uint32_t, uint32_t, void *user) {
+    RawSink *s = static_cast<RawSink *>(user);
+    if (!modes_host_wants(s->h, mm)) return;
+    s->msgs++;
+    const int len = 3 + mm->msgbits / 4;                                          // '*' + hex + ';' + '\n'
+    if (s->out && s->n + (uint64_t)len + 1 <= s->cap) modes_format_raw(mm, s->out + s->n);
+    s->n += (uint64_t)len;
+}
+}  // namespace
+
+// The --raw listing of a batch straight into a text buffer (what `dump1090 --raw` prints for these buffers,
+// dump1090.c:1324-1326 behind the filter of :1803): the sink of the CLI's --raw mode without a callback per line.
+uint64_t modes_host_resolve_raw(modes_host *h, const modes_record *recs, uint64_t nrecs, const uint64_t *cands, uint64_t ncand,
+                                char *out, uint64_t cap, uint64_t *nbytes) {
+    RawSink s{h, out, cap, 0, 0};
+    modes_host_resolve(h, recs, nrecs, cands, ncand, raw_sink, &s);
+    if (nbytes) *nbytes = s.n;
+    return s.msgs;
+}
+
 static int format_hex_line(const struct modesMessage *mm, char *buf, const char *hex) {
     int n = 0;
     buf[n++] = '*';

@@ -127,6 +127,21 @@ class HostResolver:
         return int(self._lib.modes_host_resolve_to_array(self._h, records.ctypes.data, records.size, cptr, ncand,
                                                          None, 0))
 
+    def raw_listing(self, records: np.ndarray, candidates: np.ndarray | None = None) -> tuple[int, bytes]:
+        """(number of lines, the --raw listing) of a batch, formatted in C (modes_host_resolve_raw)."""
+        records = np.ascontiguousarray(records, dtype=N.RECORD_DTYPE)
+        cptr, ncand = None, 0
+        if candidates is not None:
+            candidates = np.ascontiguousarray(candidates, dtype=np.uint64)
+            cptr, ncand = candidates.ctypes.data, candidates.size
+        cap = 62 * records.size + 64                      # at most two 31-byte lines per record
+        if getattr(self, "_rawbuf", None) is None or len(self._rawbuf) < cap:
+            self._rawbuf = C.create_string_buffer(cap)
+        nbytes = C.c_uint64()
+        n = self._lib.modes_host_resolve_raw(self._h, records.ctypes.data, records.size, cptr, ncand, self._rawbuf, cap,
+                                             C.byref(nbytes))
+        return int(n), self._rawbuf.raw[: nbytes.value]
+
     def stats(self) -> dict:
         st = N.HostStats()
         self._lib.modes_host_get_stats(self._h, C.byref(st))
@@ -222,12 +237,12 @@ class Demodulator:
 
     def __init__(self, device: int = 0, fix: bool = True, aggressive: bool = False, check_crc: bool = True,
                  keep_candidates: bool = False, run_chunks: int = 0, slot_cap: int = 0, max_records: int = 0,
-                 scan_variant: int = 0, overlap: bool = False):
+                 scan_variant: int = 0, overlap: bool = False, no_retry: bool = False, direct_records: int = 0):
         self._lib = N.gpu_lib()
         self.flags = dict(fix=fix, aggressive=aggressive, check_crc=check_crc)
         self.device = device
         cfg = N.GpuConfig(device, int(fix), int(aggressive), int(keep_candidates), run_chunks, slot_cap, max_records,
-                          scan_variant, int(overlap), 0)
+                          scan_variant, int(overlap), N.GPU_NO_RETRY if no_retry else 0, direct_records, 0)
         h = C.c_void_p()
         rc = self._lib.modes_gpu_create(C.byref(cfg), C.byref(h))
         if rc != N.MODES_OK:
@@ -235,6 +250,7 @@ class Demodulator:
         self._h = h
         self.keep_candidates = keep_candidates
         self.last = {}
+        self._out = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -287,17 +303,48 @@ class Demodulator:
         self._keepalive = iq
         self._check(self._lib.modes_gpu_detect(self._h, C.byref(span), self._stream_ptr(st)))
 
-    def fetch(self):
-        """Wait for detect(); -> (records ndarray, candidates ndarray | None, info dict)."""
+    def fetch(self, copy: bool = True):
+        """Wait for detect(); -> (records ndarray, candidates ndarray | None, info dict).  copy=False: the arrays are
+        views of the library's own (pinned) buffers, valid until the next detect on this context."""
         res = N.GpuResult()
         self._check(self._lib.modes_gpu_fetch(self._h, C.byref(res)))
-        return self._unpack(res)
+        return self._unpack(res, copy)
 
-    def _unpack(self, res):
+    def set_output(self, records=None, count=None):
+        """Caller-owned device output (modes_gpu_set_output): `records` a CUDA uint8 tensor of capacity * 64 bytes
+        that receives the ordered list, `count` a CUDA int64 tensor of one element that receives the number of
+        records - both written by the kernels of detect(), in stream order.  None, None: the context's own list."""
+        if records is None:
+            self._check(self._lib.modes_gpu_set_output(self._h, None, 0, None))
+            self._out = None
+            return
+        import torch
+        assert records.is_cuda and records.dtype == torch.uint8 and records.is_contiguous() and records.numel() % 64 == 0
+        assert count is None or (count.is_cuda and count.dtype == torch.int64 and count.numel() == 1)
+        self._check(self._lib.modes_gpu_set_output(self._h, records.data_ptr(), records.numel() // 64,
+                                                   count.data_ptr() if count is not None else None))
+        self._out = (records, count)
+
+    def stream_wait(self, stream):
+        """Make `stream` wait for the results of the detect in flight (modes_gpu_stream_wait)."""
+        self._check(self._lib.modes_gpu_stream_wait(self._h, self._stream_ptr(stream)))
+
+    def fetch_device(self):
+        """Wait for detect() without copying the records: -> (number of records, info dict).  The ordered list
+        is in the tensor given to set_output() (its first n * 64 bytes)."""
+        res = N.GpuResult()
+        self._check(self._lib.modes_gpu_fetch_device(self._h, C.byref(res)))
+        self.last = dict(n_records=int(res.n_records), n_forwarded=int(res.n_forwarded), n_preambles=int(res.n_preambles),
+                         scan_ms=float(res.scan_ms), demod_ms=float(res.demod_ms), order_ms=float(res.order_ms))
+        return int(res.n_records), dict(self.last)
+
+    def _unpack(self, res, copy: bool = True):
         n = int(res.n_records)
         if n:
             raw = (C.c_uint8 * (n * 64)).from_address(C.cast(res.records, C.c_void_p).value)
-            recs = np.frombuffer(raw, dtype=N.RECORD_DTYPE).copy()        # the library reuses its buffer on the next call
+            recs = np.frombuffer(raw, dtype=N.RECORD_DTYPE)
+            if copy:
+                recs = recs.copy()                                        # the library reuses its buffer on the next call
         else:
             recs = np.zeros(0, dtype=N.RECORD_DTYPE)
         cands = None
@@ -306,8 +353,29 @@ class Demodulator:
             cands = (np.frombuffer((C.c_uint8 * (nc * 8)).from_address(C.cast(res.candidates, C.c_void_p).value),
                                    dtype=np.uint64).copy() if nc else np.zeros(0, dtype=np.uint64))
         self.last = dict(n_records=n, n_forwarded=int(res.n_forwarded), n_preambles=int(res.n_preambles),
-                         scan_ms=float(res.scan_ms), demod_ms=float(res.demod_ms))
+                         scan_ms=float(res.scan_ms), demod_ms=float(res.demod_ms), order_ms=float(res.order_ms))
         return recs, cands, dict(self.last)
+
+    # ---- host buffers: what the C host does (modes_gpu_submit_host + fetch) -------------------
+    def host_alloc(self, nbytes: int):
+        """Pinned host memory as a numpy uint8 array (modes_gpu_host_alloc); free with host_free(arr)."""
+        p = C.c_void_p()
+        self._check(self._lib.modes_gpu_host_alloc(self._h, nbytes, C.byref(p)))
+        arr = np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=np.uint8)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data)
+        self._lib.modes_gpu_host_free(self._h, p)
+
+    def submit_host(self, data: np.ndarray, stream_byte0: int = 0, first_block: int = 0, nblocks: int | None = None):
+        """Asynchronous host -> HBM copy + kernels (modes_gpu_submit_host); fetch() later."""
+        assert data.dtype == np.uint8 and data.flags.c_contiguous
+        if nblocks is None:
+            nblocks = block_count(stream_byte0 + data.size) - first_block
+        self._check(self._lib.modes_gpu_submit_host(self._h, data.ctypes.data, data.size, stream_byte0, first_block, nblocks))
 
     def records_from_host(self, data: np.ndarray, stream_byte0: int = 0, first_block: int = 0,
                           nblocks: int | None = None):
@@ -332,7 +400,7 @@ class Demodulator:
         try:
             n = data.size if isinstance(data, np.ndarray) else data.numel()
             total = block_count(n)
-            msgs, tot = [], dict(n_records=0, n_forwarded=0, n_preambles=0, scan_ms=0.0, demod_ms=0.0)
+            msgs, tot = [], dict(n_records=0, n_forwarded=0, n_preambles=0, scan_ms=0.0, demod_ms=0.0, order_ms=0.0)
             for b0 in range(0, total, batch_blocks):
                 nb = min(batch_blocks, total - b0)
                 lo, hi = shard_byte_range(b0, nb, n)

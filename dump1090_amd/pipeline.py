@@ -1,0 +1,236 @@
+"""The pipelined step loop of a host that keeps a GPU (one rank of N) busy: several detect calls in flight,
+the record lists fetched - or gathered to rank 0 from device memory - behind them, the sequential resolve on its
+own thread.  bench.py drives it with the HIP Demodulator; tests/test_pipeline.py drives the same code on CPU
+(gloo, world_size 2) with a stand-in detector fed by the oracle."""
+from __future__ import annotations
+
+import queue
+import threading
+import time
+
+import numpy as np
+
+
+class Resolver(threading.Thread):
+    """Rank 0's sequential half on its own thread (the C host does the same): record lists in, --raw listing out.
+    A fresh whitelist per step: every step demodulates the same stream from its beginning; the calls of one step
+    share it (like the batches of one file)."""
+
+    def __init__(self, flags):
+        super().__init__(daemon=True)
+        self.flags = flags
+        self.q = queue.Queue()
+        self.msgs = 0                   # messages of the timed steps
+        self.step_text = []             # listing of the step in progress, one piece per call
+        self.last_text = b""            # listing of the last complete step
+        self.last_lines = 0
+        self.error = None
+        self._res = None
+        self.start()
+
+    def submit(self, recs, counts, first_call, last_call, timed, done_event):
+        """recs: the records of one call - this rank's (counts None) or the gathered lists of all ranks, rank after
+        rank (counts = records per rank)."""
+        self.q.put((recs, counts, first_call, last_call, timed, done_event))
+
+    def _resolve(self, recs, timed):
+        n, text = self._res.raw_listing(recs, None)
+        self.step_text.append(text)
+        if timed:
+            self.msgs += n
+
+    def run(self):
+        from .demod import HostResolver
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            recs, counts, first_call, last_call, timed, done = item
+            try:
+                if first_call:
+                    if self._res is not None:
+                        self._res.close()
+                    self._res = HostResolver(**self.flags)
+                    self.step_text = []
+                    self._parts = []
+                if counts is None or (first_call and last_call):
+                    self._resolve(recs, timed)                  # one rank, or one call per step: already in stream order
+                else:
+                    # several calls per step and several ranks: stream order is rank-major (rank 0's calls, then
+                    # rank 1's ...), the gathered lists arrive call-major - keep the pieces, resolve at the step's end
+                    offs = np.concatenate([[0], np.cumsum(counts)])
+                    self._parts.append([recs[offs[r]: offs[r + 1]].copy() for r in range(len(counts))])
+                    if last_call:
+                        for r in range(len(counts)):
+                            for call in self._parts:
+                                self._resolve(call[r], timed)
+                if last_call:
+                    self.last_text = b"".join(self.step_text)
+                    self.last_lines = self.last_text.count(b"\n")
+            except Exception as e:          # noqa: BLE001 - reported by the main thread
+                self.error = e
+            done.set()
+
+    def stop(self):
+        self.q.put(None)
+        self.join()
+
+
+def split_calls(first_block, nblocks, ncalls, lo, total_bytes):
+    """A rank's buffers in `ncalls` contiguous GPU calls (one call holds at most 8 GiB - 64 KiB of samples):
+    -> [(first_block, nblocks, byte_lo, byte_hi)] with the bytes each call needs (its buffers + the 476-byte carry)."""
+    from .demod import shard_blocks, shard_byte_range
+    out = []
+    for c in range(ncalls):
+        b0, nb = shard_blocks(nblocks, ncalls, c)
+        clo, chi = shard_byte_range(first_block + b0, nb, total_bytes)
+        out.append((first_block + b0, nb, clo, chi))
+    return out
+
+
+def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, rank=0, dist=None, coll_device=None,
+              cap_records=1 << 16, streams=(None,), device_sync=lambda: None):
+    """`warm` untimed + `steps` timed steps of the hot path over this rank's shard `iq` (stream bytes from `lo`;
+    a CUDA uint8 tensor - anything sliceable that make_demod()'s detect accepts); a step is the sequence `calls`
+    of GPU calls (split_calls).  `depth` contexts (make_demod() each) are used in rotation, so that the GPU always
+    has the next call queued while the host fetches, gathers and resolves the previous ones:
+
+        call i       detect queued on streams[i mod len]; N > 1: all_gather of the record counts queued behind it
+        call i - 1   N > 1: counts on the host -> exact-size transfers of the device-resident lists to rank 0 queued
+        call i - 2   records on rank 0's host -> resolver thread (sequential resolve + --raw formatting)
+
+    world > 1: `dist` = torch.distributed (initialised), coll_device = where the gathered bytes travel (the CUDA
+    device with RCCL; "cpu" with gloo: the lists are fetched to the host first).  Returns a dict of measurements
+    (rank 0: also the --raw listing of the last step)."""
+    import torch
+    from .distributed import RecordGather
+
+    demods = [make_demod() for _ in range(depth)]
+    works = list(streams)
+    slots = None
+    on_gpu = coll_device is not None and torch.device(coll_device).type == "cuda"
+    if world > 1:
+        gather = RecordGather(cap_records, device=coll_device)
+        slots = [gather.slot() for _ in range(depth)]
+        if on_gpu:
+            for d, s in zip(demods, slots):
+                d.set_output(s.own_records, s.count)
+            # the exchanges of a call are queued on a stream of their own, behind the call's results (with overlap the
+            # detect's launch stream does not wait for the demod and order kernels)
+            comms = [torch.cuda.Stream(device=coll_device) for _ in range(depth)]
+    resolver = Resolver(dict(fix=flags["fix"], aggressive=flags["aggressive"], check_crc=True)) if rank == 0 else None
+    free = [threading.Event() for _ in range(depth)]          # the resolver is done with context k's record buffer
+    for e in free:
+        e.set()
+
+    def sync_all():
+        device_sync()
+        if world > 1:
+            dist.barrier()
+            device_sync()
+
+    scan_ms, demod_ms, order_ms = [], [], []
+    last = {}
+
+    def note(info, timed):
+        last.update(info)
+        if timed:
+            scan_ms.append(info["scan_ms"])
+            demod_ms.append(info["demod_ms"])
+            order_ms.append(info["order_ms"])
+
+    # phase 1 of a call in flight (N > 1): its counts are on the host -> queue the transfers of the lists
+    def phase_records(k, stream, timed):
+        d, s = demods[k], slots[k]
+        if on_gpu:
+            _, info = d.fetch_device()
+        else:                                                   # --backend gloo smoke mode: the lists travel as CPU tensors
+            recs, _, info = d.fetch()
+            s.own_records[: recs.size * 64] = torch.from_numpy(recs.view(np.uint8).reshape(-1))
+            s.count[0] = recs.size
+            s.exchange_counts()
+        s.exchange_records(stream=stream)
+        note(info, timed)
+
+    # phase 2: the records are on rank 0's host -> resolver thread
+    def phase_resolve(k, tag, timed):
+        counts = None
+        if world > 1:
+            recs = slots[k].wait()
+            counts = slots[k].counts
+        else:
+            recs, _, info = demods[k].fetch(copy=False)         # a view of the context's pinned list
+            note(info, timed)
+        if rank == 0:
+            free[k].clear()
+            resolver.submit(recs, counts, tag[0], tag[1], timed, free[k])
+
+    stage = {}                                                  # context -> [phase, stream, timed, (first call, last call of its step)]
+    order = []                                                  # contexts with a call in flight, oldest first
+
+    def advance(k, upto):
+        st = stage.get(k)
+        if st is None:
+            return
+        if st[0] == 0 and world > 1 and upto >= 1:
+            phase_records(k, st[1], st[2])
+            st[0] = 1
+        if upto >= 2:
+            phase_resolve(k, st[3], st[2])
+            stage.pop(k)
+            order.remove(k)
+
+    t0 = None
+    ncall = 0
+    for step in range(warm + steps):
+        if step == warm:
+            for k in list(order):
+                advance(k, 2)
+            for e in free:
+                e.wait()
+            sync_all()
+            t0 = time.perf_counter()
+        timed = step >= warm
+        for ci, (b0, nb, clo, chi) in enumerate(calls):
+            k = ncall % depth
+            if k in stage:                                      # its previous call must be complete first
+                for kk in list(order):
+                    advance(kk, 2)
+                    if kk == k:
+                        break
+            free[k].wait()                                      # ... and resolved: the record buffer is reused
+            stream = works[ncall % len(works)]
+            demods[k].detect(iq[clo - lo: chi - lo], stream_byte0=clo, first_block=b0, nblocks=nb, stream=stream)
+            if world > 1 and on_gpu:
+                demods[k].stream_wait(comms[k])
+                slots[k].exchange_counts(stream=comms[k])
+                stream = comms[k]
+            stage[k] = [0, stream, timed, (ci == 0, ci == len(calls) - 1)]
+            order.append(k)
+            ncall += 1
+            # keep the older calls moving: the previous one gets its transfers queued, the one before is handed over
+            if len(order) >= 2:
+                advance(order[-2], 1)
+            if len(order) >= 3:
+                advance(order[0], 2)
+    for k in list(order):
+        advance(k, 2)
+    for e in free:
+        e.wait()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    out = {"elapsed": elapsed, "scan_ms": float(np.mean(scan_ms)), "demod_ms": float(np.mean(demod_ms)),
+           "order_ms": float(np.mean(order_ms)), "last": dict(last), "depth": depth, "calls_per_step": len(calls),
+           "call_bytes": float(np.mean([chi - clo for _, _, clo, chi in calls])), "steps": steps}
+    if rank == 0:
+        if resolver.error is not None:
+            raise resolver.error
+        out.update(msgs=resolver.msgs, listing=resolver.last_text, lines=resolver.last_lines)
+        resolver.stop()
+    for d in demods:
+        d.close()
+    return out

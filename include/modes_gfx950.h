@@ -56,14 +56,20 @@ typedef struct {
     int32_t  keep_candidates;  /* also return every preamble position (for --stats)   */
     uint32_t run_chunks;       /* tuning: 512-sample chunks per wavefront run, 0=auto */
     uint32_t slot_cap;         /* tuning: forwarded positions per run, 0=auto         */
-    uint32_t max_records;      /* record-list capacity, 0 = 1<<20                     */
+    uint32_t max_records;      /* record-list capacity; 0 = automatic (starts at 1<<18 and grows)  */
     uint32_t scan_variant;     /* 0 = production scan kernel; others: see DESIGN.md   */
-    uint32_t overlap;          /* 1: only the scan kernel runs on the caller's stream; the demod
-                                  kernel and the result copy follow on the context's own stream, so
-                                  work the caller queues next (another context's scan) overlaps them.
-                                  The input must then stay untouched until modes_gpu_fetch().       */
+    uint32_t overlap;          /* 1: only the scan kernel runs on the caller's stream; the demod and order
+                                  kernels follow on the context's own stream, so work the caller queues next
+                                  (another context's scan) overlaps them.                                   */
+    uint32_t flags;            /* MODES_GPU_* below                                                       */
+    uint32_t direct_records;   /* lists of at most this many records reach the host with the kernels
+                                  (zero-copy stores, no copy operation); 0 = 4096                          */
     uint32_t reserved;
 } modes_gpu_config;
+
+/* modes_gpu_config.flags */
+#define MODES_GPU_NO_RETRY 1u  /* never repeat a call inside modes_gpu_fetch(): a list overflow returns
+                                  MODES_ERR_OVERFLOW (the lists are enlarged; the caller resubmits)      */
 
 /* One demodulation attempt at a preamble position: dump1090.c:1666-1726 (bit
  * slicing, packing, noise gate) plus the syndrome / repair lookup of
@@ -98,14 +104,16 @@ typedef struct {
 } modes_gpu_span;
 
 typedef struct {
-    const modes_record *records;       /* host memory owned by the context, ascending */
-    uint64_t            n_records;     /*   (block, j); valid until next detect       */
+    const modes_record *records;       /* ascending (block, j); host memory owned by the context (fetch) or   */
+    uint64_t            n_records;     /*   DEVICE memory (fetch_device); valid until the next detect         */
     const uint64_t     *candidates;    /* framed g of every preamble position,        */
     uint64_t            n_candidates;  /*   ascending (keep_candidates only)          */
     uint64_t            n_forwarded;   /* positions the s-domain scan forwarded       */
     uint64_t            n_preambles;   /* positions where dump1090.c:1602-1650 holds  */
     float               scan_ms;       /* HIP-event time of the scan kernel           */
-    float               demod_ms;      /* demod kernel + result-header copy           */
+    float               demod_ms;      /* of the demod kernel                         */
+    float               order_ms;      /* of the order kernel (records into stream order) */
+    float               reserved;
 } modes_gpu_result;
 
 int  modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out);
@@ -120,12 +128,40 @@ int modes_gpu_compute_magnitude(modes_gpu *ctx, const void *d_iq, uint64_t nsamp
                                 void *d_mag, void *stream);
 
 /* Replaces computeMagnitudeVector()+detectModeS() up to (not including) the
- * stateful decode, for span->nblocks buffers: launches the scan and demod
- * kernels asynchronously on `stream` (a hipStream_t; NULL = HIP's default stream). */
+ * stateful decode, for span->nblocks buffers: launches the scan, demod and order
+ * kernels asynchronously on `stream` (a hipStream_t; NULL = HIP's default stream).
+ * One detect per context at a time (MODES_ERR_STATE otherwise; use several contexts to pipeline).
+ *
+ * LIFETIME: span->iq and `stream` must stay valid, and the bytes unmodified, until the matching
+ * modes_gpu_fetch()/modes_gpu_fetch_device() has RETURNED - in every mode.  When a call needs
+ * longer lists than the context has (a run with more than 1/16 preamble-like positions; more records than
+ * the automatic capacity), fetch enlarges them and REPEATS the call on the same span and stream; nothing
+ * is ever truncated.  A host that cannot keep the input alive sets MODES_GPU_NO_RETRY: fetch then returns
+ * MODES_ERR_OVERFLOW (result->n_records = records the call needs) with the lists already enlarged, and
+ * the host resubmits the span itself. */
 int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream);
 
-/* Waits for the last modes_gpu_detect(), copies the records back, orders them. */
+/* Waits for the last modes_gpu_detect() and returns its records in stream order (host memory).  The list
+ * is put in order on the device; up to direct_records records arrive with the kernels, longer lists
+ * take one device-to-host copy here. */
 int modes_gpu_fetch(modes_gpu *ctx, modes_gpu_result *res);
+
+/* The same without the copy: res->records is the DEVICE list (the context's, or the one given to
+ * modes_gpu_set_output) - for hosts that hand the records to another device consumer, e.g. the gather of
+ * the per-GPU lists over RCCL. */
+int modes_gpu_fetch_device(modes_gpu *ctx, modes_gpu_result *res);
+
+/* Makes `stream` (a hipStream_t) wait for the results of the detect in flight - the device list and count of
+ * modes_gpu_set_output are complete for everything queued on `stream` afterwards.  Needed with overlap = 1,
+ * where the caller's own stream does not wait for the demod and order kernels. */
+int modes_gpu_stream_wait(modes_gpu *ctx, void *stream);
+
+/* Caller-owned device output: the ordered list is written to d_records (16-byte aligned, room for
+ * `capacity` records; more records than that are MODES_ERR_OVERFLOW at fetch) and, if d_count is not
+ * NULL, the number of records of the call to the 8-byte device word d_count - both by the kernels of
+ * modes_gpu_detect, in stream order, so that a collective queued behind the detect can consume them without
+ * a host round trip.  (NULL, 0, NULL) returns to the context's own list. */
+int modes_gpu_set_output(modes_gpu *ctx, void *d_records, uint64_t capacity, void *d_count);
 
 /* Host-buffer convenience used by the C host: stages `nbytes` stream bytes that
  * start at stream offset `stream_byte0` into the context's device buffer, then
@@ -160,7 +196,7 @@ int modes_gpu_synth_noise(modes_gpu *ctx, void *d_out, uint64_t first_byte, uint
 int modes_gpu_fill(modes_gpu *ctx, void *d_out, uint64_t nbytes, uint8_t value, void *stream);
 
 /* ABI version of this header. */
-#define MODES_GFX950_ABI 2
+#define MODES_GFX950_ABI 3
 int modes_gpu_abi_version(void);
 
 #ifdef __cplusplus

@@ -140,6 +140,14 @@ uint64_t modes_host_resolve_to_array(modes_host *h, const modes_record *recs, ui
                                      const uint64_t *candidates, uint64_t ncand,
                                      modes_emitted *out, uint64_t cap);
 
+/* Same resolve with the CLI's --raw sink built in: the listing `dump1090 --raw` prints for these buffers
+ * (one "*<hex>;\n" line per message that passes the display filter, dump1090.c:1324-1326, :1803) is written
+ * to out[0..cap); *nbytes = length of the whole listing (may exceed cap; then only whole lines that fit are
+ * stored).  Returns the number of lines. */
+uint64_t modes_host_resolve_raw(modes_host *h, const modes_record *recs, uint64_t nrecs,
+                                const uint64_t *candidates, uint64_t ncand,
+                                char *out, uint64_t cap, uint64_t *nbytes);
+
 /* dump1090.c:1803: would useModesMessage() display/forward this message? */
 int modes_host_wants(const modes_host *h, const struct modesMessage *mm);
 

@@ -27,17 +27,3 @@ def build(force=False):
 if __name__ == "__main__":
     print(build(force=True))
 
-
-ORDER_OUT = os.path.join(HERE, "liborder_shim.so")
-ORDER_SRC = os.path.join(HERE, "order_shim.cpp")
-ORDER_HDR = os.path.join(ROOT, "dump1090_amd", "csrc", "modes_order.h")
-
-
-def build_order(force=False):
-    """tests/native/liborder_shim.so: modes_order.h behind one C function."""
-    if not force and os.path.exists(ORDER_OUT) and os.path.getmtime(ORDER_OUT) >= max(os.path.getmtime(ORDER_SRC),
-                                                                                       os.path.getmtime(ORDER_HDR)):
-        return ORDER_OUT
-    subprocess.run([clangxx(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread",
-                    "-I", os.path.join(ROOT, "include"), "-o", ORDER_OUT, ORDER_SRC], check=True)
-    return ORDER_OUT

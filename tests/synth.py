@@ -260,7 +260,8 @@ class SparseFrameStream:
 
 
 def config3_stream(seed: int, nblocks: int, *, per: int = 65536, sigma_q16: int = 941, amp=(40, 100),
-                   flip1: int = 10, edge_every: int = 997, smear=(0,), flip2: int = 0) -> SparseFrameStream:
+                   flip1: int = 10, edge_every: int = 997, smear=(0,), flip2: int = 0,
+                   only_samples=None) -> SparseFrameStream:
     """BASELINE config 3: sigma=3 noise + DF11/DF17 frames with valid parity, about one per `per`
     samples at hashed offsets, amplitude 40..100, random carrier phase, one in `flip1` with one
     flipped data bit; every `edge_every`-th frame sits at one of the buffer-seam offsets of
@@ -268,9 +269,16 @@ def config3_stream(seed: int, nblocks: int, *, per: int = 65536, sigma_q16: int 
     nsamp = nblocks * BLOCK_STRIDE
     placements = []
     clean = {}
-    k = 0
-    for base in range(0, nsamp - per, per):
-        h = int(hash_at(seed ^ 0xC0F3, np.array([k], dtype=np.uint64))[0])
+    # only_samples = (lo, hi): just the frames that can touch samples [lo, hi) of the same stream (a rank's shard of
+    # a multi-GPU run builds its part without walking the other ranks' frames)
+    k_lo, k_hi = 0, max(0, (nsamp - per + per - 1) // per)
+    if only_samples is not None:
+        k_lo = max(k_lo, only_samples[0] // per - 1)
+        k_hi = min(k_hi, only_samples[1] // per + 2)
+    hashes = hash_at(seed ^ 0xC0F3, np.arange(k_lo, max(k_lo, k_hi), dtype=np.uint64))
+    for k in range(k_lo, k_hi):
+        base = k * per
+        h = int(hashes[k - k_lo])
         o = base + 300 + h % (per - 900)
         if edge_every and k % edge_every == edge_every - 1:
             seam = (base // BLOCK_STRIDE + 1) * BLOCK_STRIDE - CARRY
@@ -291,7 +299,10 @@ def config3_stream(seed: int, nblocks: int, *, per: int = 65536, sigma_q16: int 
         sm = smear[(h >> 52) % len(smear)]
         placements.append((o, bytes(fb), int(a), int((h >> 56) & 63), int(sm)))
         clean[o] = make_frame(df, bytes(pay))
-        k += 1
+    if only_samples is not None:
+        keep = [p for p in placements if p[0] + SparseFrameStream.SPAN > only_samples[0] and p[0] < only_samples[1]]
+        clean = {p[0]: clean[p[0]] for p in keep}
+        placements = keep
     st = SparseFrameStream(seed, nblocks * DATA_LEN, sigma_q16, placements)
     st.clean = clean                 # sample -> the frame as transmitted before any bit flip
     return st

@@ -31,13 +31,13 @@ def test_gpu_library_exports_header():
     L = N.gpu_lib()
     for n in names:
         assert getattr(L, n)
-    assert L.modes_gpu_abi_version() == 2
+    assert L.modes_gpu_abi_version() == 3
 
 
 def test_struct_layouts():
     assert C.sizeof(N.Attempt) == 28 and C.sizeof(N.Record) == 64
     assert N.RECORD_DTYPE.itemsize == 64 and N.RECORD_DTYPE.fields["att"][1] == 8
-    assert C.sizeof(N.GpuConfig) == 40 and C.sizeof(N.Span) == 40
+    assert C.sizeof(N.GpuConfig) == 48 and C.sizeof(N.Span) == 40 and C.sizeof(N.GpuResult) == 64
 
 
 def test_create_without_gpu_fails_loudly():

@@ -39,7 +39,27 @@ def _worker(rank, world, port, case, fs, outdir):
     flags = orc.FLAGSETS[fs]
     first, n = shard_blocks(block_count(data.size), world, rank)
     recs, cands = oracle_records(data, maxfix_of(flags), blocks=range(first, first + n))
-    recs, cands = gather_records(recs, cands, dst=0)
+    # the product path of bench.py --gpus N: device-resident lists (CPU tensors under gloo), counts first, then
+    # exact-size point-to-point transfers into rank 0's contiguous buffer - two calls in flight, like the bench
+    import torch
+    from dump1090_amd.distributed import RecordGather
+    g = RecordGather(cap_records=4096, device="cpu")        # the same capacity on every rank
+    slots = [g.slot(), g.slot()]
+    for k, s in enumerate(slots):                         # the second call carries only every other record
+        mine = np.ascontiguousarray(recs if k == 0 else recs[::2])
+        s.own_records[: mine.size * 64] = torch.from_numpy(mine.view(np.uint8).reshape(-1).copy())
+        s.count[0] = mine.size
+        s.exchange_counts()
+    for s in slots:
+        s.exchange_records()
+    got = [s.wait() for s in slots]
+    _, cands = gather_records(recs[:0], cands, dst=0)
+    if rank == 0:
+        assert got[1].size == sum((c + 1) // 2 for c in slots[0].counts)
+        recs = got[0].copy()
+    else:
+        assert got == [None, None]
+        recs = None
     if rank == 0:
         r = HostResolver(**flags)
         text = raw_text(r.resolve(recs, cands))

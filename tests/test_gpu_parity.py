@@ -28,11 +28,64 @@ def to_dev(torch, data):
 
 
 def test_native_library_is_loaded(torch_cuda):
-    from dump1090_amd import Demodulator, _native as N
-    d = Demodulator()
+    """The product libraries - not a fallback - are what this process runs: both are mapped, a context exists
+    on the GPU, and the ABI version is the header's."""
+    from dump1090_amd import Demodulator, HostResolver, _native as N
+    d, r = Demodulator(), HostResolver()
     maps = open("/proc/self/maps").read()
-    assert "libmodes_gfx950.so" in maps and "libmodes_host.so" not in maps or True
-    assert os.path.exists(N.GPU_LIB)
+    assert os.path.realpath(N.GPU_LIB) in maps, "libmodes_gfx950.so is not mapped"
+    assert os.path.realpath(N.HOST_LIB) in maps, "libmodes_host.so is not mapped"
+    assert N.gpu_lib().modes_gpu_abi_version() == 3
+    r.close()
+    d.close()
+
+
+def test_one_detect_per_context_at_a_time(torch_cuda, streams):
+    """A second detect before the fetch would relaunch over live scratch: MODES_ERR_STATE, and the first one survives."""
+    from dump1090_amd import Demodulator, ModesError
+    iq = to_dev(torch_cuda, streams["frames"])
+    d = Demodulator()
+    d.detect(iq)
+    with pytest.raises(ModesError, match="MODES_ERR_STATE"):
+        d.detect(iq)
+    recs, _, _ = d.fetch()
+    want, _ = oracle_records(streams["frames"], 1)
+    assert_records_equal(recs, want, "after the refused second detect")
+    with pytest.raises(ModesError, match="MODES_ERR_STATE"):
+        d.fetch()
+    d.close()
+
+
+def test_device_output_and_direct_host_path_agree(torch_cuda, streams):
+    """The ordered list in a caller-owned device buffer (modes_gpu_set_output + fetch_device: what the RCCL gather
+    consumes), the zero-copy host path (short lists) and the copy path (long lists) are the same records."""
+    from dump1090_amd import Demodulator, ModesError, RECORD_DTYPE
+    torch = torch_cuda
+    data = streams["modes1"]
+    iq = to_dev(torch, data)
+    want, _ = oracle_records(data, 1)
+    assert want.size > 1000
+    for direct in (0, 1, 1 << 20):                      # default (4096: copy path here), everything copied, everything direct
+        d = Demodulator(direct_records=direct)
+        d.detect(iq)
+        recs, _, info = d.fetch()
+        assert_records_equal(recs, want, ("direct_records", direct))
+        d.close()
+    d = Demodulator()
+    out = torch.zeros(8192 * 64, dtype=torch.uint8, device="cuda:0")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    d.set_output(out, cnt)
+    d.detect(iq)
+    n, info = d.fetch_device()
+    assert n == want.size and int(cnt.item()) == n
+    got = out[: n * 64].cpu().numpy().view(RECORD_DTYPE)
+    assert_records_equal(got, want, "device list")
+    small = torch.zeros(64 * 64, dtype=torch.uint8, device="cuda:0")
+    d.set_output(small, cnt)
+    d.detect(iq)
+    with pytest.raises(ModesError, match="MODES_ERR_OVERFLOW"):
+        d.fetch_device()
+    assert int(cnt.item()) == want.size                  # the device word still says what the call needed
     d.close()
 
 
@@ -115,6 +168,13 @@ def test_modes1_published_hash_from_host_buffer(torch_cuda, streams):
     ([], 3202, "0bf2290fa954f1675437e52508ea8aa3"),                       # the verbose dump of every field
     (["--aggressive", "--no-crc-check"], 5357, "b4e11b2e0017cdf772e49d300ab19158"),
     (["--raw", "--batch-blocks", "1"], 284, "4a81758c8bec5e45ffa8541c5622938a"),
+    # the N-GPU split of the C host, emulated on one device: batch b runs on "GPU" b mod N, each with its own
+    # contexts; the listing and the counters must not notice
+    (["--raw", "--batch-blocks", "1", "--gpu-list", "0,0"], 284, "4a81758c8bec5e45ffa8541c5622938a"),
+    (["--raw", "--batch-blocks", "1", "--gpu-list", "0,0,0", "--depth", "1"], 284, "4a81758c8bec5e45ffa8541c5622938a"),
+    (["--stats", "--batch-blocks", "1", "--gpu-list", "0,0"], 9, "bc3d1c04b24f4989f0fc4a2d1f45abdd"),
+    (["--batch-blocks", "2", "--gpu-list", "0,0", "--aggressive", "--no-crc-check"], 5357, "b4e11b2e0017cdf772e49d300ab19158"),
+    (["--raw", "--gpus", "1"], 284, "4a81758c8bec5e45ffa8541c5622938a"),
 ])
 def test_cli_reproduces_reference_stdout(torch_cuda, flags, lines, md5):
     """dump1090_amd --ifile testfiles/modes1.bin: BASELINE.md section 4 hashes of the reference."""
@@ -291,3 +351,50 @@ def test_dense_capture_grows_record_list_and_matches_reference(torch_cuda):
     with pytest.raises(RuntimeError, match="OVERFLOW"):
         small.fetch()
     small.close()
+
+
+def test_no_retry_reports_overflow_and_the_resubmitted_call_succeeds(torch_cuda):
+    """MODES_GPU_NO_RETRY (a host that cannot keep its input alive until fetch): both overflow cases come back as
+    MODES_ERR_OVERFLOW with the lists already enlarged; the host resubmits the span and gets the full result."""
+    from dump1090_amd import Demodulator, ModesError
+    torch = torch_cuda
+    # (a) slot lists: the periodic preamble-like signal of test_slot_overflow_is_retried_not_dropped
+    n = 2 * synth.DATA_LEN
+    iq = np.full(n, 127, dtype=np.uint8)
+    s = np.arange(n // 2)
+    pulse = np.isin(s % 15, (0, 2, 7, 9))
+    iq[0::2][pulse] = 210
+    iq[1::2][pulse] = 60
+    iq[-480:] = 127
+    dev = to_dev(torch, iq)
+    d = Demodulator(keep_candidates=True, check_crc=False, no_retry=True)
+    d.detect(dev)
+    with pytest.raises(ModesError, match="MODES_ERR_OVERFLOW"):
+        d.fetch()
+    d.detect(dev)
+    recs, cands, _ = d.fetch()
+    want_r, want_c = oracle_records(iq, 1)
+    assert np.array_equal(cands, want_c)
+    assert_records_equal(recs, want_r, "periodic, resubmitted")
+    d.close()
+    # (b) record list: the reference's capture tiled until it holds more records than the automatic capacity (2^18)
+    one = synth.modes1_padded(os.path.join(ROOT, "tests", "golden", "modes1.bin"))
+    host = np.tile(one, (512 << 20) // one.size)
+    dev = torch.from_numpy(host).to("cuda:0")
+    d = Demodulator(no_retry=True)
+    d.detect(dev)
+    with pytest.raises(ModesError, match="MODES_ERR_OVERFLOW"):
+        d.fetch()
+    d.detect(dev)
+    recs, _, info = d.fetch()
+    assert info["n_records"] > (1 << 18)
+    per_tile, _ = oracle_records(one, 1)
+    # every tile but the first repeats the same records (the first tile has no carry-in from a previous one)
+    nb = one.size // synth.DATA_LEN
+    tile5 = recs[(recs["block"] >= 5 * nb) & (recs["block"] < 6 * nb)].copy()
+    tile9 = recs[(recs["block"] >= 9 * nb) & (recs["block"] < 10 * nb)].copy()
+    tile5["block"] -= 5 * nb
+    tile9["block"] -= 9 * nb
+    assert np.array_equal(tile5, tile9) and abs(int(tile5.size) - int(per_tile.size)) < 8
+    assert np.all(np.diff(recs["block"].astype(np.int64) * 131072 + recs["j"]) > 0)      # strictly ascending: device order
+    d.close()

@@ -1,0 +1,96 @@
+"""dump1090_amd/pipeline.py on CPU: the step loop bench.py runs on every rank (several calls in flight, the
+record lists gathered to rank 0, the resolve on its own thread), driven here by a stand-in detector that gets
+its records from the oracle - world_size 1 in-process, world_size 2 over gloo.  The listing rank 0 ends up with
+must be the reference's, whatever the split into ranks and calls."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleDetector:
+    """Quacks like dump1090_amd.Demodulator for run_steps' host-list mode: detect() remembers the buffers,
+    fetch() returns their records (ascending, RECORD_DTYPE) from the oracle."""
+
+    def __init__(self, data, maxfix):
+        self.data, self.maxfix, self.span, self.calls = data, maxfix, None, 0
+
+    def detect(self, iq, stream_byte0=0, first_block=0, nblocks=None, stream=None):
+        from dump1090_amd import shard_byte_range
+        assert self.span is None, "one detect per context at a time"
+        lo, hi = shard_byte_range(first_block, nblocks, self.data.size)
+        assert (stream_byte0, len(iq)) == (lo, hi - lo), "the call got exactly the bytes its buffers need"
+        assert np.array_equal(iq, self.data[lo:hi])
+        self.span = (first_block, nblocks)
+        self.calls += 1
+
+    def fetch(self, copy=True):
+        from helpers import oracle_records
+        first, n = self.span
+        self.span = None
+        recs, _ = oracle_records(self.data, self.maxfix, blocks=range(first, first + n))
+        return recs, None, dict(n_records=recs.size, n_forwarded=0, n_preambles=0, scan_ms=0.0, demod_ms=0.0, order_ms=0.0)
+
+    def close(self):
+        pass
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, case, ncalls, depth, outdir):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import synth
+    from dump1090_amd import block_count, shard_blocks, shard_byte_range
+    from dump1090_amd.pipeline import run_steps, split_calls
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    data = {"frames": synth.case_frames, "edges": synth.case_edges}[case]()
+    total = block_count(data.size)
+    first, n = shard_blocks(total - 1, world, rank)            # bench.py's sharding: the EOF buffer goes to the last rank
+    if rank == world - 1:
+        n += 1
+    lo, hi = shard_byte_range(first, n, data.size)
+    calls = split_calls(first, n, ncalls, lo, data.size)
+    made = []
+
+    def make():
+        made.append(OracleDetector(data, 1))
+        return made[-1]
+
+    out = run_steps(make, data[lo:hi], lo, calls, dict(fix=True, aggressive=False), steps=2, warm=1, depth=depth,
+                    world=world, rank=rank, dist=dist, coll_device="cpu", cap_records=4096)
+    assert sum(d.calls for d in made) == 3 * ncalls and out["calls_per_step"] == ncalls
+    if rank == 0:
+        with open(os.path.join(outdir, "out.txt"), "wb") as f:
+            f.write(out["listing"])
+        assert out["msgs"] == 2 * out["lines"]                   # two timed steps, the same listing each
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,ncalls,depth", [("frames", 1, 3), ("edges", 2, 3), ("edges", 3, 2), ("frames", 2, 1)])
+def test_single_rank_pipeline(tmp_path, golden, case, ncalls, depth):
+    _run(0, 1, 0, case, ncalls, depth, str(tmp_path))
+    assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
+
+
+@pytest.mark.parametrize("case,ncalls,depth", [("frames", 1, 3), ("edges", 2, 3), ("edges", 2, 2)])
+def test_two_ranks_gather_over_gloo(tmp_path, golden, case, ncalls, depth):
+    mp.spawn(_run, args=(2, _free_port(), case, ncalls, depth, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]

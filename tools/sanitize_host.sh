@@ -1,0 +1,44 @@
+#!/bin/bash
+# Runs the CPU tests of the host library and of the header-only device arithmetic against sanitizer builds:
+#   tools/sanitize_host.sh            UBSan, then ASan
+#   tools/sanitize_host.sh ubsan|asan one of them
+# (-fno-sanitize-recover / abort_on_error: any finding kills the test process).  The host library is built with
+# gcc, the shim around modes_core.h needs clang (vector extensions) and its shared sanitizer runtime; under ASan
+# python itself has to run with the runtimes preloaded.  The normal builds are restored whatever happens.
+R=$(cd "$(dirname "$0")/.." && pwd)
+cd "$R"
+CLANG=/opt/rocm/lib/llvm/bin/clang++
+RT=$(ls -d /opt/rocm/lib/llvm/lib/clang/*/lib/linux | head -1)
+cp dump1090_amd/libmodes_host.so /tmp/libmodes_host_orig.so
+restore() {
+    cp /tmp/libmodes_host_orig.so "$R/dump1090_amd/libmodes_host.so"
+    (cd "$R" && python -c "import sys; sys.path.insert(0, 'tests'); from native.build import build; build(force=True)")
+}
+trap restore EXIT
+set -e
+TESTS="tests/test_host.py tests/test_track.py tests/test_core.py"
+run_one() {
+    local kind=$1 san preload=""
+    if [ "$kind" = ubsan ]; then
+        san="-fsanitize=undefined -fno-sanitize-recover=undefined"
+    else
+        san="-fsanitize=address -fno-omit-frame-pointer"
+        # both runtimes (gcc's for the host library, clang's for the shim) must be loaded before python's first malloc
+        preload="$(gcc -print-file-name=libasan.so):$RT/libclang_rt.asan-x86_64.so"
+    fi
+    (cd dump1090_amd/csrc && g++ -O1 -g -std=c++17 -fPIC $san -I../../include -shared -o ../libmodes_host.so modes_host.cpp modes_track.cpp -lm)
+    (cd tests/native && $CLANG -O1 -g -std=c++17 -fPIC -shared $san -shared-libsan -Wl,-rpath,$RT -I ../../dump1090_amd/csrc -o libcore_shim.so core_shim.cpp)
+    echo "== $kind =="
+    if [ "$kind" = asan ]; then
+        # gcc's runtime first: it owns malloc; python's own leaks are not ours to report
+        LD_PRELOAD="$(gcc -print-file-name=libasan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 \
+            python -m pytest tests/test_host.py tests/test_track.py -x -q -p no:cacheprovider
+    else
+        python -m pytest $TESTS -x -q -p no:cacheprovider
+    fi
+}
+case "${1:-all}" in
+    ubsan) run_one ubsan ;;
+    asan)  run_one asan ;;
+    *)     run_one ubsan; run_one asan ;;
+esac
