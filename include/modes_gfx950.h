@@ -41,7 +41,9 @@ extern "C" {
  * bytes [262144k - 476, 262144(k+1)), 127 outside the stream; 131310 magnitudes;
  * detectModeS tests local offsets j in [0,131070).  "Framed coordinate"
  * g = 131072*k + j  <->  file sample g - 238. */
+#ifndef MODES_DATA_LEN                    /* dump1090.c:54 has its own spelling of the same number */
 #define MODES_DATA_LEN        262144u
+#endif
 #define MODES_CARRY_BYTES     476u
 #define MODES_BLOCK_STRIDE    131072u     /* samples between buffer starts            */
 #define MODES_BLOCK_POSITIONS 131070u     /* tested j per buffer (dump1090.c:1593)    */

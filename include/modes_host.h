@@ -22,13 +22,25 @@
 extern "C" {
 #endif
 
+/* (guarded: a translation unit that is dump1090.c itself - integration/modes_dropin.c - already has them) */
+#ifndef MODES_LONG_MSG_BITS
 #define MODES_LONG_MSG_BITS   112
 #define MODES_SHORT_MSG_BITS  56
 #define MODES_LONG_MSG_BYTES  (112 / 8)
 #define MODES_SHORT_MSG_BYTES (56 / 8)
+#endif
+#ifndef MODES_UNIT_FEET
 #define MODES_UNIT_FEET   0
 #define MODES_UNIT_METERS 1
+#endif
 
+/* Layout of struct modesMessage below (LP64): a host that brings its own definition - the reference's,
+ * MODES_HOST_NO_MESSAGE_STRUCT - checks these with _Static_assert (integration/modes_dropin.c). */
+#define MODES_MESSAGE_SIZE          180
+#define MODES_MESSAGE_OFFSET_FLIGHT 96
+#define MODES_MESSAGE_OFFSET_UNIT   176
+
+#ifndef MODES_HOST_NO_MESSAGE_STRUCT
 /* dump1090.c:211-260, field for field. */
 struct modesMessage {
     /* Generic fields */
@@ -80,6 +92,7 @@ struct modesMessage {
     /* Fields used by multiple message types. */
     int altitude, unit;
 };
+#endif /* MODES_HOST_NO_MESSAGE_STRUCT */
 
 /* The flags of the reference's global `Modes` the path reads
  * (dump1090.c:167,168,179; defaults dump1090.c:305,306,315). */

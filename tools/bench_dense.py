@@ -15,12 +15,12 @@ for flags in (dict(), dict(aggressive=True)):
     out = {}
     for rep in range(4):
         t0 = time.perf_counter()
-        d.detect(iq); recs, cands, info = d.fetch()
+        d.detect(iq); recs, cands, info = d.fetch(copy=False)
         t1 = time.perf_counter()
-        r = HostResolver(**flags); n = r.count(recs, cands); r.close()
+        r = HostResolver(**flags); n, _ = r.raw_listing(recs, cands); r.close()
         t2 = time.perf_counter()
         out = {"flags": flags, "gib": iq.numel() / 2**30, "records": len(recs), "messages": n, "scan_ms": round(info["scan_ms"], 3),
-               "demod_ms": round(info["demod_ms"], 3), "gpu_call_s": round(t1 - t0, 4), "resolve_s": round(t2 - t1, 4),
+               "demod_ms": round(info["demod_ms"], 3), "order_ms": round(info["order_ms"], 3), "gpu_call_s": round(t1 - t0, 4), "resolve_s": round(t2 - t1, 4),
                "preambles": info["n_preambles"], "forwarded": info["n_forwarded"]}
     print(json.dumps(out), flush=True)
     d.close()

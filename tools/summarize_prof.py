@@ -14,7 +14,7 @@ def find(pattern):
 
 
 def short(name):
-    for k in ("scan_fused_kernel", "scan_kernel", "demod_kernel", "finalize_kernel", "compact_candidates", "synth_noise", "fill_kernel",
+    for k in ("scan_fused_kernel", "scan_kernel", "demod_kernel", "order_kernel", "prefix_kernel", "compact_candidates", "synth_noise", "fill_kernel",
               "magnitude_kernel", "power_kernel"):
         if k in name:
             return k
@@ -64,7 +64,7 @@ for f in find("*counter_collection.csv"):
         agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     print("== counters (%s): mean per dispatch" % os.path.relpath(f, out))
     for k, cs in agg.items():
-        if k not in ("scan_fused_kernel", "scan_kernel", "demod_kernel"):
+        if k not in ("scan_fused_kernel", "scan_kernel", "demod_kernel", "order_kernel"):
             continue
         print("  %s" % k)
         for c, v in cs.items():
@@ -90,6 +90,13 @@ for k, d in traffic.items():
     if "WRITE_SIZE_KB_mean" in d:
         d["hbm_write_bytes_per_launch_uncalibrated"] = int(d["WRITE_SIZE_KB_mean"] * 1024)
 if traffic:
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rel in ("dump1090_amd/csrc/modes_gfx950.hip", "dump1090_amd/csrc/modes_core.h"):
+        h.update(open(os.path.join(root, rel), "rb").read())
+    traffic["kernel_source_sha256_16"] = h.hexdigest()[:16]      # bench.py reports the counters only for these very sources
+    traffic["tag"] = os.path.basename(os.path.normpath(out))
     traffic["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on bench.py's default workload "
                         "(1 GiB per launch); FETCH_SIZE doubled (gfx950 correction for 16 B/lane streaming reads)")
     with open(os.path.join(out, "traffic.json"), "w") as fh:
