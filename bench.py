@@ -153,16 +153,23 @@ def check_listing(listing: bytes, expected: list[str]):
     missing = sum(1 for e in expected if e not in listed)
     assert missing <= len(expected) // 200, "%d of %d injected frames are not in the listing" % (missing, len(expected))
     assert 0.99 * len(expected) <= len(lines) <= 1.02 * len(expected) + 64, "%d lines for %d frames" % (len(lines), len(expected))
-    # stream order: the expected frames that were listed appear in the order of their offsets
-    pos, at = {}, 0
+    # stream order: walking the expected frames in the order of their offsets, each one is found at or after the
+    # line of its predecessor (two frames may carry the same bytes: take the first occurrence not yet passed)
+    from bisect import bisect_left
+    where = {}
     for i, ln in enumerate(lines):
-        pos.setdefault(ln, i)
+        where.setdefault(ln, []).append(i)
+    at = out_of_order = 0
     for e in expected:
-        p = pos.get(e)
-        if p is None:
+        occ = where.get(e)
+        if not occ:
             continue
-        assert p >= at, "the listing is not in stream order around %s" % e
-        at = p
+        k = bisect_left(occ, at)
+        if k == len(occ):
+            out_of_order += 1
+        else:
+            at = occ[k]
+    assert out_of_order == 0, "%d expected frames appear before their predecessors: the listing is not in stream order" % out_of_order
     return {"lines": len(lines), "expected_frames": len(expected), "missing": missing,
             "md5": hashlib.md5(listing).hexdigest()}
 
@@ -181,15 +188,19 @@ def main():
     ap.add_argument("--cpu-mib", type=int, default=1024, help="MiB of the workload timed on the CPU baseline")
     ap.add_argument("--run-chunks", type=int, default=0)
     ap.add_argument("--scan-variant", type=int, default=0, help="0 = production scan kernel, 1 = fused single-pass scan")
-    ap.add_argument("--depth", type=int, default=3, help="detect calls in flight (contexts used in rotation)")
+    ap.add_argument("--demod-variant", type=int, default=0, help="0 = production demod kernel, 1 = 4-wave / small-table kernel that fits next to the scan")
+    ap.add_argument("--depth", type=int, default=4, help="detect calls in flight (contexts used in rotation)")
     ap.add_argument("--settle", type=int, default=80,
                     help="extra untimed steps before the W warmup steps: the chip's power management needs ~40 "
                          "back-to-back steps (13 ms) to settle - the scan kernel runs 0.22, 0.27, 0.21 ms at steps "
                          "1, 10, 60 of a sustained run (tools/scan_steps.py)")
-    ap.add_argument("--overlap", type=int, default=1,
-                    help="1 (default): a step's demod and order kernels run on the context's own stream, concurrent with "
-                         "the next step's scan (a demod workgroup fits on a CU next to the scan's); 0: everything in order "
-                         "on one stream (per-kernel durations then add up to the step)")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="modes_gpu_config.overlap: 0 = scan, demod and order kernels in order on one stream; 2 (default) = the "
+                         "order kernel (a few microseconds, no LDS) runs on the context's own stream next to the following "
+                         "step's scan; 1 = the demod kernel too (measured: no gain - its workgroups wait for the scan to drain)")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="one call in this many carries HIP timing events around its kernels (they cost ~9 us of idle GPU per "
+                         "kernel boundary); 1 = every call")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the scans are spread over")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                                                       "the N > 1 control flow on a box with fewer GPUs than ranks)")
@@ -238,10 +249,11 @@ def main():
         """K timed steps over this rank's HBM-resident shard (dump1090_amd/pipeline.py)"""
         def make():
             return Demodulator(device=local, run_chunks=args.run_chunks, scan_variant=args.scan_variant,
-                               overlap=bool(args.overlap), max_records=cap_records if world > 1 else 0, **flags)
+                               overlap=args.overlap, demod_variant=args.demod_variant,
+                               max_records=cap_records if world > 1 else 0, **flags)
         return run_steps(make, iq, lo, calls, flags, steps, warm, args.depth, world=world, rank=rank, dist=dist,
                          coll_device=coll_dev, cap_records=cap_records, streams=works,
-                         device_sync=lambda: torch.cuda.synchronize(dev))
+                         device_sync=lambda: torch.cuda.synchronize(dev), time_every=max(1, args.time_every))
 
     line = {}
     noise = None
@@ -312,7 +324,7 @@ def main():
         "%d MiB per GPU of sigma=3 noise + DF11/DF17 frames, --fix; BASELINE.json configs[%d]" % (args.frames_mib, 2 if world == 1 else 3))
     samples_per_step = head["total"] // 2                                     # the whole stream: every rank's shard
     value = samples_per_step * head_steps / head["elapsed"] / 1e6
-    achieved = head["call_bytes"] / (head["scan_ms"] * 1e-3) / 1e9           # this rank's launches: 2 B per sample
+    achieved = head["call_bytes"] / (max(head["scan_ms"], 1e-9) * 1e-3) / 1e9  # this rank's launches: 2 B per sample
     traffic, traffic_note = measured_traffic(args.mib) if noise is not None else (None, "no PMC pass for this workload")
     line = {
         "metric": "IQ Msamples/s demodulated", "value": round(value, 1), "unit": "Msamples/s",
@@ -323,14 +335,16 @@ def main():
                    "flags": "--raw --no-fix" if noise is not None else "--raw",
                    "sharding": "buffers over %d rank(s)" % world, "settle_steps": args.settle if noise is not None else 6,
                    "step": "scan + demod + order kernels, record fetch%s, host resolve + --raw formatting on a second thread; "
-                           "%d detect(s) in flight; overlap=%d" % (
+                           "%d detect(s) in flight; overlap=%d; completion by a host-visible word (no event in the stream), kernel timing events on "
+                           "one call in %d" % (
                                ", device-resident lists gathered to rank 0 over %s (counts all_gather + exact-size send/recv)" % (
                                    "RCCL" if args.backend == "nccl" else args.backend) if world > 1 else "",
-                               head["depth"], args.overlap)},
+                               head["depth"], args.overlap, args.time_every)},
         "msgs_per_s": round(head.get("msgs", 0) / head["elapsed"], 2) if rank == 0 else None,
         "preambles_per_step_rank0": int(head["last"].get("n_preambles", 0)),
         "forwarded_per_step_rank0": int(head["last"].get("n_forwarded", 0)),
-        "kernel_ms": {"scan": round(head["scan_ms"], 4), "demod": round(head["demod_ms"], 4), "order": round(head["order_ms"], 4)},
+        "kernel_ms": {"scan": round(head["scan_ms"], 4), "demod": round(head["demod_ms"], 4), "order": round(head["order_ms"], 4),
+                      "timed_calls": head["timed_calls"], "of_calls": head["steps"] * head["calls_per_step"]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": "scan_kernel", "algorithmic_bytes_per_launch": int(head["call_bytes"])},
@@ -340,7 +354,7 @@ def main():
                         "(1 per 65,536 samples, 10 %% with a flipped bit, seam offsets), --fix" % (2 if world == 1 else 3, args.frames_mib))
         if rank == 0:
             f["listing_check"] = frames["check"]
-        f["wall_over_kernels"] = round(f["ms_per_step"] / (frames["scan_ms"] + frames["demod_ms"] + frames["order_ms"]), 3)
+        f["wall_over_kernels"] = round(f["ms_per_step"] / max(1e-9, frames["calls_per_step"] * (frames["scan_ms"] + frames["demod_ms"] + frames["order_ms"])), 3)
         line["frames"] = f
     elif frames is not None and rank == 0:
         line["listing_check"] = frames["check"]

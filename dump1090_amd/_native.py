@@ -35,7 +35,7 @@ class GpuConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("fix_errors", C.c_int32), ("aggressive", C.c_int32),
                 ("keep_candidates", C.c_int32), ("run_chunks", C.c_uint32), ("slot_cap", C.c_uint32),
                 ("max_records", C.c_uint32), ("scan_variant", C.c_uint32), ("overlap", C.c_uint32),
-                ("flags", C.c_uint32), ("direct_records", C.c_uint32), ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32), ("direct_records", C.c_uint32), ("demod_variant", C.c_uint32)]
 
 
 GPU_NO_RETRY = 1
@@ -114,8 +114,8 @@ SINK_FN = C.CFUNCTYPE(None, C.POINTER(ModesMessage), C.c_uint32, C.c_uint32, C.c
 
 # every symbol include/*.h declares (tests/test_abi.py checks the libraries export them)
 GPU_SYMBOLS = ("modes_gpu_create", "modes_gpu_destroy", "modes_gpu_last_error", "modes_gpu_compute_magnitude",
-               "modes_gpu_detect", "modes_gpu_fetch", "modes_gpu_fetch_device", "modes_gpu_set_output", "modes_gpu_stream_wait", "modes_gpu_demod_host", "modes_gpu_submit_host",
-               "modes_gpu_host_alloc", "modes_gpu_host_free", "modes_gpu_compute_power",
+               "modes_gpu_detect", "modes_gpu_fetch", "modes_gpu_fetch_device", "modes_gpu_set_output", "modes_gpu_stream_wait", "modes_gpu_set_timing", "modes_gpu_demod_host", "modes_gpu_submit_host",
+               "modes_gpu_host_alloc", "modes_gpu_host_free", "modes_gpu_compute_power", "modes_gpu_debug_tables",
                "modes_gpu_synth_noise", "modes_gpu_fill", "modes_gpu_abi_version")
 HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_set_time", "modes_host_resolve", "modes_host_resolve_to_array",
                 "modes_host_resolve_raw", "modes_host_wants",
@@ -135,6 +135,13 @@ def gpu_lib():
     if _gpu is None:
         if not os.path.exists(GPU_LIB):
             raise ModesError(-2, "%s is not built (python -c 'import __graft_entry__ as g; g.build()')" % GPU_LIB)
+        # torch brings its own copy of the HIP runtime: load it first, so that this library binds to the runtime torch's
+        # streams and tensors live in (loaded the other way round the process ends up with two runtimes, and the second
+        # one sees no device)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(GPU_LIB)
         L.modes_gpu_create.argtypes = [C.POINTER(GpuConfig), C.POINTER(C.c_void_p)]
         L.modes_gpu_destroy.argtypes = [C.c_void_p]
@@ -143,10 +150,12 @@ def gpu_lib():
         L.modes_gpu_last_error.restype = C.c_char_p
         L.modes_gpu_compute_magnitude.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.modes_gpu_compute_power.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.modes_gpu_debug_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.modes_gpu_detect.argtypes = [C.c_void_p, C.POINTER(Span), C.c_void_p]
         L.modes_gpu_fetch.argtypes = [C.c_void_p, C.POINTER(GpuResult)]
         L.modes_gpu_fetch_device.argtypes = [C.c_void_p, C.POINTER(GpuResult)]
         L.modes_gpu_stream_wait.argtypes = [C.c_void_p, C.c_void_p]
+        L.modes_gpu_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.modes_gpu_set_output.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.modes_gpu_submit_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
         L.modes_gpu_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]

@@ -100,6 +100,28 @@ MODES_HD uint32_t modes_lut_index(uint32_t i_byte, uint32_t q_byte) {
     return s > 32767u ? 32767u : s;
 }
 
+/* The reference's magnitude WITHOUT the table: maglut[...] = round(360 * sqrt(s)) (dump1090.c:362, in double) for the
+ * saturated power s_sat = min(s, 32767) the kernels carry (32767 stands for 32768: I = Q = 255; 32767 itself is not a
+ * sum of two squares).  360 sqrt(s) is never a half-integer, so m is the one integer with (m - 1/2)^2 < 129600 s <
+ * (m + 1/2)^2, i.e. m^2 - m < N <= m^2 + m for N = 129600 s (< 2^32: 32-bit arithmetic throughout).  A single-precision
+ * square root is within one of m; the two comparisons settle it.  The demod kernel uses this for powers beyond its small
+ * LDS table (strong signals), so that the table fits next to the scan kernel's workgroups.  Exhaustively checked against the
+ * table on the host (tests/test_core.py) and on the device (tests/test_gpu_parity.py). */
+MODES_HD uint32_t modes_mag_exact(uint32_t s_sat) {
+    const uint32_t s = s_sat >= 32767u ? 32768u : s_sat;
+    const uint32_t n = s * 129600u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t m = (uint32_t)(__builtin_sqrtf((float)n) + 0.5f);
+    const uint32_t mm = __umul24(m, m);                      /* m <= 65167: the low 32 bits of the 24-bit product are exact */
+#else
+    uint32_t m = (uint32_t)(__builtin_sqrtf((float)n) + 0.5f);
+    const uint32_t mm = m * m;
+#endif
+    if (mm - m >= n && m > 0) m -= 1;                        /* N <= m^2 - m : one too many */
+    else if (mm + m < n) m += 1;                             /* N >  m^2 + m : one short    */
+    return m;
+}
+
 /* ---------------------------------------------------- preamble predicates */
 
 /* The full predicate of dump1090.c:1602-1650 on true magnitudes m[0..14]. */

@@ -183,18 +183,31 @@ __global__ __launch_bounds__(256) void power_kernel(const uint8_t *__restrict__ 
 // Device-side state of one detect call, zeroed by the scan kernel.
 struct ResultHeader {
     uint32_t n_records;               // staging slots reserved so far = records (exact reservation: no holes)
-    uint32_t done;                    // demod workgroups retired; the last one turns the batch counts into offsets
+    uint32_t ordered;                 // finalize_kernel has put the (short) list in order itself: order_kernel has nothing to do
     uint32_t pad[2];
 };
 
-// What one demod workgroup found, written straight to pinned host memory when the workgroup retires
-// (plain stores, visible to the host once the kernel has completed): no totals atomics on the device
-// and no result-copy kernel.
+// What one demod workgroup found: plain stores to device memory when it retires, summed by finalize_kernel.  (A ticket
+// that lets the LAST demod workgroup do the summing needs an agent-scope release per workgroup = an L2 write-back on its
+// XCD; the workgroups that finish early then slow their neighbours' loads down - measured: the kernel went from 38 to
+// 57 us, profiles/r02p.  A kernel boundary does that cache maintenance once.)
 struct WgTotals {
     unsigned long long n_forwarded, n_preambles;
-    uint32_t n_records;      // records written
     uint32_t flags;          // bit 0: a run overflowed its slot list; bit 1: internal inconsistency (pre-test vs full gate)
-    uint32_t pad[2];
+    uint32_t pad;
+};
+
+// What finalize_kernel tells the host, in pinned host memory: the totals of the call, whether the ordered list is
+// complete already, and - written LAST, behind a system-scope release - the sequence number of the call.
+// modes_gpu_fetch polls that word: the completion of a call costs no packet in the stream (an event record between the
+// last kernel and the next call's scan kernel is 5.6 us of idle GPU; timing events around the kernels 9 us each:
+// profiles/r02f), so consecutive calls run back to back.
+struct HostHeader {
+    unsigned long long n_forwarded, n_preambles;
+    uint32_t n_records;
+    uint32_t flags;
+    uint32_t ordered;
+    uint32_t seq;
 };
 
 struct ScanParams {
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanPara
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t run = blockIdx.x * kScanWaves + wave;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *P.hdr = ResultHeader{0, 0, {0, 0}};   // demod_kernel accumulates into it
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.hdr = ResultHeader{0, 0, {0, 0}};   // demod_kernel reserves record slots in it
     if (run >= P.nruns) return;
     uint32_t *ring = ring_all[wave];
 
@@ -310,10 +323,7 @@ __device__ unsigned long long g_trace[8192 * 8];      // per demod wavefront: st
 constexpr uint32_t kNoPos = 0xFFFFFFFFu;          // a survivor whose first gate failed after all (edge of the span)
 constexpr uint64_t kNoKey = ~0ull;
 
-constexpr int kDemodWaves = 4;        // wavefronts per demod workgroup: 4 waves, < 10 KiB of LDS and the magnitude table read
-                                      // through L1/L2, so that one fits on a CU NEXT TO the scan kernel's 12 workgroups
-                                      // (153,600 of 163,840 B of LDS, 24 of 32 wave slots) - DESIGN.md 3.2
-constexpr int kDemodThreads = kDemodWaves * 64;
+// wavefronts per demod workgroup: a template parameter of the kernel (4 with LutSmall, 8 with LutFull)
 constexpr int kDemodGroup = 64;       // runs whose slot lists one demod workgroup walks together (one per lane of a wavefront)
 
 struct DemodParams {
@@ -334,8 +344,8 @@ struct DemodParams {
     uint32_t *batch_count;     // [nbatches] records of each batch
     uint32_t *batch_off;       // [nbatches] exclusive prefix of batch_count (written by the last workgroup to retire)
     uint32_t nbatches;
-    ResultHeader *hdr;         // device: slot reservation counter, retirement ticket (zeroed by the scan kernel)
-    WgTotals *host_totals;     // device view of the pinned per-workgroup totals, [gridDim.x]
+    ResultHeader *hdr;         // device: slot reservation counter (zeroed by the scan kernel)
+    WgTotals *totals;          // [gridDim.x] what each workgroup found (device memory)
     uint32_t max_records;
 };
 
@@ -523,7 +533,7 @@ __global__ __launch_bounds__(kScan2Waves * kWave) void scan_kernel(ScanParams P)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: addresses stay in SGPRs
     const uint32_t run = blockIdx.x * kScan2Waves + wave;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *P.hdr = ResultHeader{0, 0, {0, 0}};   // demod_kernel accumulates into it
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.hdr = ResultHeader{0, 0, {0, 0}};   // demod_kernel reserves record slots in it
     if (run >= P.nruns) return;
     // Runs whose loads (chunks c0-1 .. c1+1, the prefetch runs two chunks ahead) all lie inside the
     // span take the unguarded instantiation; that is every run except the first and the last few.
@@ -559,16 +569,39 @@ __device__ __forceinline__ uint32_t load_sample(const uint8_t *iq, int64_t sampl
 __device__ __forceinline__ bool samples_inside(int64_t first, int64_t last, int64_t lo, int64_t hi) {
     return 2 * first >= lo && 2 * last + 2 <= hi;
 }
-// The magnitude table in global memory (64 KiB), read through a raw buffer descriptor: SGPR base + one
-// VGPR byte offset per gather (no 64-bit address arithmetic in the vector unit).  The hot entries - the small
-// powers of noise - stay in the CU's L1, the rest in L2.
-struct Lut {
-    __amdgpu_buffer_rsrc_t r;
-    __device__ __forceinline__ uint32_t operator[](uint32_t idx) const {
-        return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, idx * 2u, 0, 0);
-    }
+// The magnitude table as the demod kernel sees it.  Two forms:
+//   LutFull   the whole table in 64 KiB of LDS, shared by the 8 wavefronts of a workgroup (2 workgroups per CU).  Production.
+//   LutSmall  the first 512 entries (powers below 512: amplitudes below 22 LSB - all of the noise) in 1 KiB of LDS,
+//             modes_mag_exact (a square root and two comparisons, modes_core.h) beyond.  With it a 4-wave demod workgroup
+//             needs < 10 KiB of LDS and fits on a CU NEXT TO the scan kernel's 12 workgroups (153,600 of 163,840 B of LDS,
+//             24 of 32 wave slots).  Built to run the demod kernel of one call under the scan of the next (overlap = 1);
+//             measured (profiles/r02c): 0.079 ms alone against LutFull's 0.050 per GiB of noise, 1.25 against 0.95 ms on
+//             the message-dense capture (strong samples take the square root), and overlapped the step only goes from
+//             0.308 to 0.297 ms: the scan's 6 waves per SIMD leave registers for ONE demod wavefront per SIMD, and one
+//             4-wave workgroup per CU is too little parallelism for a latency-bound kernel - it needs the whole next scan
+//             to finish.  Kept as demod_variant 1: an independent second implementation the parity tests cross-check.
+// fast(idx) is only valid for idx < kEntries (it masks); callers OR their indices together and repeat the few lookups
+// that were out of range through operator[].
+// Also measured and rejected (profiles/r02a): the table left in global memory and read through L1/L2 - 2.5x slower alone
+// and no gain overlapped: 36 M two-byte gathers pull 2 GB of lines through the L2 the scan is streaming 1 GB through.
+struct LutSmall {
+    static constexpr uint32_t kEntries = 512;
+    static constexpr bool kHybrid = true;
+    const uint16_t *p;
+    __device__ __forceinline__ uint32_t fast(uint32_t idx) const { return p[idx & (kEntries - 1)]; }
+    __device__ __forceinline__ uint32_t operator[](uint32_t idx) const { return idx < kEntries ? (uint32_t)p[idx] : modes_mag_exact(idx); }
 };
+struct LutFull {
+    static constexpr uint32_t kEntries = MODES_LUT_ENTRIES;
+    static constexpr bool kHybrid = false;
+    const uint16_t *p;
+    __device__ __forceinline__ uint32_t fast(uint32_t idx) const { return p[idx]; }
+    __device__ __forceinline__ uint32_t operator[](uint32_t idx) const { return p[idx]; }
+};
+// bits of a packed index pair (idx0 | idx1 << 16) that are set only when one of the two is beyond LutSmall
+constexpr uint32_t kBigPair = ~((LutSmall::kEntries - 1) | ((LutSmall::kEntries - 1) << 16));
 // magnitude of a sample packed as I | Q << 8 (low 16 bits)
+template <class Lut>
 __device__ __forceinline__ int mag_of(const Lut lut, uint32_t iq16) {
     return lut[modes_lut_index(iq16 & 0xff, (iq16 >> 8) & 0xff)];
 }
@@ -703,6 +736,7 @@ __device__ __forceinline__ uint32_t pk_lut_index(uint32_t w) { return modes_powe
 
 // Exact preamble predicate (dump1090.c:1602-1650) at buffer sample p, magnitudes from the LDS LUT.
 // Guarded form: 2-byte loads, bytes outside the span read as 127.
+template <class Lut>
 __device__ __forceinline__ bool preamble_at_guarded(const uint8_t *iq, int64_t lo, int64_t hi, const Lut lut, uint32_t p) {
     int m[15];
 #pragma unroll
@@ -712,18 +746,40 @@ __device__ __forceinline__ bool preamble_at_guarded(const uint8_t *iq, int64_t l
 }
 // Fast form: the 15 samples are two 16-byte loads at a 2-byte aligned address (unaligned-access mode, raw buffer
 // descriptor); voff = byte offset of sample p from the descriptor's base.
-__device__ __forceinline__ bool preamble_at_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const Lut lut) {
-    const u32x4 wa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0), wb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16u, 0, 0);
-    const uint32_t w[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+template <bool EXACT, class Lut>
+__device__ __forceinline__ bool preamble_eval(const uint32_t (&idx)[8], const Lut lut) {
     int m[16];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const uint32_t idx = pk_lut_index(w[i]);
-        m[2 * i] = lut[idx & 0xffffu];
-        m[2 * i + 1] = lut[idx >> 16];
+        m[2 * i] = (int)(EXACT ? lut[idx[i] & 0xffffu] : lut.fast(idx[i] & 0xffffu));
+        m[2 * i + 1] = (int)(EXACT ? lut[idx[i] >> 16] : lut.fast(idx[i] >> 16));
     }
     struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
     return modes_preamble_exact(Win{m});
+}
+template <class Lut>
+__device__ __forceinline__ bool preamble_at_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const Lut lut) {
+    const u32x4 wa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0), wb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16u, 0, 0);
+    const uint32_t w[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+    if constexpr (!Lut::kHybrid) {                                           // index and look up dword by dword
+        int m[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t ix = pk_lut_index(w[i]);
+            m[2 * i] = (int)lut.p[ix & 0xffffu];
+            m[2 * i + 1] = (int)lut.p[ix >> 16];
+        }
+        struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
+        return modes_preamble_exact(Win{m});
+    }
+    uint32_t idx[8], big = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { idx[i] = pk_lut_index(w[i]); big |= idx[i]; }
+    bool ok = preamble_eval<false>(idx, lut);
+    if (Lut::kHybrid && __any((big & kBigPair) != 0)) {                       // a strong sample somewhere in the wavefront
+        if (big & kBigPair) ok = preamble_eval<true>(idx, lut);
+    }
+    return ok;
 }
 
 // Noise-gate pre-test (dump1090.c:1713-1723): the sum of |lo - hi| over 56 consecutive bit pairs
@@ -736,7 +792,6 @@ __device__ __forceinline__ bool preamble_at_fast(__amdgpu_buffer_rsrc_t rsrc, ui
 // multiply + multiply-add.  voff = byte offset of the first pair from the descriptor's base.
 constexpr uint32_t kUnknown = 0xFFFFFFFFu;      // a delta sum the pre-test did not need
 constexpr int kGateLanes = 4;                   // lanes per preamble in the gate pre-test
-constexpr int kGatePerRound = kDemodThreads / kGateLanes;   // preambles a workgroup tests per round
 __device__ __forceinline__ void half_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, int t, u32x4 (&w)[4]) {
     const uint32_t o = voff + 16u * (uint32_t)t;
 #pragma unroll
@@ -746,14 +801,15 @@ __device__ __forceinline__ void half_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
 }
 // Returns this lane's part of the sum.  *first: flags of the lane's first four pairs (pairs 4t .. 4t+3 of
 // the 56), bit k = |lo - hi| < 256, bit 4 + k = lo > hi, bit 8 = (lo == hi) of its first pair.
-__device__ __forceinline__ uint32_t half_eval(const u32x4 (&w)[4], const Lut lut, uint32_t *first) {
+template <bool EXACT, class Lut>
+__device__ __forceinline__ uint32_t half_sum(const uint32_t (&idx)[16], const Lut lut, uint32_t *first) {
     uint32_t acc = 0, f = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t idx = pk_lut_index(w[i][k]);                      // both LUT indices
-            const uint32_t a = lut[idx & 0xffffu], b = lut[idx >> 16];
+            const uint32_t ix = idx[4 * i + k];                              // both LUT indices
+            const uint32_t a = EXACT ? lut[ix & 0xffffu] : lut.fast(ix & 0xffffu), b = EXACT ? lut[ix >> 16] : lut.fast(ix >> 16);
             if (i == 0 && first) {
                 const uint32_t d = __builtin_amdgcn_sad_u16(a, b, 0u);
                 f |= (d < 256u ? 1u : 0u) << k | (a > b ? 1u : 0u) << (4 + k);
@@ -767,16 +823,49 @@ __device__ __forceinline__ uint32_t half_eval(const u32x4 (&w)[4], const Lut lut
     if (first) *first = f;
     return acc;
 }
+template <class Lut>
+__device__ __forceinline__ uint32_t half_eval(const u32x4 (&w)[4], const Lut lut, uint32_t *first) {
+    if constexpr (!Lut::kHybrid) {                                           // index and look up dword by dword: the gathers spread over the VALU work
+        uint32_t acc = 0, f = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t ix = pk_lut_index(w[i][k]);                   // both LUT indices
+                const uint32_t a = lut.p[ix & 0xffffu], b = lut.p[ix >> 16];
+                if (i == 0 && first) {
+                    const uint32_t d = __builtin_amdgcn_sad_u16(a, b, 0u);
+                    f |= (d < 256u ? 1u : 0u) << k | (a > b ? 1u : 0u) << (4 + k);
+                    if (k == 0) f |= (a == b ? 1u : 0u) << 8;
+                    acc += d;
+                } else {
+                    acc = __builtin_amdgcn_sad_u16(a, b, acc);               // += |a - b| (high halves are zero)
+                }
+            }
+        }
+        if (first) *first = f;
+        return acc;
+    }
+    uint32_t idx[16], big = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { idx[4 * i + k] = pk_lut_index(w[i][k]); big |= idx[4 * i + k]; }
+    uint32_t acc = half_sum<false>(idx, lut, first);
+    if (Lut::kHybrid && __any((big & kBigPair) != 0)) {                       // a strong sample somewhere in the wavefront
+        if (big & kBigPair) acc = half_sum<true>(idx, lut, first);
+    }
+    return acc;
+}
 __device__ __forceinline__ void surv_push(uint32_t *list, uint32_t k, uint32_t p, uint32_t sum56, uint32_t sum112) {
-    list[4 * k] = p;                                                         // [4k + 3]: the rank, filled in by stage 3
-    list[4 * k + 1] = sum56;
-    list[4 * k + 2] = sum112;
+    list[3 * k] = p;
+    list[3 * k + 1] = sum56;
+    list[3 * k + 2] = sum112;
 }
 
 // First half of the demodulation of one preamble by the whole wavefront: magnitudes, the delta sums of
 // dump1090.c:1713-1717 as far as they are needed, the first slicing pass and its noise gate.
-// known56 / known112: the sums the pre-test already has (kUnknown otherwise).  lut: the magnitude table in
-// global memory (64 KiB, read through L1/L2: the hot entries - small powers - stay in the CU's L1).
+// known56 / known112: the sums the pre-test already has (kUnknown otherwise).
 struct Front {
     int lo1, hi1, lo2, hi2, pre;
     int sum56, sum112;
@@ -784,7 +873,7 @@ struct Front {
     modes_m128 bits0;
     uint8_t err0;
 };
-template <bool GUARD>
+template <bool GUARD, class Lut>
 __device__ __forceinline__ Front demod_front(const DemodParams &P, const Lut lut, int lane, int64_t pc, uint32_t known56,
                                              uint32_t known112) {
     const uint8_t *iq = P.iq;
@@ -810,7 +899,7 @@ __device__ __forceinline__ Front demod_front(const DemodParams &P, const Lut lut
 
 // Full demodulation (both attempts) -> the record in staging slot `slot`, keyed `key`.  Returns false when the first
 // noise gate fails after all (then nothing is written; the caller has already ruled that out for its entries).
-template <bool GUARD>
+template <bool GUARD, class Lut>
 __device__ __forceinline__ bool demod_full(const DemodParams &P, const Lut lut, const uint32_t *s_esyn, int lane, int64_t pc,
                                            uint32_t known56, uint32_t known112, uint32_t slot, uint64_t key) {
     const uint64_t g = (uint64_t)pc + P.g0;
@@ -895,22 +984,32 @@ __device__ __forceinline__ bool demod_full(const DemodParams &P, const Lut lut, 
 //            (coalesced sample loads; the sequential parts of the reference become carry chains, see
 //            modes_core.h): both attempts, syndrome and repair search -> record + (batch, rank) key.
 // Lists live in LDS; appends from stages 2a/2b reserve their slots with one LDS atomic per wavefront.
-// The workgroup that retires last turns the per-batch record counts into offsets for order_kernel.
+// finalize_kernel (one workgroup, next in the stream) turns the per-batch record counts into offsets.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kDemodThreads) void demod_kernel(DemodParams P) {
+template <int kDemodWaves, class Lut>
+__global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80))) void demod_kernel(DemodParams P) {
+    constexpr int kDemodThreads = kDemodWaves * 64;
+    constexpr int kGatePerRound = kDemodThreads / kGateLanes;   // preambles a workgroup tests per round
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[Lut::kEntries];
     __shared__ uint32_t s_pre[kDemodGroup + 1];        // exclusive prefix of the batch's (clamped) run counts
     __shared__ uint32_t s_list[kDemodThreads];         // preambles awaiting the gate pre-test
     __shared__ uint32_t s_long[2 * kDemodThreads];     // (position, sum over the first 56 pairs) of those that decode as long
-    __shared__ uint32_t s_surv[4 * kDemodThreads];     // (position, the two delta sums or kUnknown, rank) of those that go to stage 3
+    __shared__ uint32_t s_surv[3 * kDemodThreads];     // (position, the two delta sums or kUnknown) of those that go to stage 3
     __shared__ uint32_t s_n[2][4];                     // list counters of the current / the next block (see stage 1)
     __shared__ uint32_t s_blk[4];                      // [0] survivors dropped by the edge gate, [1] staging base, [2] records of the block
     __shared__ uint32_t s_esyn[112];
     __shared__ unsigned long long s_tot[2];
-    __shared__ uint32_t s_flags[2];                    // records written by this workgroup, WgTotals.flags
-    __shared__ uint32_t s_last;
+    __shared__ uint32_t s_flags[2];                    // [1]: WgTotals.flags bits this workgroup raises
 #ifdef MODES_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
+    if constexpr (Lut::kEntries == MODES_LUT_ENTRIES) {
+        stage_lut<kDemodThreads>(s_lut, P.tab.lut);
+    } else {                                                                 // the first entries: 16 bytes per thread and turn
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.tab.lut);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
+        for (uint32_t i = threadIdx.x; i < Lut::kEntries / 8; i += kDemodThreads) dst[i] = src[i];
+    }
     if (threadIdx.x < 112) s_esyn[threadIdx.x] = P.tab.esyn[threadIdx.x];
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_flags[threadIdx.x] = 0;
@@ -925,11 +1024,10 @@ __global__ __launch_bounds__(kDemodThreads) void demod_kernel(DemodParams P) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint8_t *iq = P.iq;
-    const Lut lut{__builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(P.tab.lut), 0, MODES_LUT_ENTRIES * 2, 0x00020000)};
+    const Lut lut{s_lut};
     const int64_t lo = P.lo, hi = P.hi;
     const uint64_t below = (1ull << lane) - 1;
     unsigned long long tot_fwd = 0, tot_cand = 0;       // tot_fwd: per lane of wavefront 0; tot_cand: workgroup-uniform
-    uint32_t tot_rec = 0;                               // workgroup-uniform
     uint32_t blk = 0;                                   // blocks processed so far: parity selects the counter set
 #ifdef MODES_TRACE
     unsigned long long tr_t[4] = {0, 0, 0, 0};          // batch set-up, stage 1, stage 2a, stages 2b + 3
@@ -1100,25 +1198,26 @@ __global__ __launch_bounds__(kDemodThreads) void demod_kernel(DemodParams P) {
             if (nsurv) {                                                     // workgroup-uniform
                 // a) survivors that skipped the pre-test: first gate now (guarded loads); a failure drops the entry
                 for (uint32_t k = (uint32_t)wave; k < nsurv; k += kDemodWaves) {
-                    if (s_surv[4 * k + 1] != kUnknown) continue;             // wave-uniform
-                    const Front f = demod_front<true>(P, lut, lane, (int64_t)s_surv[4 * k], kUnknown, kUnknown);
+                    if (s_surv[3 * k + 1] != kUnknown) continue;             // wave-uniform
+                    const Front f = demod_front<true>(P, lut, lane, (int64_t)s_surv[3 * k], kUnknown, kUnknown);
                     if (lane == 0) {
                         if (f.gate0) {
-                            s_surv[4 * k + 1] = (uint32_t)f.sum56;
-                            s_surv[4 * k + 2] = f.have112 ? (uint32_t)f.sum112 : kUnknown;
+                            s_surv[3 * k + 1] = (uint32_t)f.sum56;
+                            s_surv[3 * k + 2] = f.have112 ? (uint32_t)f.sum112 : kUnknown;
                         } else {
-                            s_surv[4 * k] = kNoPos;
+                            s_surv[3 * k] = kNoPos;
                             atomicAdd(&s_blk[0], 1u);
                         }
                     }
                 }
                 __syncthreads();
-                // b) rank by position (the block's records in stream order), one global atomic for their staging slots
+                // b) rank by position (the block's records in stream order; the ranks go where the long list was: stage 2b is
+                //    done with it), one global atomic for their staging slots
                 if ((uint32_t)tid < nsurv) {
-                    const uint32_t mine = s_surv[4 * tid];
+                    const uint32_t mine = s_surv[3 * tid];
                     uint32_t r = 0;
-                    for (uint32_t k = 0; k < nsurv; k++) r += s_surv[4 * k] < mine ? 1u : 0u;   // kNoPos is never below a live one
-                    s_surv[4 * tid + 3] = r;
+                    for (uint32_t k = 0; k < nsurv; k++) r += s_surv[3 * k] < mine ? 1u : 0u;   // kNoPos is never below a live one
+                    s_long[tid] = r;
                 }
                 if (tid == 0) {
                     const uint32_t live = nsurv - s_blk[0];
@@ -1130,10 +1229,10 @@ __global__ __launch_bounds__(kDemodThreads) void demod_kernel(DemodParams P) {
                 // c) one wavefront per record
                 const uint32_t sbase = s_blk[1], live = s_blk[2];
                 for (uint32_t k = (uint32_t)wave; k < nsurv; k += kDemodWaves) {
-                    const uint32_t pk = s_surv[4 * k];
+                    const uint32_t pk = s_surv[3 * k];
                     if (pk == kNoPos) continue;
                     const int64_t pcs = (int64_t)pk;
-                    const uint32_t k56 = s_surv[4 * k + 1], k112 = s_surv[4 * k + 2], rank = s_surv[4 * k + 3];
+                    const uint32_t k56 = s_surv[3 * k + 1], k112 = s_surv[3 * k + 2], rank = s_long[k];
                     const uint32_t slot = sbase + rank;
                     const uint64_t key = ((uint64_t)batch << 32) | (uint64_t)(prior + rank);
                     bool done;
@@ -1150,7 +1249,6 @@ __global__ __launch_bounds__(kDemodThreads) void demod_kernel(DemodParams P) {
             TRACE_ADD(3, ts3);
         }
         tot_cand += ncand;
-        tot_rec += prior;
         if (tid == 0) {
             P.cand_counts[batch] = ncand;
             P.batch_count[batch] = prior;
@@ -1167,34 +1265,105 @@ __global__ __launch_bounds__(kDemodThreads) void demod_kernel(DemodParams P) {
         }
     }
 #endif
-    // totals (tot_fwd: lanes of wavefront 0; tot_cand, tot_rec: the same number in every thread)
+    // totals (tot_fwd: lanes of wavefront 0; tot_cand: the same number in every thread)
     if (wave == 0) {
         tot_fwd = (unsigned long long)wave_sum((int)tot_fwd);                // < 2^31 per workgroup and call (slot lists are u32-indexed)
         if (lane == 0) { s_tot[0] = tot_fwd; s_tot[1] = tot_cand; }
     }
     __syncthreads();
-    if (tid == 0) {
-        P.host_totals[blockIdx.x] = WgTotals{s_tot[0], s_tot[1], tot_rec, s_flags[1], {0, 0}};
-        __threadfence();                                                     // this workgroup's batch counts before its ticket
-        s_last = atomicAdd(&P.hdr->done, 1u) == gridDim.x - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (s_last && wave == 0) {
-        // every workgroup has retired: batch_count is complete (read past the L1: other CUs wrote it)
-        __threadfence();
-        uint32_t running = 0;
-        for (uint32_t b0 = 0; b0 < P.nbatches; b0 += 64) {
-            const uint32_t b = b0 + (uint32_t)lane;
-            const uint32_t c = b < P.nbatches ? __hip_atomic_load(&P.batch_count[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            uint32_t incl = c;
+    if (tid == 0) P.totals[blockIdx.x] = WgTotals{s_tot[0], s_tot[1], s_flags[1], 0};
+}
+
+// ------------------------------------------------------------------------------------
+// finalize_kernel - ONE workgroup behind the demod kernel: sums the workgroups' totals, turns the per-batch record
+// counts into offsets (exclusive prefix), puts a SHORT list (<= inline_cap records) in stream order right away - on the
+// device and in the host's pinned copy - and publishes the call's verdict to the host (HostHeader; the sequence number
+// last, behind a system-scope release).  Long lists are left to order_kernel.
+// ------------------------------------------------------------------------------------
+struct FinalizeParams {
+    ResultHeader *hdr;
+    const WgTotals *totals;
+    uint32_t ntotals;
+    const uint32_t *batch_count;
+    uint32_t *batch_off;
+    uint32_t nbatches;
+    const modes_record *staging;
+    const uint64_t *keys;
+    modes_record *out;             // the ordered list on the device
+    modes_record *host_out;        // its pinned host copy (device view), or nullptr
+    unsigned long long *d_count;   // the caller's device count word, or nullptr
+    HostHeader *host_hdr;          // device view of the pinned header
+    uint32_t max_records;
+    uint32_t inline_cap;
+    uint32_t seq;
+};
+__global__ __launch_bounds__(512) void finalize_kernel(FinalizeParams P) {
+    __shared__ unsigned long long s_sum[2][8];
+    __shared__ uint32_t s_w[8], s_fl[8];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // totals
+    unsigned long long f = 0, c = 0;
+    uint32_t fl = 0;
+    for (uint32_t i = (uint32_t)tid; i < P.ntotals; i += 512) { f += P.totals[i].n_forwarded; c += P.totals[i].n_preambles; fl |= P.totals[i].flags; }
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t up = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += up;
-            }
-            if (b < P.nbatches) P.batch_off[b] = running + incl - c;
-            running += (uint32_t)__shfl((int)incl, 63, 64);
+    for (int off = 32; off >= 1; off >>= 1) {
+        f += (unsigned long long)__shfl_xor((long long)f, off, 64);
+        c += (unsigned long long)__shfl_xor((long long)c, off, 64);
+        fl |= (uint32_t)__shfl_xor((int)fl, off, 64);
+    }
+    if (lane == 0) { s_sum[0][wave] = f; s_sum[1][wave] = c; s_fl[wave] = fl; }
+    // exclusive prefix of the batch counts, 512 batches per pass
+    uint32_t running = 0;
+    for (uint32_t b0 = 0; b0 < P.nbatches; b0 += 512) {
+        const uint32_t b = b0 + (uint32_t)tid;
+        const uint32_t cnt = b < P.nbatches ? P.batch_count[b] : 0u;
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
         }
+        __syncthreads();                                                     // s_w of the previous pass has been read
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        uint32_t before = running;
+        for (int w = 0; w < 8; w++) {
+            const uint32_t t = s_w[w];
+            if (w < wave) before += t;
+            running += t;
+        }
+        if (b < P.nbatches) P.batch_off[b] = before + incl - cnt;
+    }
+    __syncthreads();                                                         // batch_off is written (this workgroup reads it back)
+    const uint32_t total = running;                                          // records of the call
+    const bool inl = total <= P.inline_cap && total <= P.max_records;
+    if (inl) {                                                               // order_kernel's loop, one workgroup
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.staging);
+        uint4 *dst = reinterpret_cast<uint4 *>(P.out), *hdst = reinterpret_cast<uint4 *>(P.host_out);
+        for (uint32_t piece = (uint32_t)tid; piece < 4u * total; piece += 512) {
+            const uint64_t key = P.keys[piece >> 2];
+            if (key == kNoKey) continue;
+            const uint32_t dest = P.batch_off[key >> 32] + (uint32_t)key;
+            if (dest >= P.max_records) continue;
+            const uint4 v = src[piece];
+            dst[4 * dest + (piece & 3)] = v;
+            if (hdst) hdst[4 * dest + (piece & 3)] = v;
+        }
+    }
+    __syncthreads();                                                         // the ordered list is written
+    if (tid == 0) {
+        unsigned long long nf = 0, nc = 0;
+        uint32_t flags = 0;
+        for (int w = 0; w < 8; w++) { nf += s_sum[0][w]; nc += s_sum[1][w]; flags |= s_fl[w]; }
+        if (P.d_count) *P.d_count = total;
+        P.hdr->ordered = inl ? 1u : 0u;
+        HostHeader *h = P.host_hdr;
+        h->n_forwarded = nf;
+        h->n_preambles = nc;
+        h->n_records = total;
+        h->flags = flags;
+        h->ordered = inl ? 1u : 0u;
+        __hip_atomic_store(&h->seq, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1217,6 +1386,7 @@ struct OrderParams {
     uint32_t direct_cap;
 };
 __global__ __launch_bounds__(256) void order_kernel(OrderParams P) {
+    if (P.hdr->ordered) return;                                              // the demod kernel's last workgroup did it (short list)
     const uint32_t total = P.hdr->n_records;
     if (blockIdx.x == 0 && threadIdx.x == 0 && P.d_count) *P.d_count = total;
     const uint32_t n = min(total, P.max_records);
@@ -1233,6 +1403,12 @@ __global__ __launch_bounds__(256) void order_kernel(OrderParams P) {
         dst[4 * dest + (piece & 3)] = v;
         if (direct) hdst[4 * dest + (piece & 3)] = v;
     }
+}
+
+// Debug tap: modes_mag_exact for every saturated power (the demod kernel's table-free magnitude, device square root).
+__global__ __launch_bounds__(256) void mag_exact_kernel(uint16_t *out) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s < MODES_LUT_ENTRIES) out[s] = (uint16_t)modes_mag_exact(s);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1321,7 +1497,10 @@ struct modes_gpu {
     int maxfix = 1;
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // before / after the scan kernel, after the demod kernel, results ready
+    // Kernel times: start / stop events ATTACHED to the three dispatches (hipExtLaunchKernelGGL: the timestamps of the
+    // dispatch's own completion signal - no marker packets between the kernels).  ev_done: the results are complete.
+    hipEvent_t ev_k[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // scan, demod, order: start, stop
+    hipEvent_t ev_done = nullptr;
     std::string err;
 
     uint16_t *d_lut = nullptr;
@@ -1341,8 +1520,16 @@ struct modes_gpu {
     uint32_t list_cap = 0;              // capacity of d_staging / d_keys / d_records / h_records
     ResultHeader *d_hdr = nullptr;
 
-    WgTotals *h_totals = nullptr;     // pinned + mapped, one per demod workgroup
-    WgTotals *h_totals_dev = nullptr;
+    WgTotals *d_totals = nullptr;     // device: one per resident demod workgroup
+    HostHeader *h_hdr = nullptr;      // pinned + mapped: the verdict of the call in flight (HostHeader)
+    HostHeader *h_hdr_dev = nullptr;
+    uint32_t seq = 0;                 // sequence number of the last detect
+    bool timing = true;               // attach timing events to the kernels of the next detects (modes_gpu_set_timing)
+    bool timed = false;               // ... of the detect in flight
+    bool done_recorded = false;       // ev_done was recorded behind the detect in flight (kernels follow the demod kernel)
+    hipStream_t tail_stream = nullptr;  // the stream the last kernel of the detect in flight runs on
+    bool order_launched = false;      // order_kernel is part of the detect in flight (device-output mode)
+    OrderParams order_params{};       // ... or is launched by fetch when the list turns out to be long
     uint32_t demod_grid = 0;          // workgroups of the demod launch in flight
     modes_record *h_records = nullptr;  // pinned + mapped, list_cap
     modes_record *h_records_dev = nullptr;
@@ -1390,6 +1577,8 @@ static int grow(modes_gpu *ctx, T **ptr, size_t *have, size_t want_bytes) {
     *have = want_bytes;
     return MODES_OK;
 }
+
+static int wait_results(modes_gpu *ctx);
 
 static int grid_for(uint64_t items, int per_block) {
     uint64_t b = (items + per_block - 1) / per_block;
@@ -1445,10 +1634,14 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
         hipDeviceProp_t prop;
         int per_cu = 0;
         CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
-        CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel, kDemodThreads, 0));
+        if (ctx->cfg.demod_variant == 1) CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<4, LutSmall>, 256, 0));
+        else                             CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<8, LutFull>, 512, 0));
         ctx->demod_wgs = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, prop.multiProcessorCount);
     }
-    for (auto &e : ctx->ev) CREATE_TRY(hipEventCreate(&e));
+    for (auto &e : ctx->ev_k) CREATE_TRY(hipEventCreate(&e));
+    CREATE_TRY(hipEventCreate(&ctx->ev_done));
+    if (const char *m = getenv("MODES_GPU_TIMING"))              // measurement knob (tools/gpu_round.sh): 0 = no kernel events
+        ctx->timing = atoi(m) != 0;
     // tables: the magnitude LUT exactly as the reference builds it (dump1090.c:359-364, double
     // arithmetic on the host) and the 112 single-bit syndromes.
     std::vector<uint16_t> lut(MODES_LUT_ENTRIES, 0);
@@ -1462,8 +1655,10 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     CREATE_TRY(hipMemcpy(ctx->d_lut, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(ctx->d_esyn, esyn, sizeof esyn, hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hdr), sizeof(ResultHeader)));
-    CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_totals), sizeof(WgTotals) * ctx->demod_wgs, hipHostMallocMapped));
-    CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_totals_dev), ctx->h_totals, 0));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_totals), sizeof(WgTotals) * ctx->demod_wgs));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hdr), sizeof(HostHeader), hipHostMallocMapped));
+    CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_hdr_dev), ctx->h_hdr, 0));
+    memset(ctx->h_hdr, 0, sizeof(HostHeader));
 #undef CREATE_TRY
     if (alloc_lists(ctx, ctx->cfg.max_records) != MODES_OK) return bail(MODES_ERR_NOMEM);
     *out = ctx;
@@ -1473,16 +1668,17 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
 void modes_gpu_destroy(modes_gpu *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
-    if (ctx->in_flight && ctx->ev[3]) (void)hipEventSynchronize(ctx->ev[3]);   // kernels of a detect nobody fetched
+    if (ctx->in_flight) (void)wait_results(ctx);                            // kernels of a detect nobody fetched
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     void *dev[] = {ctx->d_lut, ctx->d_esyn, ctx->d_slots, ctx->d_cand_slots, ctx->d_counts, ctx->d_cand_offsets,
-                   ctx->d_cand_dense, ctx->d_staging, ctx->d_keys, ctx->d_records, ctx->d_hdr, ctx->d_stage};
+                   ctx->d_cand_dense, ctx->d_staging, ctx->d_keys, ctx->d_records, ctx->d_hdr, ctx->d_stage, ctx->d_totals};
     for (void *p : dev)
         if (p) (void)hipFree(p);
-    if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
+    if (ctx->h_hdr) (void)hipHostFree(ctx->h_hdr);
     if (ctx->h_records) (void)hipHostFree(ctx->h_records);
-    for (auto &e : ctx->ev)
+    for (auto &e : ctx->ev_k)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1527,6 +1723,17 @@ int modes_gpu_compute_power(modes_gpu *ctx, const void *d_iq, uint64_t nsamples,
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     hipLaunchKernelGGL(power_kernel, dim3(grid_for((nsamples + 7) / 8, 256)), dim3(256), 0, pick_stream(ctx, stream),
                        static_cast<const uint8_t *>(d_iq), nsamples, static_cast<uint16_t *>(d_s));
+    HIP_TRY(ctx, hipGetLastError());
+    return MODES_OK;
+}
+
+int modes_gpu_debug_tables(modes_gpu *ctx, void *d_lut, void *d_exact, void *stream) {
+    if (!ctx) return MODES_ERR_ARG;
+    if (!d_lut || !d_exact) return fail(ctx, MODES_ERR_ARG, "debug_tables: null pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipMemcpyAsync(d_lut, ctx->d_lut, MODES_LUT_ENTRIES * 2, hipMemcpyDeviceToDevice, pick_stream(ctx, stream)));
+    hipLaunchKernelGGL(mag_exact_kernel, dim3(MODES_LUT_ENTRIES / 256), dim3(256), 0, pick_stream(ctx, stream),
+                       static_cast<uint16_t *>(d_exact));
     HIP_TRY(ctx, hipGetLastError());
     return MODES_OK;
 }
@@ -1594,7 +1801,8 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     const uint64_t nchunks = (uint64_t)(p_end + kLookback + kChunkSamples - 1) / kChunkSamples;
     uint32_t R = ctx->cfg.run_chunks;
     // automatic run length: long runs amortise a run's set-up in the scan (16 chunks is enough), but the
-    // demod kernel wants at least one batch of kDemodGroup runs per resident workgroup
+    // demod kernel wants at least one batch of kDemodGroup runs per resident workgroup (two per workgroup, dealt
+    // dynamically, measured worse: the last batch handed out ends one batch time after the average - profiles/r02k)
     if (R == 0) R = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(32, nchunks / ((uint64_t)kDemodGroup * ctx->demod_wgs)));
     if (R > 8192) return fail(ctx, MODES_ERR_ARG, "run_chunks=%u: at most 8192", R);
     R += R & 1;                                                   // the scan loop is unrolled by two chunks
@@ -1655,8 +1863,24 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     dp.batch_off = d_batch_off;
     dp.nbatches = nbatches;
     dp.hdr = ctx->d_hdr;
-    dp.host_totals = ctx->h_totals_dev;
+    dp.totals = ctx->d_totals;
     dp.max_records = ctx->cfg.max_records;
+
+    FinalizeParams fp{};
+    fp.hdr = ctx->d_hdr;
+    fp.totals = ctx->d_totals;
+    fp.batch_count = d_batch_count;
+    fp.batch_off = d_batch_off;
+    fp.nbatches = nbatches;
+    fp.staging = ctx->d_staging;
+    fp.keys = ctx->d_keys;
+    fp.out = ctx->d_user_records ? ctx->d_user_records : ctx->d_records;
+    fp.host_out = ctx->h_records_dev;
+    fp.d_count = ctx->d_user_count;
+    fp.host_hdr = ctx->h_hdr_dev;
+    fp.max_records = ctx->cfg.max_records;
+    fp.inline_cap = std::min(ctx->cfg.direct_records, ctx->cfg.max_records);
+    fp.seq = ++ctx->seq;
 
     OrderParams op{};
     op.hdr = ctx->d_hdr;
@@ -1669,31 +1893,58 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     op.max_records = ctx->cfg.max_records;
     op.direct_cap = std::min(ctx->cfg.direct_records, ctx->cfg.max_records);
 
-    // The header is zeroed by the scan kernel itself, so a detect is exactly: scan, demod, order (, prefix).
-    // Events: around the scan (the roofline kernel), after the demod kernel, and when the results are complete.
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+    // The header is zeroed by the scan kernel itself, so a detect is exactly: scan, demod, finalize (, order) (, prefix) - and,
+    // unless the caller asked for kernel times, NOTHING else in the stream: the results' completion is a word finalize_kernel
+    // writes to pinned host memory (HostHeader.seq), so the scan kernel of the next call starts when this call's kernels end.
+    // Kernel times (modes_gpu_set_timing; on by default): start / stop events attached to the dispatches - they cost ~9 us
+    // of idle GPU per kernel boundary, so a pipelined host samples them (bench.py: one call in eight).
+    const bool timed = ctx->timing;
+    ctx->timed = timed;
+    hipEvent_t *ek = ctx->ev_k;
+    auto ev = [&](int k) -> hipEvent_t { return timed ? ek[k] : nullptr; };
+    const dim3 scan_grid(ctx->cfg.scan_variant == 1 ? (nruns + kScanWaves - 1) / kScanWaves : (nruns + kScan2Waves - 1) / kScan2Waves);
     if (ctx->cfg.scan_variant == 1)
-        hipLaunchKernelGGL(scan_fused_kernel, dim3((nruns + kScanWaves - 1) / kScanWaves), dim3(kScanWaves * kWave), 0, st, sp);
+        hipExtLaunchKernelGGL(scan_fused_kernel, scan_grid, dim3(kScanWaves * kWave), 0, st, ev(0), ev(1), 0, sp);
     else
-        hipLaunchKernelGGL(scan_kernel, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st, sp);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    // cfg.overlap: everything after the scan moves to the context's own stream (ordered behind the
-    // scan by ev[1]), so the next kernel on the caller's stream - typically another context's scan -
-    // runs concurrently with this latency-bound tail: a demod workgroup (4 waves, < 10 KiB of LDS) fits on a
-    // CU next to the scan kernel's workgroups.
+        hipExtLaunchKernelGGL(scan_kernel, scan_grid, dim3(kScan2Waves * kWave), 0, st, ev(0), ev(1), 0, sp);
+    // cfg.overlap == 1: everything after the scan moves to the context's own stream (ordered behind the
+    // scan), so the next kernel on the caller's stream - typically another context's scan -
+    // may run concurrently with this latency-bound tail (in practice a demod workgroup's 77 KiB of LDS only
+    // find room when the scan drains: DESIGN.md 3.2).
     hipStream_t st2 = st;
-    if (ctx->cfg.overlap && st != ctx->own_stream) {
+    if (ctx->cfg.overlap == 1 && st != ctx->own_stream) {
         st2 = ctx->own_stream;
-        HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev[1], 0));
+        if (!timed) HIP_TRY(ctx, hipEventRecord(ek[1], st));
+        HIP_TRY(ctx, hipStreamWaitEvent(st2, ek[1], 0));
     }
-    ctx->demod_grid = std::min<uint32_t>(nbatches, ctx->demod_wgs);        // one batch of kDemodGroup runs per workgroup and turn
-    hipLaunchKernelGGL(demod_kernel, dim3(ctx->demod_grid), dim3(kDemodThreads), 0, st2, dp);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st2));
-    hipLaunchKernelGGL(order_kernel, dim3(512), dim3(256), 0, st2, op);
-    if (ctx->cfg.keep_candidates)
+    ctx->demod_grid = std::min<uint32_t>(nbatches, ctx->demod_wgs);        // every workgroup's first batch; the rest are dealt dynamically
+    if (ctx->cfg.demod_variant == 1)
+        hipExtLaunchKernelGGL((demod_kernel<4, LutSmall>), dim3(ctx->demod_grid), dim3(256), 0, st2, ev(2), ev(3), 0, dp);
+    else
+        hipExtLaunchKernelGGL((demod_kernel<8, LutFull>), dim3(ctx->demod_grid), dim3(512), 0, st2, ev(2), ev(3), 0, dp);
+    fp.ntotals = ctx->demod_grid;
+    hipExtLaunchKernelGGL(finalize_kernel, dim3(1), dim3(512), 0, st2, nullptr, nullptr, 0, fp);
+    // Lists of up to direct_records records are put in order by finalize_kernel.  order_kernel only
+    // follows in the stream when the caller consumes the list on the device (modes_gpu_set_output: it must be complete
+    // in stream order whatever its length); otherwise modes_gpu_fetch launches it when a list turns out to be long.
+    const bool tail = ctx->cfg.keep_candidates != 0;                       // prefix_kernel follows
+    ctx->order_launched = ctx->d_user_records != nullptr;
+    ctx->order_params = op;
+    if (ctx->order_launched) {
+        if (ctx->cfg.overlap == 2 && st != ctx->own_stream) {              // only the order kernel leaves the caller's stream
+            st2 = ctx->own_stream;
+            if (!timed) HIP_TRY(ctx, hipEventRecord(ek[3], st));
+            HIP_TRY(ctx, hipStreamWaitEvent(st2, ek[3], 0));
+        }
+        hipExtLaunchKernelGGL(order_kernel, dim3(512), dim3(256), 0, st2, ev(4), ev(5), 0, op);
+    }
+    if (tail)
         hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, st2, d_cand_counts, nbatches, ctx->d_cand_offsets);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st2));
+    // kernels behind finalize_kernel: their completion is an event (the host word covers the kernels up to finalize)
+    ctx->done_recorded = ctx->order_launched || tail;
+    if (ctx->done_recorded) HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st2));
+    ctx->tail_stream = st2;
 
     ctx->last_stream = st;
     ctx->last_span = *span;
@@ -1705,27 +1956,44 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     return MODES_OK;
 }
 
+// Blocks until the results of the detect in flight are complete.  The demod kernel's last workgroup publishes the call's
+// sequence number in pinned host memory: poll it (no packet in the stream); while polling, look at the stream from time
+// to time so that a faulted kernel is an error, not a hang.
+static int wait_results(modes_gpu *ctx) {
+    volatile uint32_t *seq = &ctx->h_hdr->seq;
+    for (uint64_t spins = 1;; spins++) {
+        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == ctx->seq) break;
+        if ((spins & 0x3FFF) == 0) {
+            const hipError_t q = hipStreamQuery(ctx->tail_stream);
+            if (q == hipSuccess) {                                          // everything on the stream has run
+                if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == ctx->seq) break;
+                return fail(ctx, MODES_ERR_HIP, "the kernels of the call completed without publishing results");
+            }
+            if (q != hipErrorNotReady) return fail(ctx, MODES_ERR_HIP, "while waiting for results: %s", hipGetErrorString(q));
+            if (spins > (1u << 20)) std::this_thread::yield();              // a long call: stop hogging the core
+        }
+    }
+    if (ctx->done_recorded) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done));
+    return MODES_OK;
+}
+
 // Common part of fetch / fetch_device: waits for the detect, handles the two overflow cases (which repeat the
 // call unless MODES_GPU_NO_RETRY), fills the counters of *res.  On return *n_out = records of the call.
 static int finish_detect(modes_gpu *ctx, modes_gpu_result *res, bool to_host) {
     if (!res) return fail(ctx, MODES_ERR_ARG, "fetch: null result");
     if (!ctx->in_flight) return fail(ctx, MODES_ERR_STATE, "fetch: no detect in flight");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    // Wait for THIS detect only (other work may already be queued behind it on the caller's stream);
-    // what follows runs on the context's own stream.
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
+    // Wait for THIS detect only (other work may already be queued behind it on the caller's stream): the word the demod
+    // kernel's last workgroup publishes, then the event behind any kernel that followed it.  What fetch itself launches
+    // runs on the context's own stream.
+    int rcw = wait_results(ctx);
+    if (rcw != MODES_OK) return rcw;
     hipStream_t st = ctx->own_stream;
     ctx->in_flight = false;
     memset(res, 0, sizeof *res);
-    uint64_t n_forwarded = 0, n_preambles = 0, n_records = 0;
-    uint32_t flags = 0;
-    for (uint32_t b = 0; b < ctx->demod_grid; b++) {
-        const WgTotals &t = ctx->h_totals[b];
-        n_forwarded += t.n_forwarded;
-        n_preambles += t.n_preambles;
-        n_records += t.n_records;
-        flags |= t.flags;
-    }
+    const HostHeader hh = *ctx->h_hdr;
+    const uint64_t n_forwarded = hh.n_forwarded, n_preambles = hh.n_preambles, n_records = hh.n_records;
+    const uint32_t flags = hh.flags;
     const bool no_retry = (ctx->cfg.flags & MODES_GPU_NO_RETRY) != 0;
     if (flags & 2u) return fail(ctx, MODES_ERR_HIP, "internal: the noise-gate pre-test and the full demodulation disagree");
     if (flags & 1u) {
@@ -1762,9 +2030,16 @@ static int finish_detect(modes_gpu *ctx, modes_gpu_result *res, bool to_host) {
         return finish_detect(ctx, res, to_host);
     }
     const modes_record *d_list = ctx->d_user_records ? ctx->d_user_records : ctx->d_records;
-    const uint32_t direct_cap = std::min(ctx->cfg.direct_records, ctx->cfg.max_records);
-    if (to_host && n_records > direct_cap) {                            // short lists are on the host already (order_kernel)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_records, d_list, (size_t)n_records * sizeof(modes_record), hipMemcpyDeviceToHost, st));
+    bool ordered_late = false;
+    if (!hh.ordered) {                                                  // a long list: short ones are complete, on the host too
+        if (!ctx->order_launched) {
+            hipExtLaunchKernelGGL(order_kernel, dim3(512), dim3(256), 0, st, ctx->timed ? ctx->ev_k[4] : nullptr,
+                                  ctx->timed ? ctx->ev_k[5] : nullptr, 0, ctx->order_params);
+            HIP_TRY(ctx, hipGetLastError());
+            ordered_late = true;
+        }
+        if (to_host)
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_records, d_list, (size_t)n_records * sizeof(modes_record), hipMemcpyDeviceToHost, st));
     }
     if (ctx->cfg.keep_candidates && n_preambles) {
         if (ctx->cand_dense_elems < n_preambles) {
@@ -1793,9 +2068,13 @@ static int finish_detect(modes_gpu *ctx, modes_gpu_result *res, bool to_host) {
     res->n_candidates = ctx->h_cands.size();
     res->n_forwarded = n_forwarded;
     res->n_preambles = n_preambles;
-    (void)hipEventElapsedTime(&res->scan_ms, ctx->ev[0], ctx->ev[1]);
-    (void)hipEventElapsedTime(&res->demod_ms, ctx->ev[1], ctx->ev[2]);
-    (void)hipEventElapsedTime(&res->order_ms, ctx->ev[2], ctx->ev[3]);      // order (+ candidate prefix)
+    if (ctx->timed) {
+        // the host word is published before the demod kernel has retired: its stop event may still be pending
+        (void)hipEventSynchronize(ctx->ev_k[(ctx->order_launched || ordered_late) ? 5 : 3]);
+        (void)hipEventElapsedTime(&res->scan_ms, ctx->ev_k[0], ctx->ev_k[1]);
+        (void)hipEventElapsedTime(&res->demod_ms, ctx->ev_k[2], ctx->ev_k[3]);
+        if (ctx->order_launched || ordered_late) (void)hipEventElapsedTime(&res->order_ms, ctx->ev_k[4], ctx->ev_k[5]);
+    }
     return MODES_OK;
 }
 
@@ -1803,7 +2082,17 @@ int modes_gpu_stream_wait(modes_gpu *ctx, void *stream) {
     if (!ctx) return MODES_ERR_ARG;
     if (!ctx->in_flight) return fail(ctx, MODES_ERR_STATE, "stream_wait: no detect in flight");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    HIP_TRY(ctx, hipStreamWaitEvent(static_cast<hipStream_t>(stream), ctx->ev[3], 0));
+    if (!ctx->done_recorded) {                                              // the detect left no event behind: record one now
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_done, ctx->tail_stream));
+        ctx->done_recorded = true;
+    }
+    HIP_TRY(ctx, hipStreamWaitEvent(static_cast<hipStream_t>(stream), ctx->ev_done, 0));
+    return MODES_OK;
+}
+
+int modes_gpu_set_timing(modes_gpu *ctx, int on) {
+    if (!ctx) return MODES_ERR_ARG;
+    ctx->timing = on != 0;
     return MODES_OK;
 }
 

@@ -237,12 +237,13 @@ class Demodulator:
 
     def __init__(self, device: int = 0, fix: bool = True, aggressive: bool = False, check_crc: bool = True,
                  keep_candidates: bool = False, run_chunks: int = 0, slot_cap: int = 0, max_records: int = 0,
-                 scan_variant: int = 0, overlap: bool = False, no_retry: bool = False, direct_records: int = 0):
+                 scan_variant: int = 0, overlap: int = 0, no_retry: bool = False, direct_records: int = 0,
+                 demod_variant: int = 0):
         self._lib = N.gpu_lib()
         self.flags = dict(fix=fix, aggressive=aggressive, check_crc=check_crc)
         self.device = device
         cfg = N.GpuConfig(device, int(fix), int(aggressive), int(keep_candidates), run_chunks, slot_cap, max_records,
-                          scan_variant, int(overlap), N.GPU_NO_RETRY if no_retry else 0, direct_records, 0)
+                          scan_variant, int(overlap), N.GPU_NO_RETRY if no_retry else 0, direct_records, demod_variant)
         h = C.c_void_p()
         rc = self._lib.modes_gpu_create(C.byref(cfg), C.byref(h))
         if rc != N.MODES_OK:
@@ -290,6 +291,17 @@ class Demodulator:
         self._check(self._lib.modes_gpu_compute_power(self._h, iq.data_ptr(), n, out.data_ptr(), self._stream_ptr(st)))
         return out
 
+    def debug_tables(self):
+        """(the device's magnitude table by saturated power, modes_mag_exact of every index computed on the device)"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        lut = torch.empty(32768, dtype=torch.uint16, device=dev)
+        exact = torch.empty(32768, dtype=torch.uint16, device=dev)
+        self._check(self._lib.modes_gpu_debug_tables(self._h, lut.data_ptr(), exact.data_ptr(),
+                                                     self._stream_ptr(torch.cuda.current_stream(dev))))
+        torch.cuda.synchronize(dev)
+        return lut.cpu().numpy(), exact.cpu().numpy()
+
     # ---- detectModeS (stateless part), dump1090.c:1563 -----------------------------------
     def detect(self, iq, stream_byte0: int = 0, first_block: int = 0, nblocks: int | None = None, stream=None):
         """Launch scan + demod for buffers [first_block, first_block+nblocks) of a stream whose bytes
@@ -324,6 +336,10 @@ class Demodulator:
         self._check(self._lib.modes_gpu_set_output(self._h, records.data_ptr(), records.numel() // 64,
                                                    count.data_ptr() if count is not None else None))
         self._out = (records, count)
+
+    def set_timing(self, on: bool):
+        """Kernel times in the result of every detect that follows (default on; ~9 us of idle GPU per kernel boundary)."""
+        self._check(self._lib.modes_gpu_set_timing(self._h, int(bool(on))))
 
     def stream_wait(self, stream):
         """Make `stream` wait for the results of the detect in flight (modes_gpu_stream_wait)."""

@@ -89,7 +89,7 @@ def split_calls(first_block, nblocks, ncalls, lo, total_bytes):
 
 
 def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, rank=0, dist=None, coll_device=None,
-              cap_records=1 << 16, streams=(None,), device_sync=lambda: None):
+              cap_records=1 << 16, streams=(None,), device_sync=lambda: None, time_every=8):
     """`warm` untimed + `steps` timed steps of the hot path over this rank's shard `iq` (stream bytes from `lo`;
     a CUDA uint8 tensor - anything sliceable that make_demod()'s detect accepts); a step is the sequence `calls`
     of GPU calls (split_calls).  `depth` contexts (make_demod() each) are used in rotation, so that the GPU always
@@ -98,6 +98,9 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         call i       detect queued on streams[i mod len]; N > 1: all_gather of the record counts queued behind it
         call i - 1   N > 1: counts on the host -> exact-size transfers of the device-resident lists to rank 0 queued
         call i - 2   records on rank 0's host -> resolver thread (sequential resolve + --raw formatting)
+
+    Kernel times cost idle GPU time (events around the kernels: ~9 us per boundary), so only one call in `time_every`
+    carries them (modes_gpu_set_timing); the averages returned are over those calls of the timed steps.
 
     world > 1: `dist` = torch.distributed (initialised), coll_device = where the gathered bytes travel (the CUDA
     device with RCCL; "cpu" with gloo: the lists are fetched to the host first).  Returns a dict of measurements
@@ -133,8 +136,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     last = {}
 
     def note(info, timed):
-        last.update(info)
-        if timed:
+        last.update({k: v for k, v in info.items() if not k.endswith("_ms")})
+        if timed and info.get("scan_ms", 0.0) > 0.0:                        # a call that carried timing events
             scan_ms.append(info["scan_ms"])
             demod_ms.append(info["demod_ms"])
             order_ms.append(info["order_ms"])
@@ -200,6 +203,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                         break
             free[k].wait()                                      # ... and resolved: the record buffer is reused
             stream = works[ncall % len(works)]
+            if hasattr(demods[k], "set_timing"):
+                demods[k].set_timing(ncall % time_every == 0)
             demods[k].detect(iq[clo - lo: chi - lo], stream_byte0=clo, first_block=b0, nblocks=nb, stream=stream)
             if world > 1 and on_gpu:
                 demods[k].stream_wait(comms[k])
@@ -223,8 +228,9 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    out = {"elapsed": elapsed, "scan_ms": float(np.mean(scan_ms)), "demod_ms": float(np.mean(demod_ms)),
-           "order_ms": float(np.mean(order_ms)), "last": dict(last), "depth": depth, "calls_per_step": len(calls),
+    mean = lambda v: float(np.mean(v)) if v else 0.0
+    out = {"elapsed": elapsed, "scan_ms": mean(scan_ms), "demod_ms": mean(demod_ms), "order_ms": mean(order_ms),
+           "timed_calls": len(scan_ms), "last": dict(last), "depth": depth, "calls_per_step": len(calls),
            "call_bytes": float(np.mean([chi - clo for _, _, clo, chi in calls])), "steps": steps}
     if rank == 0:
         if resolver.error is not None:

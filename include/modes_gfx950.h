@@ -60,13 +60,16 @@ typedef struct {
     uint32_t slot_cap;         /* tuning: forwarded positions per run, 0=auto         */
     uint32_t max_records;      /* record-list capacity; 0 = automatic (starts at 1<<18 and grows)  */
     uint32_t scan_variant;     /* 0 = production scan kernel; others: see DESIGN.md   */
-    uint32_t overlap;          /* 1: only the scan kernel runs on the caller's stream; the demod and order
-                                  kernels follow on the context's own stream, so work the caller queues next
-                                  (another context's scan) overlaps them.                                   */
+    uint32_t overlap;          /* 0: all kernels in order on the caller's stream.  1: only the scan kernel runs
+                                  there; the demod and order kernels follow on the context's own stream, so work
+                                  the caller queues next (another context's scan) may overlap them.  2: only the
+                                  order kernel leaves the caller's stream (it fits next to anything).          */
     uint32_t flags;            /* MODES_GPU_* below                                                       */
     uint32_t direct_records;   /* lists of at most this many records reach the host with the kernels
                                   (zero-copy stores, no copy operation); 0 = 4096                          */
-    uint32_t reserved;
+    uint32_t demod_variant;    /* 0 = production demod kernel (8-wave workgroups, the whole 64 KiB magnitude table in
+                                  LDS); 1 = 4-wave workgroups with a 1 KiB table + exact square root beyond it, small
+                                  enough to sit on a CU next to the scan kernel (the cross-check kernel) */
 } modes_gpu_config;
 
 /* modes_gpu_config.flags */
@@ -158,6 +161,11 @@ int modes_gpu_fetch_device(modes_gpu *ctx, modes_gpu_result *res);
  * where the caller's own stream does not wait for the demod and order kernels. */
 int modes_gpu_stream_wait(modes_gpu *ctx, void *stream);
 
+/* Kernel times in modes_gpu_result (scan_ms, demod_ms, order_ms): HIP events attached to the kernels of every detect
+ * that follows (on: the default) or none (off: the times read 0).  The events cost ~9 us of idle GPU per kernel
+ * boundary; a pipelined host switches them off, or on for a sample of its calls. */
+int modes_gpu_set_timing(modes_gpu *ctx, int on);
+
 /* Caller-owned device output: the ordered list is written to d_records (16-byte aligned, room for
  * `capacity` records; more records than that are MODES_ERR_OVERFLOW at fetch) and, if d_count is not
  * NULL, the number of records of the call to the 8-byte device word d_count - both by the kernels of
@@ -188,6 +196,10 @@ void modes_gpu_host_free(modes_gpu *ctx, void *p);
  * compares on the magnitude (the LUT is strictly monotone in s). */
 int modes_gpu_compute_power(modes_gpu *ctx, const void *d_iq, uint64_t nsamples,
                             void *d_s, void *stream);
+
+/* Debug / test tap of the demod kernel's magnitudes: the 32768-entry table (the reference's LUT by saturated power)
+ * to d_lut and modes_mag_exact() of every index, computed on the device, to d_exact (32768 u16 each). */
+int modes_gpu_debug_tables(modes_gpu *ctx, void *d_lut, void *d_exact, void *stream);
 
 /* Synthetic-input generator (bench / tests): the integer noise of
  * tests/synth.py:noise_bytes, bytes [first_byte, first_byte+nbytes) -> d_out. */

@@ -7,6 +7,12 @@
 
 extern "C" {
 
+// modes_mag_exact over n saturated powers (and, with err = -1 / +1, the same correction step fed a square root that is
+// one too small / too large - what a 1-ulp device sqrt may produce).
+void shim_mag_exact(const uint32_t *s_sat, uint64_t n, uint32_t *out) {
+    for (uint64_t k = 0; k < n; k++) out[k] = modes_mag_exact(s_sat[k]);
+}
+
 // modes_power_pair + modes_scan8 over a whole stream, 8 positions per call, as the
 // scan kernel's lanes do.  flags[p] = 1 if position p is forwarded.
 void shim_scan_stream(const uint8_t *iq, uint64_t nsamples, uint8_t *flags) {

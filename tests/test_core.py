@@ -27,8 +27,32 @@ def shim():
     L.shim_syndrome.restype = C.c_uint32
     L.shim_bit_syndrome.restype = C.c_uint32
     L.shim_find_fix.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+    L.shim_mag_exact.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     assert L.shim_sizeof_attempt_core() == 16
     return L
+
+
+def test_mag_exact_equals_the_reference_table_for_every_power(shim):
+    """modes_mag_exact (the demod kernel's table-free magnitude for strong samples) == round(360 sqrt(s)) as the
+    reference's LUT holds it (dump1090.c:359-364, double arithmetic), for every saturated power, not only the 5924
+    that are sums of two squares; and the +-1 correction it applies is enough for any square root within one of the
+    true value."""
+    s = np.arange(32768, dtype=np.uint32)
+    out = np.zeros_like(s)
+    shim.shim_mag_exact(s.ctypes.data, s.size, out.ctypes.data)
+    true_s = s.astype(np.float64)
+    true_s[32767] = 32768.0                                  # the saturated value stands for I = Q = 255
+    want = np.round(np.sqrt(true_s) * 360.0).astype(np.uint32)
+    assert np.array_equal(out, want)
+    assert out.max() == 65167
+    # the correction step in isolation: m0 = want + d, d in {-1, 0, 1}, must come back to want
+    n = (true_s * 129600).astype(np.uint64)
+    for d in (-1, 0, 1):
+        m = want.astype(np.int64) + d
+        m = np.maximum(m, 0).astype(np.uint64)
+        mm = m * m
+        fixed = np.where((mm - m >= n) & (m > 0) & (mm >= m), m - 1, np.where(mm + m < n, m + 1, m))
+        assert np.array_equal(fixed.astype(np.uint32), want), d
 
 
 def numpy_forward_mask(iq):

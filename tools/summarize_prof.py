@@ -14,7 +14,7 @@ def find(pattern):
 
 
 def short(name):
-    for k in ("scan_fused_kernel", "scan_kernel", "demod_kernel", "order_kernel", "prefix_kernel", "compact_candidates", "synth_noise", "fill_kernel",
+    for k in ("scan_fused_kernel", "scan_kernel", "demod_kernel", "finalize_kernel", "order_kernel", "prefix_kernel", "compact_candidates", "synth_noise", "fill_kernel",
               "magnitude_kernel", "power_kernel"):
         if k in name:
             return k
@@ -64,7 +64,7 @@ for f in find("*counter_collection.csv"):
         agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     print("== counters (%s): mean per dispatch" % os.path.relpath(f, out))
     for k, cs in agg.items():
-        if k not in ("scan_fused_kernel", "scan_kernel", "demod_kernel", "order_kernel"):
+        if k not in ("scan_fused_kernel", "scan_kernel", "demod_kernel", "finalize_kernel", "order_kernel"):
             continue
         print("  %s" % k)
         for c, v in cs.items():
