@@ -198,10 +198,17 @@ def main():
                     help="modes_gpu_config.overlap: 0 = scan, demod and order kernels in order on one stream; 2 (default) = the "
                          "order kernel (a few microseconds, no LDS) runs on the context's own stream next to the following "
                          "step's scan; 1 = the demod kernel too (measured: no gain - its workgroups wait for the scan to drain)")
-    ap.add_argument("--time-every", type=int, default=8,
+    ap.add_argument("--time-every", type=int, default=16,
                     help="one call in this many carries HIP timing events around its kernels (they cost ~9 us of idle GPU per "
                          "kernel boundary); 1 = every call")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams the scans are spread over")
+    ap.add_argument("--resolve-threads", type=int, default=0,
+                    help="threads of rank 0's resolve (modes_host_resolve_raw_mt: exact, speculative pieces confirmed in order); "
+                         "0 = min(16, host cores / (4 x ranks on the host))")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the calls are spread over.  2 (default): the scan kernel of call i+1 does not wait for the "
+                         "demod / finalize kernels of call i (it fills their gaps; they are latency-bound and leave the vector "
+                         "units idle); the calls that carry timing events are run alone, so their kernel times - the roofline's "
+                         "- are the kernels' own.  1: everything in order on one stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                                                       "the N > 1 control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -253,7 +260,8 @@ def main():
                                max_records=cap_records if world > 1 else 0, **flags)
         return run_steps(make, iq, lo, calls, flags, steps, warm, args.depth, world=world, rank=rank, dist=dist,
                          coll_device=coll_dev, cap_records=cap_records, streams=works,
-                         device_sync=lambda: torch.cuda.synchronize(dev), time_every=max(1, args.time_every))
+                         device_sync=lambda: torch.cuda.synchronize(dev), time_every=max(1, args.time_every),
+                         resolve_threads=args.resolve_threads or max(1, min(16, (os.cpu_count() or 4) // (4 * world))))
 
     line = {}
     noise = None
@@ -336,10 +344,10 @@ def main():
                    "sharding": "buffers over %d rank(s)" % world, "settle_steps": args.settle if noise is not None else 6,
                    "step": "scan + demod + order kernels, record fetch%s, host resolve + --raw formatting on a second thread; "
                            "%d detect(s) in flight; overlap=%d; completion by a host-visible word (no event in the stream), kernel timing events on "
-                           "one call in %d" % (
+                           "one call in %d (run alone); %d launch stream(s)" % (
                                ", device-resident lists gathered to rank 0 over %s (counts all_gather + exact-size send/recv)" % (
                                    "RCCL" if args.backend == "nccl" else args.backend) if world > 1 else "",
-                               head["depth"], args.overlap, args.time_every)},
+                               head["depth"], args.overlap, args.time_every, max(1, args.streams))},
         "msgs_per_s": round(head.get("msgs", 0) / head["elapsed"], 2) if rank == 0 else None,
         "preambles_per_step_rank0": int(head["last"].get("n_preambles", 0)),
         "forwarded_per_step_rank0": int(head["last"].get("n_forwarded", 0)),

@@ -49,8 +49,9 @@ struct Options {
     int fix_errors = 1, check_crc = 1, aggressive = 0;
     std::vector<int> devices;              // HIP ordinals, one per "GPU" of the split (the same ordinal may repeat)
     uint64_t batch_blocks = 512;           // 128 MiB of samples per GPU call
-    int read_threads = 32;                 // parallel pread() slices for regular files (8 GiB file, 256-core host: 42 GB/s at 8, 45 at 32, 30 at 64)
+    int read_threads = 16;                 // parallel pread() slices for regular files (8 GiB file, 256-core host: 42 GB/s at 8, 45 at 32, 30 at 64)
     int depth = 3;                         // batches in flight per device (lanes = depth x devices)
+    int resolve_threads = 8;               // --raw only: pieces of a batch resolved in parallel (modes_host_resolve_raw_mt)
 };
 
 struct Sink {
@@ -77,7 +78,8 @@ void show_help() {
         "--gpu-list <a,b,...>     The same with explicit ordinals; an ordinal may repeat (several contexts on one device).\n"
         "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).\n"
         "--depth <n>              Batches in flight per device (default: 3).\n"
-        "--read-threads <n>       Threads reading a regular file (default: 32).\n"
+        "--read-threads <n>       Threads reading a regular file (default: 16).\n"
+        "--resolve-threads <n>    With --raw: threads that resolve one batch (default: 8; the listing does not depend on it).\n"
         "--timing                 Print a JSON line with the phase times to stderr.\n"
         "--help                   Show this help.\n");
 }
@@ -230,6 +232,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--batch-blocks") && more) opt.batch_blocks = strtoull(argv[++j], nullptr, 10);
         else if (!strcmp(a, "--depth") && more) opt.depth = std::max(1, atoi(argv[++j]));
         else if (!strcmp(a, "--read-threads") && more) opt.read_threads = std::max(1, atoi(argv[++j]));
+        else if (!strcmp(a, "--resolve-threads") && more) opt.resolve_threads = std::max(1, atoi(argv[++j]));
         else if (!strcmp(a, "--help")) { show_help(); return 0; }
         else {
             fprintf(stderr, "Unknown or not enough arguments for option '%s'.\n\n", a);
@@ -302,6 +305,8 @@ int main(int argc, char **argv) {
     bool reader_done = false, failed = false;
     uint64_t n_messages_out = 0;
 
+    const bool raw_fast = opt.raw && !opt.stats && !opt.sbs && !opt.raw_net && !opt.onlyaddr;
+    std::vector<char> rawbuf;
     std::thread resolver([&] {
         for (uint64_t b = 0;; b++) {
             {
@@ -319,6 +324,14 @@ int main(int argc, char **argv) {
                 return;
             }
             if (live) modes_host_set_time(host, (int64_t)time(nullptr));          // dump1090.c:913,924
+            if (raw_fast) {                                                       // the --raw listing of a long batch, several threads
+                const uint64_t cap = res.n_records * 62 + 64;
+                if (rawbuf.size() < cap) rawbuf.resize(cap);
+                uint64_t nb = 0;
+                n_messages_out += modes_host_resolve_raw_mt(host, res.records, res.n_records, rawbuf.data(), rawbuf.size(), &nb,
+                                                            opt.resolve_threads);
+                sink.out.assign(rawbuf.data(), (size_t)nb);
+            } else
             n_messages_out += modes_host_resolve(host, res.records, res.n_records, res.candidates, res.n_candidates, on_message, &sink);
             if (!sink.out.empty()) {
                 fwrite(sink.out.data(), 1, sink.out.size(), stdout);

@@ -12,6 +12,9 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "modes_core.h"
 
@@ -67,6 +70,16 @@ struct modes_host {
     int64_t icao_seen[kIcaoSlots] = {};   // caller's clock (modes_host_set_time) when the address was last validated
     int64_t now_s = 0;                    // never advanced by a file run: nothing expires (the default)
     bool have_candidates = false;
+    struct IcaoLog *log = nullptr;        // set while a piece of a batch is resolved speculatively (modes_host_resolve_raw_mt)
+};
+
+// What a speculative piece did to / asked of the whitelist: which slots it wrote, and every lookup that was answered from
+// a slot it had NOT written yet - i.e. from the state it was started with, which is a guess until the pieces before it are
+// confirmed.
+struct IcaoLog {
+    struct Lookup { uint32_t addr; bool known; };
+    bool written[kIcaoSlots] = {};
+    std::vector<Lookup> lookups;
 };
 
 extern "C" {
@@ -108,10 +121,13 @@ static void icao_remember(modes_host *h, uint32_t addr) {                       
     const uint32_t s = icao_slot(addr);
     h->icao[s] = addr;
     h->icao_seen[s] = h->now_s;
+    if (h->log) h->log->written[s] = true;
 }
 static bool icao_known(const modes_host *h, uint32_t addr) {                                            // :919-925
     const uint32_t s = icao_slot(addr);
-    return addr != 0 && h->icao[s] == addr && h->now_s - h->icao_seen[s] <= kIcaoTtl;
+    const bool known = addr != 0 && h->icao[s] == addr && h->now_s - h->icao_seen[s] <= kIcaoTtl;
+    if (h->log && addr != 0 && !h->log->written[s]) h->log->lookups.push_back({addr, known});
+    return known;
 }
 
 // decodeAC13Field, :988-1012.
@@ -401,6 +417,140 @@ uint64_t modes_host_resolve_raw(modes_host *h, const modes_record *recs, uint64_
     modes_host_resolve(h, recs, nrecs, cands, ncand, raw_sink, &s);
     if (nbytes) *nbytes = s.n;
     return s.msgs;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same listing from several threads.  The resolve is sequential only through the ICAO whitelist (and the skip
+// window, which never crosses a buffer): the batch is cut at buffer boundaries into one piece per thread, every piece is
+// resolved SPECULATIVELY from a guessed whitelist - the state the batch started with, overlaid with the addresses the
+// pieces before it will certainly or almost certainly add (frames with a clean CRC) - and logs every lookup that was
+// answered from that guess.  Then, in order: a piece whose logged answers all hold under the TRUE state it should have
+// started from executed exactly like the sequential resolve (same answers -> same control flow -> same output) and is
+// kept; a piece with a wrong answer is resolved again from the true state (rare: it takes a frame inside another frame's
+// skip window, or one only a not-yet-seen address validates).  Exact by construction; tests/test_host.py compares it with
+// the one-thread listing on every stream.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Piece {
+    uint64_t lo = 0, hi = 0;
+    modes_host host;                 // private copy: config, clock, whitelist (guess, then the piece's own writes), stats of the piece
+    IcaoLog log;
+    std::string text;
+    uint64_t msgs = 0;
+};
+struct TextSink {
+    modes_host *h;
+    std::string *text;
+    uint64_t msgs;
+};
+void text_sink(const struct modesMessage *mm, uint32_t, uint32_t, void *user) {
+    TextSink *s = static_cast<TextSink *>(user);
+    if (!modes_host_wants(s->h, mm)) return;
+    char line[40];
+    const int n = modes_format_raw(mm, line);
+    s->text->append(line, (size_t)n);
+    s->msgs++;
+}
+void run_piece(Piece &p, const modes_record *recs) {
+    p.log = IcaoLog{};
+    p.text.clear();
+    p.host.st = modes_host_stats{};
+    p.host.have_candidates = false;
+    p.host.log = &p.log;
+    TextSink sink{&p.host, &p.text, 0};
+    modes_host_resolve(&p.host, recs + p.lo, p.hi - p.lo, nullptr, 0, text_sink, &sink);
+    p.host.log = nullptr;
+    p.msgs = sink.msgs;
+}
+}  // namespace
+
+uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint64_t nrecs, char *out, uint64_t cap,
+                                   uint64_t *nbytes, int threads) {
+    // threads < 0: exactly -threads pieces however short the list (tests); otherwise at least 4096 records per thread
+    const uint64_t kMinPiece = threads < 0 ? 1 : 4096;
+    int T = threads < 0 ? -threads : threads;
+    T = T < 1 ? 1 : (T > 64 ? 64 : T);
+    if ((uint64_t)T > nrecs / kMinPiece) T = (int)(nrecs / kMinPiece);
+    if (T <= 1) return modes_host_resolve_raw(h, recs, nrecs, nullptr, 0, out, cap, nbytes);
+    // pieces: equal shares of the records, cut where the buffer changes (the skip window resets there)
+    std::vector<Piece> pieces;
+    uint64_t lo = 0;
+    for (int t = 0; t < T && lo < nrecs; t++) {
+        uint64_t hi = t == T - 1 ? nrecs : nrecs * (uint64_t)(t + 1) / (uint64_t)T;
+        if (hi < lo) hi = lo;
+        while (hi < nrecs && hi > 0 && recs[hi].block == recs[hi - 1].block) hi++;
+        if (hi == lo) continue;
+        pieces.emplace_back();
+        pieces.back().lo = lo;
+        pieces.back().hi = hi;
+        lo = hi;
+    }
+    const size_t P = pieces.size();
+    // guesses: the batch's initial state, plus - piece by piece - what the clean DF11/17/18 frames of the earlier pieces write
+    // (dump1090.c:1198: crcok without repair).  Which of them really get decoded depends on skip windows: a guess, checked below.
+    {
+        modes_host g = *h;
+        g.log = nullptr;
+        for (size_t t = 0; t < P; t++) {
+            pieces[t].host = g;
+            for (uint64_t i = pieces[t].lo; i < pieces[t].hi; i++) {
+                for (int a = 0; a < 2; a++) {
+                    const modes_attempt &at = recs[i].att[a];
+                    const int df = at.msg[0] >> 3;
+                    if (at.gate_ok && at.syndrome == 0 && (df == 11 || df == 17 || df == 18) &&
+                        (at.errors == 0 || (h->cfg.aggressive && at.errors < 3))) {
+                        icao_remember(&g, ((uint32_t)at.msg[1] << 16) | ((uint32_t)at.msg[2] << 8) | at.msg[3]);
+                        break;                                                    // a good first attempt ends the position
+                    }
+                }
+            }
+        }
+    }
+    {   // speculative resolve, one thread per piece
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < P; t++) th.emplace_back([&, t] { run_piece(pieces[t], recs); });
+        run_piece(pieces[0], recs);
+        for (auto &x : th) x.join();
+    }
+    // confirm in order: the true state at the start of piece t is the confirmed state at the end of piece t - 1
+    modes_host truth = *h;                                                        // whitelist + clock of the true sequential run
+    truth.log = nullptr;
+    for (size_t t = 0; t < P; t++) {
+        Piece &p = pieces[t];
+        bool ok = true;
+        for (const IcaoLog::Lookup &q : p.log.lookups) {
+            if (icao_known(&truth, q.addr) != q.known) { ok = false; break; }
+        }
+        if (!ok) {                                                                // rare: again, from the true state
+            const modes_host_config cfg = p.host.cfg;
+            p.host = truth;
+            p.host.cfg = cfg;
+            run_piece(p, recs);
+        }
+        // true state after the piece: its writes over the true state before it
+        for (uint32_t s2 = 0; s2 < kIcaoSlots; s2++)
+            if (p.log.written[s2]) { truth.icao[s2] = p.host.icao[s2]; truth.icao_seen[s2] = p.host.icao_seen[s2]; }
+    }
+    // merge: whitelist, counters, text
+    memcpy(h->icao, truth.icao, sizeof h->icao);
+    memcpy(h->icao_seen, truth.icao_seen, sizeof h->icao_seen);
+    uint64_t total = 0, msgs = 0;
+    for (Piece &p : pieces) {
+        h->st.valid_preamble += p.host.st.valid_preamble;
+        h->st.out_of_phase += p.host.st.out_of_phase;
+        h->st.demodulated += p.host.st.demodulated;
+        h->st.goodcrc += p.host.st.goodcrc;
+        h->st.badcrc += p.host.st.badcrc;
+        h->st.fixed += p.host.st.fixed;
+        h->st.single_bit_fix += p.host.st.single_bit_fix;
+        h->st.two_bits_fix += p.host.st.two_bits_fix;
+        if (out && total + p.text.size() + 1 <= cap) memcpy(out + total, p.text.data(), p.text.size());
+        total += p.text.size();
+        msgs += p.msgs;
+    }
+    if (out && total < cap) out[total] = 0;
+    if (nbytes) *nbytes = total;
+    return msgs;
 }
 
 static int format_hex_line(const struct modesMessage *mm, char *buf, const char *hex) {

@@ -127,8 +127,9 @@ class HostResolver:
         return int(self._lib.modes_host_resolve_to_array(self._h, records.ctypes.data, records.size, cptr, ncand,
                                                          None, 0))
 
-    def raw_listing(self, records: np.ndarray, candidates: np.ndarray | None = None) -> tuple[int, bytes]:
-        """(number of lines, the --raw listing) of a batch, formatted in C (modes_host_resolve_raw)."""
+    def raw_listing(self, records: np.ndarray, candidates: np.ndarray | None = None, threads: int = 1) -> tuple[int, bytes]:
+        """(number of lines, the --raw listing) of a batch, formatted in C (modes_host_resolve_raw; with threads > 1 and
+        no candidates: modes_host_resolve_raw_mt, the same listing from several threads)."""
         records = np.ascontiguousarray(records, dtype=N.RECORD_DTYPE)
         cptr, ncand = None, 0
         if candidates is not None:
@@ -138,8 +139,12 @@ class HostResolver:
         if getattr(self, "_rawbuf", None) is None or len(self._rawbuf) < cap:
             self._rawbuf = C.create_string_buffer(cap)
         nbytes = C.c_uint64()
-        n = self._lib.modes_host_resolve_raw(self._h, records.ctypes.data, records.size, cptr, ncand, self._rawbuf, cap,
-                                             C.byref(nbytes))
+        if threads > 1 and candidates is None:
+            n = self._lib.modes_host_resolve_raw_mt(self._h, records.ctypes.data, records.size, self._rawbuf, cap,
+                                                    C.byref(nbytes), threads)
+        else:
+            n = self._lib.modes_host_resolve_raw(self._h, records.ctypes.data, records.size, cptr, ncand, self._rawbuf, cap,
+                                                 C.byref(nbytes))
         return int(n), self._rawbuf.raw[: nbytes.value]
 
     def stats(self) -> dict:

@@ -16,9 +16,10 @@ class Resolver(threading.Thread):
     A fresh whitelist per step: every step demodulates the same stream from its beginning; the calls of one step
     share it (like the batches of one file)."""
 
-    def __init__(self, flags):
+    def __init__(self, flags, threads=1):
         super().__init__(daemon=True)
         self.flags = flags
+        self.threads = threads          # modes_host_resolve_raw_mt: pieces of a long list resolved in parallel (exact)
         self.q = queue.Queue()
         self.msgs = 0                   # messages of the timed steps
         self.step_text = []             # listing of the step in progress, one piece per call
@@ -34,7 +35,7 @@ class Resolver(threading.Thread):
         self.q.put((recs, counts, first_call, last_call, timed, done_event))
 
     def _resolve(self, recs, timed):
-        n, text = self._res.raw_listing(recs, None)
+        n, text = self._res.raw_listing(recs, None, threads=self.threads)
         self.step_text.append(text)
         if timed:
             self.msgs += n
@@ -89,7 +90,7 @@ def split_calls(first_block, nblocks, ncalls, lo, total_bytes):
 
 
 def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, rank=0, dist=None, coll_device=None,
-              cap_records=1 << 16, streams=(None,), device_sync=lambda: None, time_every=8):
+              cap_records=1 << 16, streams=(None,), device_sync=lambda: None, time_every=8, resolve_threads=1):
     """`warm` untimed + `steps` timed steps of the hot path over this rank's shard `iq` (stream bytes from `lo`;
     a CUDA uint8 tensor - anything sliceable that make_demod()'s detect accepts); a step is the sequence `calls`
     of GPU calls (split_calls).  `depth` contexts (make_demod() each) are used in rotation, so that the GPU always
@@ -121,7 +122,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             # the exchanges of a call are queued on a stream of their own, behind the call's results (with overlap the
             # detect's launch stream does not wait for the demod and order kernels)
             comms = [torch.cuda.Stream(device=coll_device) for _ in range(depth)]
-    resolver = Resolver(dict(fix=flags["fix"], aggressive=flags["aggressive"], check_crc=True)) if rank == 0 else None
+    resolver = Resolver(dict(fix=flags["fix"], aggressive=flags["aggressive"], check_crc=True), resolve_threads) if rank == 0 else None
     free = [threading.Event() for _ in range(depth)]          # the resolver is done with context k's record buffer
     for e in free:
         e.set()
@@ -203,9 +204,23 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                         break
             free[k].wait()                                      # ... and resolved: the record buffer is reused
             stream = works[ncall % len(works)]
+            timed_call = ncall % time_every == 0 and hasattr(demods[k], "set_timing")
             if hasattr(demods[k], "set_timing"):
-                demods[k].set_timing(ncall % time_every == 0)
+                demods[k].set_timing(timed_call)
+            # With several launch streams the kernels of consecutive calls overlap (the next scan fills the gaps and the
+            # tail of this call's latency-bound kernels) and a kernel's duration then includes the time it shared the
+            # chip.  The calls that carry timing events are therefore run ALONE: they start when everything queued
+            # before has finished, and nothing queued later starts before they are done - their times are the kernels'.
+            alone = timed_call and len(works) > 1 and stream is not None
+            if alone:
+                for w in works:
+                    if w is not stream:
+                        stream.wait_stream(w)
             demods[k].detect(iq[clo - lo: chi - lo], stream_byte0=clo, first_block=b0, nblocks=nb, stream=stream)
+            if alone:
+                for w in works:
+                    if w is not stream:
+                        demods[k].stream_wait(w)
             if world > 1 and on_gpu:
                 demods[k].stream_wait(comms[k])
                 slots[k].exchange_counts(stream=comms[k])

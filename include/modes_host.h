@@ -161,6 +161,14 @@ uint64_t modes_host_resolve_raw(modes_host *h, const modes_record *recs, uint64_
                                 const uint64_t *candidates, uint64_t ncand,
                                 char *out, uint64_t cap, uint64_t *nbytes);
 
+/* The same listing (and the same whitelist / counter updates) computed by up to `threads` threads: the batch is cut at
+ * buffer boundaries, the pieces are resolved speculatively and confirmed in order (modes_host.cpp) - byte-identical to
+ * modes_host_resolve_raw without candidates.  For hosts whose one resolve thread would be the bottleneck: a
+ * message-dense stream, or rank 0 of an N-GPU run that resolves N GPUs' records.  (threads < 0: exactly -threads
+ * pieces however short the list is - for tests; otherwise a thread gets at least 4096 records.) */
+uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint64_t nrecs,
+                                   char *out, uint64_t cap, uint64_t *nbytes, int threads);
+
 /* dump1090.c:1803: would useModesMessage() display/forward this message? */
 int modes_host_wants(const modes_host *h, const struct modesMessage *mm);
 

@@ -149,3 +149,65 @@ def test_icao_whitelist_ttl_follows_the_callers_clock(streams, golden):
         kept += r.resolve(recs[i:i + 1], None)
     assert raw_text(kept) == golden["modes1"]["raw"]["default"]["text"]
     r.close()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_multithreaded_resolve_equals_the_sequential_one(streams, golden, case):
+    """modes_host_resolve_raw_mt: pieces resolved speculatively from guessed whitelists and confirmed in order must give
+    the sequential listing, the same counters and the same whitelist afterwards - for any number of pieces, on the
+    reference's own capture (AP-validated frames depend on addresses from earlier pieces) as on the synthetic ones."""
+    data = streams[case]
+    for fs in ("default", "aggressive", "nofix"):
+        flags = orc.FLAGSETS[fs]
+        recs, _ = oracle_records(data, maxfix_of(flags))
+        seq = HostResolver(**flags)
+        n0, text0 = seq.raw_listing(recs, None)
+        assert text0.decode() == golden[case]["raw"][fs]["text"]
+        follow0 = seq.raw_listing(recs, None)                      # the whitelist the first pass left behind
+        for pieces in (2, 3, 7, 32):
+            mt = HostResolver(**flags)
+            n1, text1 = mt.raw_listing(recs, None, threads=-pieces)
+            assert (n1, text1) == (n0, text0), (case, fs, pieces)
+            s0, s1 = seq.stats(), mt.stats()
+            assert mt.raw_listing(recs, None, threads=-pieces) == follow0, (case, fs, pieces, "state after the batch")
+            mt.close()
+        seq.close()
+
+
+def test_multithreaded_resolve_rejects_wrong_guesses():
+    """A piece whose speculation was wrong is resolved again: an AP-validated frame (DF4) whose address is only known
+    from a frame that sits INSIDE another frame's skip window of an earlier piece looks validated to the guess (the guess
+    ignores skip windows) but is not; and the other way round for an address repaired (not clean) earlier."""
+    from dump1090_amd import RECORD_DTYPE
+    import synth as sy
+
+    def rec(block, j, frame, syndrome=0, nfix=0, pos=0xFF):
+        r = np.zeros(1, dtype=RECORD_DTYPE)
+        r["block"], r["j"] = block, j
+        for a in (0, 1):
+            r["att"]["msg"][0, a, :len(frame)] = np.frombuffer(frame, dtype=np.uint8)
+            r["att"]["gate_ok"][0, a] = 1
+            r["att"]["syndrome"][0, a] = syndrome
+            r["att"]["nfix"][0, a] = nfix
+            r["att"]["fixpos"][0, a] = (pos, 0xFF)
+        return r
+
+    a17 = sy.make_frame(17, sy._payload(1, 14, 1))                 # aircraft A, clean
+    b17 = sy.make_frame(17, sy._payload(1, 14, 2))                 # aircraft B, clean - but inside A's skip window
+    addr_b = b17[1:4]
+    # a DF4 whose AP field validates against B: data bytes 0..3, parity = crc(data) xor address
+    data4 = bytes([4 << 3, 0x12, 0x34, 0x56])
+    lib = N.host_lib()
+    crc = lib.modes_compute_crc(data4 + bytes(3), 56)
+    ap = bytes([((crc >> 16) & 0xFF) ^ addr_b[0], ((crc >> 8) & 0xFF) ^ addr_b[1], (crc & 0xFF) ^ addr_b[2]])
+    df4 = data4 + ap
+    syn4 = lib.modes_checksum(df4, 56)
+    recs = np.concatenate([rec(0, 100, a17), rec(0, 150, b17),     # piece 0: B is skipped (j = 150 < 100 + 241)
+                           rec(1, 100, df4, syndrome=syn4)])       # piece 1: DF4 "from B": nobody remembered B
+    seq = HostResolver()
+    want = seq.raw_listing(recs, None)
+    assert want[0] == 1                                            # only A's frame
+    mt = HostResolver()
+    assert mt.raw_listing(recs, None, threads=-2) == want
+    seq.close()
+    mt.close()

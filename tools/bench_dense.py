@@ -17,10 +17,13 @@ for flags in (dict(), dict(aggressive=True)):
         t0 = time.perf_counter()
         d.detect(iq); recs, cands, info = d.fetch(copy=False)
         t1 = time.perf_counter()
-        r = HostResolver(**flags); n, _ = r.raw_listing(recs, cands); r.close()
+        r = HostResolver(**flags); n, text1 = r.raw_listing(recs, None); r.close()
         t2 = time.perf_counter()
+        r = HostResolver(**flags); n16, text16 = r.raw_listing(recs, None, threads=16); r.close()
+        t3 = time.perf_counter()
+        assert (n16, text16) == (n, text1), "the 16-thread resolve differs from the sequential one"
         out = {"flags": flags, "gib": iq.numel() / 2**30, "records": len(recs), "messages": n, "scan_ms": round(info["scan_ms"], 3),
-               "demod_ms": round(info["demod_ms"], 3), "order_ms": round(info["order_ms"], 3), "gpu_call_s": round(t1 - t0, 4), "resolve_s": round(t2 - t1, 4),
+               "demod_ms": round(info["demod_ms"], 3), "order_ms": round(info["order_ms"], 3), "gpu_call_s": round(t1 - t0, 4), "resolve_s": round(t2 - t1, 4), "resolve_16_threads_s": round(t3 - t2, 4),
                "preambles": info["n_preambles"], "forwarded": info["n_forwarded"]}
     print(json.dumps(out), flush=True)
     d.close()
