@@ -198,7 +198,7 @@ def main():
                     help="modes_gpu_config.overlap: 0 = scan, demod and order kernels in order on one stream; 2 (default) = the "
                          "order kernel (a few microseconds, no LDS) runs on the context's own stream next to the following "
                          "step's scan; 1 = the demod kernel too (measured: no gain - its workgroups wait for the scan to drain)")
-    ap.add_argument("--time-every", type=int, default=16,
+    ap.add_argument("--time-every", type=int, default=8,
                     help="one call in this many carries HIP timing events around its kernels (they cost ~9 us of idle GPU per "
                          "kernel boundary); 1 = every call")
     ap.add_argument("--resolve-threads", type=int, default=0,
@@ -362,7 +362,8 @@ def main():
                         "(1 per 65,536 samples, 10 %% with a flipped bit, seam offsets), --fix" % (2 if world == 1 else 3, args.frames_mib))
         if rank == 0:
             f["listing_check"] = frames["check"]
-        f["wall_over_kernels"] = round(f["ms_per_step"] / max(1e-9, frames["calls_per_step"] * (frames["scan_ms"] + frames["demod_ms"] + frames["order_ms"])), 3)
+        ksum = frames["calls_per_step"] * (frames["scan_ms"] + frames["demod_ms"] + frames["order_ms"])
+        f["wall_over_kernels"] = round(f["ms_per_step"] / ksum, 3) if ksum > 0 else None
         line["frames"] = f
     elif frames is not None and rank == 0:
         line["listing_check"] = frames["check"]

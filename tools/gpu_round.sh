@@ -30,9 +30,11 @@ for s in $STEPS; do
             cp gpurun_out/prof_$TAG/kt/*kernel_stats.csv "$O/prof/" 2>/dev/null; find gpurun_out/prof_$TAG -name "*kernel_stats.csv" -exec cp {} "$O/prof/kt_kernel_stats.csv" \; ;;
     e2e)    run e2e 600 python tools/e2e_cli.py 8 ;;
     dense)  run dense 300 python tools/bench_dense.py ;;
-    gaps)   B="$R/bench.py --workload noise --no-end-to-end --no-cpu-baseline --depth 4 --settle 40 --steps 100"
-            ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$O/gaps_kt" -o kt -f csv -- python $B --time-every 100000 > "$O/gaps_kt.log" 2>&1 )
-            python tools/kernel_gaps.py "$O/gaps_kt" > "$O/gaps_kt_summary.txt" 2>&1 ;;
+    gaps)   B="$R/bench.py --workload noise --no-end-to-end --no-cpu-baseline --settle 40 --steps 100"
+            ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$O/overlap_kt" -o kt -f csv -- python $B --time-every 100000 > "$O/overlap_kt.log" 2>&1 )
+            ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$O/serial_kt" -o kt -f csv -- python $B --time-every 100000 --streams 1 > "$O/serial_kt.log" 2>&1 )
+            python tools/kernel_gaps.py "$O/overlap_kt" > "$O/overlap_kt_summary.txt" 2>&1
+            python tools/kernel_gaps.py "$O/serial_kt" > "$O/serial_kt_summary.txt" 2>&1 ;;
     trace)  run trace_v0 300 python tools/trace_demod.py dump1090_amd/libmodes_gfx950_trace.so 1024 0
             run trace_v1 300 python tools/trace_demod.py dump1090_amd/libmodes_gfx950_trace.so 1024 1 ;;
   esac

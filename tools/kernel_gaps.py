@@ -24,6 +24,18 @@ for k, v in dur.items():
     print("%-28s n=%4d  median %8.1f us  mean %8.1f" % (k, len(v), statistics.median(v) / 1e3, statistics.mean(v) / 1e3))
 for k, v in gaps.items():
     print("gap %-36s n=%4d  median %6.1f us  mean %6.1f  min %6.1f  max %6.1f" % (k, len(v), statistics.median(v) / 1e3, statistics.mean(v) / 1e3, min(v) / 1e3, max(v) / 1e3))
+# how much of the time is more than one of these kernels running?
+edges = sorted([(e[1], 1) for e in ev] + [(e[2], -1) for e in ev])
+busy = over = 0
+depth = 0
+for (t, d), (t2, _) in zip(edges, edges[1:]):
+    depth += d
+    if depth >= 1:
+        busy += t2 - t
+    if depth >= 2:
+        over += t2 - t
+span = edges[-1][0] - edges[0][0]
+print("of %.1f ms traced: a kernel is running %.1f %% of the time, two or more %.1f %%" % (span / 1e6, 100.0 * busy / span, 100.0 * over / span))
 scans = [e for e in ev if e[0] == "scan_kernel"]
 per = [b[1] - a[1] for a, b in zip(scans, scans[1:])]
 print("scan-to-scan period: median %.1f us, mean %.1f us" % (statistics.median(per) / 1e3, statistics.mean(per) / 1e3))
