@@ -35,6 +35,8 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
 
@@ -51,6 +53,7 @@ struct Options {
     uint64_t batch_blocks = 512;           // 128 MiB of samples per GPU call
     int read_threads = 16;                 // parallel pread() slices for regular files (8 GiB file, 256-core host: 42 GB/s at 8, 45 at 32, 30 at 64)
     int depth = 3;                         // batches in flight per device (lanes = depth x devices)
+    bool use_mmap = true;                  // regular files: copy out of a mapping of the file instead of pread()
     int resolve_threads = 8;               // --raw only: pieces of a batch resolved in parallel (modes_host_resolve_raw_mt)
 };
 
@@ -79,6 +82,7 @@ void show_help() {
         "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).\n"
         "--depth <n>              Batches in flight per device (default: 3).\n"
         "--read-threads <n>       Threads reading a regular file (default: 16).\n"
+        "--no-mmap                Read a regular file with pread() instead of copying out of a mapping of it.\n"
         "--resolve-threads <n>    With --raw: threads that resolve one batch (default: 8; the listing does not depend on it).\n"
         "--timing                 Print a JSON line with the phase times to stderr.\n"
         "--help                   Show this help.\n");
@@ -148,9 +152,22 @@ private:
 
 // A regular file is read by several threads at once (pread on disjoint slices): one thread copying
 // out of the page cache is ~10x slower than the PCIe link that follows.  *got < want only at end of file.
-bool read_parallel(Pool &pool, int fd, off_t *pos, uint8_t *dst, size_t want, size_t *got) {
+bool read_parallel(Pool &pool, int fd, const uint8_t *map, size_t map_len, off_t *pos, uint8_t *dst, size_t want, size_t *got) {
     *got = 0;
     if (want == 0) return true;
+    if (map) {                                                               // the file is mapped: plain copies, no system call per slice
+        const size_t have = (size_t)*pos < map_len ? map_len - (size_t)*pos : 0, n = std::min(want, have);
+        const int ns = pool.size();
+        const size_t sl = (n / (size_t)ns + 4095) & ~(size_t)4095;
+        const uint8_t *src = map + *pos;
+        pool.run(ns, [&](int t) {
+            const size_t lo = (size_t)t * sl;
+            if (lo < n) memcpy(dst + lo, src + lo, std::min(sl, n - lo));
+        });
+        *got = n;
+        *pos += (off_t)n;
+        return true;
+    }
     const int nslices = pool.size();
     const size_t slice = (want / (size_t)nslices + 4095) & ~(size_t)4095;
     std::vector<ssize_t> done((size_t)nslices, 0);
@@ -232,6 +249,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--batch-blocks") && more) opt.batch_blocks = strtoull(argv[++j], nullptr, 10);
         else if (!strcmp(a, "--depth") && more) opt.depth = std::max(1, atoi(argv[++j]));
         else if (!strcmp(a, "--read-threads") && more) opt.read_threads = std::max(1, atoi(argv[++j]));
+        else if (!strcmp(a, "--no-mmap")) opt.use_mmap = false;
         else if (!strcmp(a, "--resolve-threads") && more) opt.resolve_threads = std::max(1, atoi(argv[++j]));
         else if (!strcmp(a, "--help")) { show_help(); return 0; }
         else {
@@ -350,6 +368,19 @@ int main(int argc, char **argv) {
     // --loop replays a file forever through the sequential path; a plain regular file is read in parallel
     const bool seekable = !opt.loop && fd != 0 && lseek(fd, 0, SEEK_CUR) != (off_t)-1;
     Pool pool(seekable ? opt.read_threads : 1);
+    const uint8_t *map = nullptr;
+    size_t map_len = 0;
+    if (seekable && opt.use_mmap) {
+        struct stat sb;
+        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            void *m2 = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_SHARED, fd, 0);
+            if (m2 != MAP_FAILED) {
+                map = static_cast<const uint8_t *>(m2);
+                map_len = (size_t)sb.st_size;
+                (void)madvise(m2, map_len, MADV_SEQUENTIAL);
+            }
+        }
+    }
     off_t file_pos = 0;
     uint64_t first_block = 0, total_bytes = 0;
     size_t carry = 0;                       // valid carry bytes at the front of the current buffer (0 for the first batch)
@@ -366,7 +397,7 @@ int main(int argc, char **argv) {
         if (carry) memcpy(ln.buf, carry_bytes, MODES_CARRY_BYTES);               // dump1090.c:481
         size_t got = 0;
         uint8_t *dst = ln.buf + carry;
-        const bool ok = seekable ? read_parallel(pool, fd, &file_pos, dst, batch_bytes, &got)
+        const bool ok = seekable ? read_parallel(pool, fd, map, map_len, &file_pos, dst, batch_bytes, &got)
                                  : read_full(fd, dst, batch_bytes, &got);
         if (!ok) { perror("read"); rc = 1; break; }
         while (got < batch_bytes && opt.loop && fd != 0 && !seekable) { // dump1090.c:488-494
@@ -431,6 +462,7 @@ int main(int argc, char **argv) {
         modes_gpu_host_free(ln.gpu, ln.buf);
         modes_gpu_destroy(ln.gpu);
     }
+    if (map) munmap(const_cast<uint8_t *>(map), map_len);
     if (fd > 0) close(fd);
     return rc;
 }
