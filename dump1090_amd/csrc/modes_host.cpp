@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <chrono>
+#include <cstdlib>
 #include <string>
 #include <thread>
 #include <vector>
@@ -486,6 +488,9 @@ uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint
         lo = hi;
     }
     const size_t P = pieces.size();
+    const bool dbg = getenv("MODES_HOST_MT_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     // guesses: the batch's initial state, plus - piece by piece - what the clean DF11/17/18 frames of the earlier pieces write
     // (dump1090.c:1198: crcok without repair).  Which of them really get decoded depends on skip windows: a guess, checked below.
     {
@@ -506,12 +511,15 @@ uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint
             }
         }
     }
+    const double t1 = now();
     {   // speculative resolve, one thread per piece
         std::vector<std::thread> th;
         for (size_t t = 1; t < P; t++) th.emplace_back([&, t] { run_piece(pieces[t], recs); });
         run_piece(pieces[0], recs);
         for (auto &x : th) x.join();
     }
+    const double t2 = now();
+    int reruns = 0;
     // confirm in order: the true state at the start of piece t is the confirmed state at the end of piece t - 1
     modes_host truth = *h;                                                        // whitelist + clock of the true sequential run
     truth.log = nullptr;
@@ -526,11 +534,13 @@ uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint
             p.host = truth;
             p.host.cfg = cfg;
             run_piece(p, recs);
+            reruns++;
         }
         // true state after the piece: its writes over the true state before it
         for (uint32_t s2 = 0; s2 < kIcaoSlots; s2++)
             if (p.log.written[s2]) { truth.icao[s2] = p.host.icao[s2]; truth.icao_seen[s2] = p.host.icao_seen[s2]; }
     }
+    const double t3 = now();
     // merge: whitelist, counters, text
     memcpy(h->icao, truth.icao, sizeof h->icao);
     memcpy(h->icao_seen, truth.icao_seen, sizeof h->icao_seen);
@@ -550,6 +560,9 @@ uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint
     }
     if (out && total < cap) out[total] = 0;
     if (nbytes) *nbytes = total;
+    if (dbg)
+        fprintf(stderr, "resolve_raw_mt: %zu pieces, %llu records: guess %.2f ms, speculative %.2f ms, confirm %.2f ms (%d re-run), merge %.2f ms\n",
+                P, (unsigned long long)nrecs, t1 - t0, t2 - t1, t3 - t2, reruns, now() - t3);
     return msgs;
 }
 

@@ -82,6 +82,9 @@ def _to_message(e: N.Emitted, check_crc: bool = True) -> Message:
                    mm.phase_corrected, mm.iid, e.block, e.j, extra, buf.value.decode("ascii", "replace"))
 
 
+_RAWBUF = None
+
+
 class HostResolver:
     """The sequential half: records -> messages (libmodes_host.so).  No GPU needed."""
 
@@ -136,16 +139,17 @@ class HostResolver:
             candidates = np.ascontiguousarray(candidates, dtype=np.uint64)
             cptr, ncand = candidates.ctypes.data, candidates.size
         cap = 62 * records.size + 64                      # at most two 31-byte lines per record
-        if getattr(self, "_rawbuf", None) is None or len(self._rawbuf) < cap:
-            self._rawbuf = C.create_string_buffer(cap)
+        global _RAWBUF
+        if _RAWBUF is None or len(_RAWBUF) < cap:         # one grow-only buffer per process (resolvers are short-lived)
+            _RAWBUF = (C.c_char * (cap + cap // 4))()
         nbytes = C.c_uint64()
         if threads > 1 and candidates is None:
-            n = self._lib.modes_host_resolve_raw_mt(self._h, records.ctypes.data, records.size, self._rawbuf, cap,
+            n = self._lib.modes_host_resolve_raw_mt(self._h, records.ctypes.data, records.size, _RAWBUF, len(_RAWBUF),
                                                     C.byref(nbytes), threads)
         else:
-            n = self._lib.modes_host_resolve_raw(self._h, records.ctypes.data, records.size, cptr, ncand, self._rawbuf, cap,
+            n = self._lib.modes_host_resolve_raw(self._h, records.ctypes.data, records.size, cptr, ncand, _RAWBUF, len(_RAWBUF),
                                                  C.byref(nbytes))
-        return int(n), self._rawbuf.raw[: nbytes.value]
+        return int(n), C.string_at(_RAWBUF, nbytes.value)     # copies the listing only, not the whole buffer
 
     def stats(self) -> dict:
         st = N.HostStats()

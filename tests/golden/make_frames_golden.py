@@ -291,7 +291,9 @@ def main():
     for tag, flags in (("", []), ("_aggressive", ["--aggressive"]), ("_nofix", ["--no-fix"])):
         verbose, sbs, ro, table = run_reference(lines, flags)
         open(os.path.join(HERE, "frames_in.txt"), "w").write("".join(lines))
-        open(os.path.join(HERE, "frames_verbose%s.txt" % tag), "w").write(verbose)
+        import gzip
+        with gzip.open(os.path.join(HERE, "frames_verbose%s.txt.gz" % tag), "wt") as gz:      # 48,000 lines: kept compressed
+            gz.write(verbose)
         open(os.path.join(HERE, "frames_sbs%s.txt" % tag), "w").write(sbs)
         open(os.path.join(HERE, "frames_rawnet%s.txt" % tag), "w").write(ro)
         open(os.path.join(HERE, "frames_aircraft%s.json" % tag), "w").write(table)

@@ -14,7 +14,14 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_text(name):
-    return open(os.path.join(GOLD, name)).read()
+    """a golden of tests/golden (the three big verbose dumps are kept gzipped)"""
+    path = os.path.join(GOLD, name)
+    if not os.path.exists(path) and os.path.exists(path + ".gz"):
+        import gzip
+        with gzip.open(path + ".gz", "rt") as f:
+            return f.read()
+    with open(path) as f:
+        return f.read()
 
 
 def modes1_messages(streams, flagset):
