@@ -203,7 +203,7 @@ def main():
                          "kernel boundary); 1 = every call")
     ap.add_argument("--resolve-threads", type=int, default=0,
                     help="threads of rank 0's resolve (modes_host_resolve_raw_mt: exact, speculative pieces confirmed in order); "
-                         "0 = min(16, host cores / (4 x ranks on the host))")
+                         "0 = min(32, host cores / 4): rank 0 is the only rank that resolves")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the calls are spread over.  2 (default): the scan kernel of call i+1 does not wait for the "
                          "demod / finalize kernels of call i (it fills their gaps; they are latency-bound and leave the vector "
@@ -211,6 +211,9 @@ def main():
                          "- are the kernels' own.  1: everything in order on one stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                                                       "the N > 1 control flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="with one rank: run the N > 1 code path anyway (process group of one, device output buffers, count "
+                         "all_gather, transfers) - exercises the RCCL calls on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
@@ -234,8 +237,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")     # where the gathered bytes travel
-    if world > 1:
+    dist_on = world > 1 or args.force_gather
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -257,11 +262,12 @@ def main():
         def make():
             return Demodulator(device=local, run_chunks=args.run_chunks, scan_variant=args.scan_variant,
                                overlap=args.overlap, demod_variant=args.demod_variant,
-                               max_records=cap_records if world > 1 else 0, **flags)
+                               max_records=cap_records if dist_on else 0, **flags)
         return run_steps(make, iq, lo, calls, flags, steps, warm, args.depth, world=world, rank=rank, dist=dist,
                          coll_device=coll_dev, cap_records=cap_records, streams=works,
                          device_sync=lambda: torch.cuda.synchronize(dev), time_every=max(1, args.time_every),
-                         resolve_threads=args.resolve_threads or max(1, min(16, (os.cpu_count() or 4) // (4 * world))))
+                         resolve_threads=args.resolve_threads or max(1, min(32, (os.cpu_count() or 4) // 4)),
+                         gather=dist_on)
 
     line = {}
     noise = None
@@ -332,7 +338,8 @@ def main():
         "%d MiB per GPU of sigma=3 noise + DF11/DF17 frames, --fix; BASELINE.json configs[%d]" % (args.frames_mib, 2 if world == 1 else 3))
     samples_per_step = head["total"] // 2                                     # the whole stream: every rank's shard
     value = samples_per_step * head_steps / head["elapsed"] / 1e6
-    achieved = head["call_bytes"] / (max(head["scan_ms"], 1e-9) * 1e-3) / 1e9  # this rank's launches: 2 B per sample
+    assert head["timed_calls"] > 0 and head["scan_ms"] > 0, "no call of the timed region carried timing events"
+    achieved = head["call_bytes"] / (head["scan_ms"] * 1e-3) / 1e9             # this rank's launches: 2 B per sample
     traffic, traffic_note = measured_traffic(args.mib) if noise is not None else (None, "no PMC pass for this workload")
     line = {
         "metric": "IQ Msamples/s demodulated", "value": round(value, 1), "unit": "Msamples/s",
@@ -374,7 +381,7 @@ def main():
         line["cpu_baseline"] = cpu_baseline(iq_noise, min(args.cpu_mib << 20, noise["span"] // 262144 * 262144))
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -56,21 +56,28 @@ class Resolver(threading.Thread):
                     self._parts = []
                 if counts is None or (first_call and last_call):
                     self._resolve(recs, timed)                  # one rank, or one call per step: already in stream order
+                    done.set()
                 else:
                     # several calls per step and several ranks: stream order is rank-major (rank 0's calls, then
-                    # rank 1's ...), the gathered lists arrive call-major - keep the pieces, resolve at the step's end
+                    # rank 1's ...), the gathered lists arrive call-major - keep the pieces (views of the gather buffers:
+                    # their slots stay busy until the step is resolved), resolve at the step's end
                     offs = np.concatenate([[0], np.cumsum(counts)])
-                    self._parts.append([recs[offs[r]: offs[r + 1]].copy() for r in range(len(counts))])
+                    self._parts.append(([recs[offs[r]: offs[r + 1]] for r in range(len(counts))], done))
                     if last_call:
                         for r in range(len(counts)):
-                            for call in self._parts:
+                            for call, _ in self._parts:
                                 self._resolve(call[r], timed)
+                        for _, ev in self._parts:
+                            ev.set()
+                        self._parts = []
                 if last_call:
                     self.last_text = b"".join(self.step_text)
                     self.last_lines = self.last_text.count(b"\n")
             except Exception as e:          # noqa: BLE001 - reported by the main thread
                 self.error = e
-            done.set()
+                done.set()
+                for _, ev in getattr(self, "_parts", []):
+                    ev.set()
 
     def stop(self):
         self.q.put(None)
@@ -90,7 +97,8 @@ def split_calls(first_block, nblocks, ncalls, lo, total_bytes):
 
 
 def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, rank=0, dist=None, coll_device=None,
-              cap_records=1 << 16, streams=(None,), device_sync=lambda: None, time_every=8, resolve_threads=1):
+              cap_records=1 << 16, streams=(None,), device_sync=lambda: None, time_every=8, resolve_threads=1,
+              gather=None):
     """`warm` untimed + `steps` timed steps of the hot path over this rank's shard `iq` (stream bytes from `lo`;
     a CUDA uint8 tensor - anything sliceable that make_demod()'s detect accepts); a step is the sequence `calls`
     of GPU calls (split_calls).  `depth` contexts (make_demod() each) are used in rotation, so that the GPU always
@@ -103,19 +111,23 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     Kernel times cost idle GPU time (events around the kernels: ~9 us per boundary), so only one call in `time_every`
     carries them (modes_gpu_set_timing); the averages returned are over those calls of the timed steps.
 
+    gather: exchange the record lists through RecordGather (default: when world > 1; True with world == 1 runs the whole
+    N > 1 code path - device output buffers, count all_gather, transfers - on a single rank, which is how the RCCL calls
+    are exercised on a one-GPU box).
     world > 1: `dist` = torch.distributed (initialised), coll_device = where the gathered bytes travel (the CUDA
     device with RCCL; "cpu" with gloo: the lists are fetched to the host first).  Returns a dict of measurements
     (rank 0: also the --raw listing of the last step)."""
     import torch
     from .distributed import RecordGather
 
+    dist_on = world > 1 if gather is None else bool(gather)          # records travel through RecordGather
     demods = [make_demod() for _ in range(depth)]
     works = list(streams)
     slots = None
     on_gpu = coll_device is not None and torch.device(coll_device).type == "cuda"
-    if world > 1:
-        gather = RecordGather(cap_records, device=coll_device)
-        slots = [gather.slot() for _ in range(depth)]
+    if dist_on:
+        rg = RecordGather(cap_records, device=coll_device)
+        slots = [rg.slot() for _ in range(depth)]
         if on_gpu:
             for d, s in zip(demods, slots):
                 d.set_output(s.own_records, s.count)
@@ -129,7 +141,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
 
     def sync_all():
         device_sync()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             device_sync()
 
@@ -159,7 +171,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     # phase 2: the records are on rank 0's host -> resolver thread
     def phase_resolve(k, tag, timed):
         counts = None
-        if world > 1:
+        if dist_on:
             recs = slots[k].wait()
             counts = slots[k].counts
         else:
@@ -176,7 +188,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         st = stage.get(k)
         if st is None:
             return
-        if st[0] == 0 and world > 1 and upto >= 1:
+        if st[0] == 0 and dist_on and upto >= 1:
             phase_records(k, st[1], st[2])
             st[0] = 1
         if upto >= 2:
@@ -186,6 +198,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
 
     t0 = None
     ncall = 0
+    first_timed_call = warm * len(calls)
     for step in range(warm + steps):
         if step == warm:
             for k in list(order):
@@ -204,7 +217,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                         break
             free[k].wait()                                      # ... and resolved: the record buffer is reused
             stream = works[ncall % len(works)]
-            timed_call = ncall % time_every == 0 and hasattr(demods[k], "set_timing")
+            # the first call of the timed region and every time_every-th after it carry timing events (none while warming up)
+            timed_call = timed and (ncall - first_timed_call) % time_every == 0 and hasattr(demods[k], "set_timing")
             if hasattr(demods[k], "set_timing"):
                 demods[k].set_timing(timed_call)
             # With several launch streams the kernels of consecutive calls overlap (the next scan fills the gaps and the
@@ -221,7 +235,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                 for w in works:
                     if w is not stream:
                         demods[k].stream_wait(w)
-            if world > 1 and on_gpu:
+            if dist_on and on_gpu:
                 demods[k].stream_wait(comms[k])
                 slots[k].exchange_counts(stream=comms[k])
                 stream = comms[k]
@@ -239,7 +253,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         e.wait()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

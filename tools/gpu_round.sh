@@ -13,6 +13,7 @@ for s in $STEPS; do
   case $s in
     smoke)  run smoke 300 python __graft_entry__.py smoke ; run smoke2 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     parity) run parity 900 python -m pytest tests/test_gpu_parity.py tests/test_dropin.py -m gpu -q --maxfail=6 -p no:cacheprovider ;;
+    benchtest) run benchtest 1200 python -m pytest tests/test_gpu_bench.py -m gpu -q --maxfail=6 -p no:cacheprovider ;;
     full)   run full 1500 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --maxfail=3 -p no:cacheprovider ;;
     full8)  run full8 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --maxfail=3 -p no:cacheprovider -k "not sixty_four" ;;
     bench)  run bench 600 python bench.py ;;
