@@ -16,9 +16,10 @@ class Resolver(threading.Thread):
     A fresh whitelist per step: every step demodulates the same stream from its beginning; the calls of one step
     share it (like the batches of one file)."""
 
-    def __init__(self, flags, threads=1):
+    def __init__(self, flags, threads=1, hold_views=True):
         super().__init__(daemon=True)
         self.flags = flags
+        self.hold_views = hold_views    # keep the gather buffers of a step's calls until the step is resolved (else: copy)
         self.threads = threads          # modes_host_resolve_raw_mt: pieces of a long list resolved in parallel (exact)
         self.q = queue.Queue()
         self.msgs = 0                   # messages of the timed steps
@@ -62,13 +63,18 @@ class Resolver(threading.Thread):
                     # rank 1's ...), the gathered lists arrive call-major - keep the pieces (views of the gather buffers:
                     # their slots stay busy until the step is resolved), resolve at the step's end
                     offs = np.concatenate([[0], np.cumsum(counts)])
-                    self._parts.append(([recs[offs[r]: offs[r + 1]] for r in range(len(counts))], done))
+                    if self.hold_views:
+                        self._parts.append(([recs[offs[r]: offs[r + 1]] for r in range(len(counts))], done))
+                    else:                                       # fewer buffers than calls per step: release this one now
+                        self._parts.append(([recs[offs[r]: offs[r + 1]].copy() for r in range(len(counts))], None))
+                        done.set()
                     if last_call:
                         for r in range(len(counts)):
                             for call, _ in self._parts:
                                 self._resolve(call[r], timed)
                         for _, ev in self._parts:
-                            ev.set()
+                            if ev is not None:
+                                ev.set()
                         self._parts = []
                 if last_call:
                     self.last_text = b"".join(self.step_text)
@@ -77,7 +83,8 @@ class Resolver(threading.Thread):
                 self.error = e
                 done.set()
                 for _, ev in getattr(self, "_parts", []):
-                    ev.set()
+                    if ev is not None:
+                        ev.set()
 
     def stop(self):
         self.q.put(None)
@@ -134,7 +141,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             # the exchanges of a call are queued on a stream of their own, behind the call's results (with overlap the
             # detect's launch stream does not wait for the demod and order kernels)
             comms = [torch.cuda.Stream(device=coll_device) for _ in range(depth)]
-    resolver = Resolver(dict(fix=flags["fix"], aggressive=flags["aggressive"], check_crc=True), resolve_threads) if rank == 0 else None
+    resolver = Resolver(dict(fix=flags["fix"], aggressive=flags["aggressive"], check_crc=True), resolve_threads,
+                        hold_views=depth > len(calls)) if rank == 0 else None
     free = [threading.Event() for _ in range(depth)]          # the resolver is done with context k's record buffer
     for e in free:
         e.set()
@@ -215,7 +223,11 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                     advance(kk, 2)
                     if kk == k:
                         break
-            free[k].wait()                                      # ... and resolved: the record buffer is reused
+            # ... and resolved: the record buffer is reused.  (Rank 0 with several calls per step: the resolver releases a
+            # step's buffers together, when it has the step's last call - hand it everything that is still in flight.)
+            while not free[k].is_set() and order:
+                advance(order[0], 2)
+            free[k].wait()
             stream = works[ncall % len(works)]
             # the first call of the timed region and every time_every-th after it carry timing events (none while warming up)
             timed_call = timed and (ncall - first_timed_call) % time_every == 0 and hasattr(demods[k], "set_timing")

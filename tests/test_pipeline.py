@@ -90,7 +90,7 @@ def test_single_rank_pipeline(tmp_path, golden, case, ncalls, depth):
     assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
 
 
-@pytest.mark.parametrize("case,ncalls,depth", [("frames", 1, 3), ("edges", 2, 3), ("edges", 2, 2)])
+@pytest.mark.parametrize("case,ncalls,depth", [("frames", 1, 3), ("edges", 2, 3), ("edges", 2, 2), ("edges", 2, 1), ("edges", 3, 4)])
 def test_two_ranks_gather_over_gloo(tmp_path, golden, case, ncalls, depth):
     mp.spawn(_run, args=(2, _free_port(), case, ncalls, depth, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
