@@ -1987,7 +1987,7 @@ static int finish_detect(modes_gpu *ctx, modes_gpu_result *res, bool to_host) {
     // kernel's last workgroup publishes, then the event behind any kernel that followed it.  What fetch itself launches
     // runs on the context's own stream.
     int rcw = wait_results(ctx);
-    if (rcw != MODES_OK) return rcw;
+    if (rcw != MODES_OK) { ctx->in_flight = false; return rcw; }             // the call is lost; the context stays usable
     hipStream_t st = ctx->own_stream;
     ctx->in_flight = false;
     memset(res, 0, sizeof *res);

@@ -170,7 +170,7 @@ int modes_gpu_set_timing(modes_gpu *ctx, int on);
  * `capacity` records; more records than that are MODES_ERR_OVERFLOW at fetch) and, if d_count is not
  * NULL, the number of records of the call to the 8-byte device word d_count - both by the kernels of
  * modes_gpu_detect, in stream order, so that a collective queued behind the detect can consume them without
- * a host round trip.  (NULL, 0, NULL) returns to the context's own list. */
+ * a host round trip.  (NULL, 0, NULL) returns to the context's own list (which keeps the capacity it has). */
 int modes_gpu_set_output(modes_gpu *ctx, void *d_records, uint64_t capacity, void *d_count);
 
 /* Host-buffer convenience used by the C host: stages `nbytes` stream bytes that

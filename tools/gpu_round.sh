@@ -17,14 +17,14 @@ for s in $STEPS; do
     full)   run full 1500 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --maxfail=3 -p no:cacheprovider ;;
     full8)  run full8 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --maxfail=3 -p no:cacheprovider -k "not sixty_four" ;;
     bench)  run bench 600 python bench.py ;;
-    ab)     B="python bench.py --workload noise --no-end-to-end --no-cpu-baseline"
-            run ab_s1_d4 200 $B --streams 1 --depth 4
-            run ab_s2_d4 200 $B --streams 2 --depth 4
-            run ab_s2_d6 200 $B --streams 2 --depth 6
-            run ab_s3_d6 200 $B --streams 3 --depth 6
-            run ab_s2_d4_t8 200 $B --streams 2 --depth 4 --time-every 8
-            run ab_s2_d4_k100 200 $B --streams 2 --depth 4 --steps 100
-            run ab_s2_d4_v1 200 $B --streams 2 --depth 4 --demod-variant 1 ;;
+    ab)     B="python bench.py --workload noise --no-end-to-end --no-cpu-baseline --steps 60"
+            run ab_s2 200 $B
+            MODES_DEMOD_PER_CU=1 run ab_s2_cu1 200 $B
+            MODES_DEMOD_PER_CU=1 run ab_s2_cu1_R16 200 $B --run-chunks 16
+            MODES_DEMOD_PER_CU=1 run ab_s3_cu1 200 $B --streams 3 --depth 6
+            run ab_s3 200 $B --streams 3 --depth 6
+            run ab_s1 200 $B --streams 1
+            MODES_DEMOD_PER_CU=1 run ab_s1_cu1 200 $B --streams 1 ;;
     gloo)   run gloo2 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 \
                 bench.py --gpus 2 --backend gloo --frames-mib 1024 --steps 5 --warmup 2 --settle 10 ;;
     prof)   run prof 900 bash tools/profile.sh "$TAG" ; mkdir -p "$O/prof"; cp -r gpurun_out/prof_$TAG/summary.txt gpurun_out/prof_$TAG/traffic.json "$O/prof/" 2>/dev/null

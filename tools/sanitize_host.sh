@@ -18,13 +18,11 @@ trap restore EXIT
 set -e
 TESTS="tests/test_host.py tests/test_track.py tests/test_core.py"
 run_one() {
-    local kind=$1 san preload=""
+    local kind=$1 san
     if [ "$kind" = ubsan ]; then
         san="-fsanitize=undefined -fno-sanitize-recover=undefined"
     else
         san="-fsanitize=address -fno-omit-frame-pointer"
-        # both runtimes (gcc's for the host library, clang's for the shim) must be loaded before python's first malloc
-        preload="$(gcc -print-file-name=libasan.so):$RT/libclang_rt.asan-x86_64.so"
     fi
     (cd dump1090_amd/csrc && g++ -O1 -g -std=c++17 -fPIC $san -I../../include -shared -o ../libmodes_host.so modes_host.cpp modes_track.cpp -lm)
     (cd tests/native && $CLANG -O1 -g -std=c++17 -fPIC -shared $san -shared-libsan -Wl,-rpath,$RT -I ../../dump1090_amd/csrc -o libcore_shim.so core_shim.cpp)
