@@ -205,10 +205,10 @@ def main():
                     help="threads of rank 0's resolve (modes_host_resolve_raw_mt: exact, speculative pieces confirmed in order); "
                          "0 = min(32, host cores / 4): rank 0 is the only rank that resolves")
     ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the calls are spread over.  2 (default): the scan kernel of call i+1 does not wait for the "
-                         "demod / finalize kernels of call i (it fills their gaps; they are latency-bound and leave the vector "
-                         "units idle); the calls that carry timing events are run alone, so their kernel times - the roofline's "
-                         "- are the kernels' own.  1: everything in order on one stream")
+                    help="launch streams of the throughput region.  2 (default): the scan kernel of call i+1 does not queue behind the "
+                         "demod / finalize kernels of call i (they are latency-bound and leave the vector units idle; it also fills "
+                         "the 6 us in front of every scan).  Kernel durations are measured in a second timed region on ONE stream, "
+                         "where every kernel runs alone (`one_launch_stream`).  1: one region, one stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                                                       "the N > 1 control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--force-gather", action="store_true",
@@ -255,22 +255,33 @@ def main():
         lo, hi = shard_byte_range(first_block, nblocks, total_bytes)
         return first_block, nblocks, lo, hi
 
-    works = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    def leg(iq, lo, calls, flags, steps, warm, cap_records, nstreams, timing):
+        """K timed steps over this rank's HBM-resident shard (dump1090_amd/pipeline.py).  timing: one call in --time-every
+        carries HIP timing events around its kernels (one launch stream only: the times are then the kernels' own); without:
+        no events at all - pure throughput."""
+        works = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
 
-    def leg(iq, lo, calls, flags, steps, warm, cap_records):
-        """K timed steps over this rank's HBM-resident shard (dump1090_amd/pipeline.py)"""
+        class NoTiming:                                   # run_steps switches timing per call only on objects that have set_timing
+            def __init__(self, d):
+                self._d = d
+                d.set_timing(False)
+
+            def __getattr__(self, k):
+                if k == "set_timing":
+                    raise AttributeError(k)
+                return getattr(self._d, k)
+
         def make():
-            return Demodulator(device=local, run_chunks=args.run_chunks, scan_variant=args.scan_variant,
-                               overlap=args.overlap, demod_variant=args.demod_variant,
-                               max_records=cap_records if dist_on else 0, **flags)
+            d = Demodulator(device=local, run_chunks=args.run_chunks, scan_variant=args.scan_variant, overlap=args.overlap,
+                            demod_variant=args.demod_variant, max_records=cap_records if dist_on else 0, **flags)
+            return d if timing else NoTiming(d)
         return run_steps(make, iq, lo, calls, flags, steps, warm, args.depth, world=world, rank=rank, dist=dist,
                          coll_device=coll_dev, cap_records=cap_records, streams=works,
                          device_sync=lambda: torch.cuda.synchronize(dev), time_every=max(1, args.time_every),
-                         resolve_threads=args.resolve_threads or max(1, min(32, (os.cpu_count() or 4) // 4)),
-                         gather=dist_on)
+                         resolve_threads=args.resolve_threads or max(1, min(32, (os.cpu_count() or 4) // 4)), gather=dist_on)
 
     line = {}
-    noise = None
+    noise = noise1 = None
     iq_noise = None
     if args.workload in ("all", "noise"):
         per_gpu = args.mib << 20
@@ -284,8 +295,17 @@ def main():
         torch.cuda.synchronize(dev)
         gen.close()
         calls = split_calls(first_block, nblocks, 1, lo, total)
-        noise = leg(iq_noise, lo, calls, dict(fix=False, aggressive=False), args.steps, args.settle + args.warmup, 1 << 16)
-        noise.update(total=total, span=hi - lo, per_gpu=per_gpu)
+        # Two timed regions of K steps each over the same resident input:
+        #   throughput  --streams (2) launch streams, no events in the streams: `value`, `ms_per_step`
+        #   kernels     ONE launch stream, timing events on one call in --time-every: every kernel runs alone, so the
+        #               durations are the kernels' own -> `kernel_ms`, `roofline`; its own step time is `one_launch_stream`
+        # (--streams 1: one region serves both.)
+        noflags = dict(fix=False, aggressive=False)
+        noise1 = leg(iq_noise, lo, calls, noflags, args.steps, args.settle + args.warmup, 1 << 16, 1, True)
+        noise = noise1 if args.streams <= 1 else leg(iq_noise, lo, calls, noflags, args.steps, args.settle + args.warmup, 1 << 16,
+                                                    args.streams, False)
+        for x in (noise, noise1):
+            x.update(total=total, span=hi - lo, per_gpu=per_gpu)
 
     frames = None
     if args.workload in ("all", "frames"):
@@ -299,7 +319,7 @@ def main():
         max_blocks = (total // 262144) // world + 1
         calls = split_calls(first_block, nblocks, (max_blocks + 32766) // 32767, lo, total)
         fsteps = args.frames_steps if args.workload == "all" else args.steps
-        frames = leg(iq_f, lo, calls, dict(fix=True, aggressive=False), fsteps, 6, 1 << 17)
+        frames = leg(iq_f, lo, calls, dict(fix=True, aggressive=False), fsteps, 6, 1 << 17, 1, True)
         frames.update(total=total, span=hi - lo, per_gpu=per_gpu)
         expected = mine
         if world > 1:
@@ -332,14 +352,15 @@ def main():
         return d
 
     head = noise if noise is not None else frames
+    kern = noise1 if noise1 is not None else frames            # the region whose kernel times are reported
     head_steps = head["steps"]
     head_name = ("%d MiB synthetic uint8 IQ @ 2 Msps format per GPU (sigma=3 integer noise, seed 20260922), --no-fix, "
                  "HBM-resident; BASELINE.json configs[1]" % args.mib) if noise is not None else (
         "%d MiB per GPU of sigma=3 noise + DF11/DF17 frames, --fix; BASELINE.json configs[%d]" % (args.frames_mib, 2 if world == 1 else 3))
     samples_per_step = head["total"] // 2                                     # the whole stream: every rank's shard
     value = samples_per_step * head_steps / head["elapsed"] / 1e6
-    assert head["timed_calls"] > 0 and head["scan_ms"] > 0, "no call of the timed region carried timing events"
-    achieved = head["call_bytes"] / (head["scan_ms"] * 1e-3) / 1e9             # this rank's launches: 2 B per sample
+    assert kern["timed_calls"] > 0 and kern["scan_ms"] > 0, "no call of the timed region carried timing events"
+    achieved = kern["call_bytes"] / (kern["scan_ms"] * 1e-3) / 1e9             # this rank's launches: 2 B per sample
     traffic, traffic_note = measured_traffic(args.mib) if noise is not None else (None, "no PMC pass for this workload")
     line = {
         "metric": "IQ Msamples/s demodulated", "value": round(value, 1), "unit": "Msamples/s",
@@ -351,19 +372,27 @@ def main():
                    "sharding": "buffers over %d rank(s)" % world, "settle_steps": args.settle if noise is not None else 6,
                    "step": "scan + demod + order kernels, record fetch%s, host resolve + --raw formatting on a second thread; "
                            "%d detect(s) in flight; overlap=%d; completion by a host-visible word (no event in the stream), kernel timing events on "
-                           "one call in %d (run alone); %d launch stream(s)" % (
+                           "one call in %d of the one-stream region; %d launch stream(s) in the throughput region" % (
                                ", device-resident lists gathered to rank 0 over %s (counts all_gather + exact-size send/recv)" % (
                                    "RCCL" if args.backend == "nccl" else args.backend) if world > 1 else "",
                                head["depth"], args.overlap, args.time_every, max(1, args.streams))},
         "msgs_per_s": round(head.get("msgs", 0) / head["elapsed"], 2) if rank == 0 else None,
         "preambles_per_step_rank0": int(head["last"].get("n_preambles", 0)),
         "forwarded_per_step_rank0": int(head["last"].get("n_forwarded", 0)),
-        "kernel_ms": {"scan": round(head["scan_ms"], 4), "demod": round(head["demod_ms"], 4), "order": round(head["order_ms"], 4),
-                      "timed_calls": head["timed_calls"], "of_calls": head["steps"] * head["calls_per_step"]},
+        "kernel_ms": {"scan": round(kern["scan_ms"], 4), "demod": round(kern["demod_ms"], 4), "order": round(kern["order_ms"], 4),
+                      "timed_calls": kern["timed_calls"], "of_calls": kern["steps"] * kern["calls_per_step"],
+                      "measured_in": "a timed region of the same K steps on ONE launch stream (every kernel alone)" if kern is not head
+                      else "the timed region"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
-                     "kernel": "scan_kernel", "algorithmic_bytes_per_launch": int(head["call_bytes"])},
+                     "kernel": "scan_kernel", "algorithmic_bytes_per_launch": int(kern["call_bytes"])},
     }
+    if noise1 is not None and noise1 is not noise:
+        line["one_launch_stream"] = {
+            "Msamples_per_s": round(noise1["total"] // 2 * noise1["steps"] / noise1["elapsed"] / 1e6, 1),
+            "ms_per_step": round(noise1["elapsed"] / noise1["steps"] * 1e3, 4),
+            "what": "the same K steps with every call on one launch stream (scan, demod, finalize strictly in order; timing events on "
+                    "one call in %d): the region kernel_ms and roofline are measured in - there the kernel times add up to the step" % args.time_every}
     if frames is not None and noise is not None:
         f = leg_summary(frames, frames["steps"], "BASELINE.json configs[%d]: %d MiB per GPU, sigma=3 noise + DF11/DF17 frames "
                         "(1 per 65,536 samples, 10 %% with a flipped bit, seam offsets), --fix" % (2 if world == 1 else 3, args.frames_mib))

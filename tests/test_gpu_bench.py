@@ -28,6 +28,10 @@ def check(j, n_gpus):
     lc = f["listing_check"]
     assert lc["missing"] == 0 and lc["lines"] >= lc["expected_frames"] > 0.9 * 256 * n_gpus * 2 ** 20 / 2 / 65536
     assert f["msgs_per_step"] == lc["lines"]
+    if "one_launch_stream" in j:
+        one = j["one_launch_stream"]
+        k = j["kernel_ms"]
+        assert one["Msamples_per_s"] > 0 and k["scan"] + k["demod"] <= one["ms_per_step"] * 1.02   # in order on one stream
 
 
 @pytest.mark.parametrize("extra", [[], ["--streams", "1"], ["--force-gather"], ["--force-gather", "--overlap", "2"]])
