@@ -13,7 +13,10 @@
 #include <cstring>
 #include <new>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -433,6 +436,56 @@ uint64_t modes_host_resolve_raw(modes_host *h, const modes_record *recs, uint64_
 // the one-thread listing on every stream.
 // ---------------------------------------------------------------------------------------------
 namespace {
+// Worker threads of the multi-threaded resolve: created once per process, on first use (starting 8-32 threads costs more
+// than resolving a batch of 35,000 records).  One parallel loop at a time; callers from different hosts take turns.
+class WorkerPool {
+public:
+    static WorkerPool &instance() {
+        static WorkerPool pool;
+        return pool;
+    }
+    // fn(0 .. n-1), the caller runs index 0 itself; returns when all are done
+    void run(size_t n, const std::function<void(size_t)> &fn) {
+        if (n <= 1) { if (n) fn(0); return; }
+        std::lock_guard<std::mutex> turn(turn_);
+        {
+            std::unique_lock<std::mutex> g(m_);
+            while (workers_.size() < n - 1) workers_.emplace_back([this] { work(); });
+            fn_ = &fn; next_ = 1; total_ = n; left_ = n - 1;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+private:
+    void work() {
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [this] { return stop_ || (fn_ && next_ < total_); });
+            if (stop_) return;
+            const size_t i = next_++;
+            const std::function<void(size_t)> *fn = fn_;
+            g.unlock();
+            (*fn)(i);
+            g.lock();
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, turn_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t next_ = 0, total_ = 0, left_ = 0;
+    bool stop_ = false;
+};
+
 struct Piece {
     uint64_t lo = 0, hi = 0;
     modes_host host;                 // private copy: config, clock, whitelist (guess, then the piece's own writes), stats of the piece
@@ -468,8 +521,8 @@ void run_piece(Piece &p, const modes_record *recs) {
 
 uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint64_t nrecs, char *out, uint64_t cap,
                                    uint64_t *nbytes, int threads) {
-    // threads < 0: exactly -threads pieces however short the list (tests); otherwise at least 4096 records per thread
-    const uint64_t kMinPiece = threads < 0 ? 1 : 4096;
+    // threads < 0: exactly -threads pieces however short the list (tests); otherwise at least 2048 records per thread
+    const uint64_t kMinPiece = threads < 0 ? 1 : 2048;
     int T = threads < 0 ? -threads : threads;
     T = T < 1 ? 1 : (T > 64 ? 64 : T);
     if ((uint64_t)T > nrecs / kMinPiece) T = (int)(nrecs / kMinPiece);
@@ -512,12 +565,8 @@ uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint
         }
     }
     const double t1 = now();
-    {   // speculative resolve, one thread per piece
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < P; t++) th.emplace_back([&, t] { run_piece(pieces[t], recs); });
-        run_piece(pieces[0], recs);
-        for (auto &x : th) x.join();
-    }
+    // speculative resolve, one worker per piece
+    WorkerPool::instance().run(P, [&](size_t t) { run_piece(pieces[t], recs); });
     const double t2 = now();
     int reruns = 0;
     // confirm in order: the true state at the start of piece t is the confirmed state at the end of piece t - 1
