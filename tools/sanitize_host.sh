@@ -1,7 +1,9 @@
 #!/bin/bash
 # Runs the CPU tests of the host library and of the header-only device arithmetic against sanitizer builds:
-#   tools/sanitize_host.sh            UBSan, then ASan
-#   tools/sanitize_host.sh ubsan|asan one of them
+#   tools/sanitize_host.sh                 UBSan, then ASan, then TSan
+#   tools/sanitize_host.sh ubsan|asan|tsan one of them
+# tsan: the multi-threaded resolve (modes_host_resolve_raw_mt: worker pool, speculative pieces) in a C++ harness built
+# together with the host sources under -fsanitize=thread, on the records of the reference's capture.
 # (-fno-sanitize-recover / abort_on_error: any finding kills the test process).  The host library is built with
 # gcc, the shim around modes_core.h needs clang (vector extensions) and its shared sanitizer runtime; under ASan
 # python itself has to run with the runtimes preloaded.  The normal builds are restored whatever happens.
@@ -35,8 +37,27 @@ run_one() {
         python -m pytest $TESTS -x -q -p no:cacheprovider
     fi
 }
+run_tsan() {
+    echo "== tsan =="
+    python - <<'PY'
+import sys
+sys.path[:0] = [".", "tests", "oracle"]
+import numpy as np, synth
+from helpers import oracle_records
+recs, _ = oracle_records(synth.modes1_padded("tests/golden/modes1.bin"), 1)
+big = np.tile(recs, 12)
+nb = int(recs["block"].max()) + 1
+for r in range(12):
+    big["block"][r * recs.size:(r + 1) * recs.size] += r * nb
+big.tofile("/tmp/modes_mt_records.bin")
+PY
+    g++ -O1 -g -std=c++17 -fsanitize=thread -Iinclude -o /tmp/modes_mt_harness tests/native/mt_harness.cpp \
+        dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp -lpthread -lm
+    TSAN_OPTIONS=halt_on_error=1 /tmp/modes_mt_harness /tmp/modes_mt_records.bin
+}
 case "${1:-all}" in
     ubsan) run_one ubsan ;;
     asan)  run_one asan ;;
-    *)     run_one ubsan; run_one asan ;;
+    tsan)  run_tsan ;;
+    *)     run_one ubsan; run_one asan; run_tsan ;;
 esac
