@@ -127,6 +127,25 @@ def test_config5_low_snr_aggressive_matches_reference(torch_cuda):
     assert d.last["stats_text"] == reference_stdout(host, "aggressive", "--stats")
     assert len(msgs) > 1000                                         # the path is exercised, not vacuous
     assert any(m.phase_corrected for m in msgs) and any(m.errorbit >= 0 for m in msgs)
+    # configs[4] names 8 GPUs: the same stream cut into the 8 buffer ranges bench.py --gpus 8 gives its ranks, each range
+    # demodulated from exactly the bytes that rank would hold, the lists concatenated in rank order and resolved once
+    # (on 16 threads, like rank 0 does) - the listing must not notice
+    from dump1090_amd import HostResolver, block_count, shard_blocks, shard_byte_range
+    total = block_count(st.nbytes)
+    parts = []
+    d8 = Demodulator(aggressive=True)
+    for rank in range(8):
+        first, n = shard_blocks(total - 1, 8, rank)
+        if rank == 7:
+            n += 1
+        lo, hi = shard_byte_range(first, n, st.nbytes)
+        d8.detect(iq[lo:hi].clone(), stream_byte0=lo, first_block=first, nblocks=n)     # the rank's own allocation
+        parts.append(d8.fetch()[0])
+    res = HostResolver(aggressive=True)
+    n_lines, text = res.raw_listing(np.concatenate(parts), None, threads=16)
+    res.close()
+    assert text.decode() == raw_text(msgs) and n_lines == len(msgs)
+    d8.close()
     d.close()
 
 
