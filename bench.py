@@ -241,10 +241,14 @@ def main():
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
+        # a rank that stops answering ends the job with an error after three minutes (the default is ten) instead of
+        # holding the node
+        import datetime
+        limit = datetime.timedelta(seconds=180)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=limit)
 
     def shard(total_bytes):
         """this rank's contiguous buffer range of a world x per-GPU stream, and the bytes it needs (476-byte carry in front)"""

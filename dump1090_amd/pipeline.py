@@ -47,6 +47,9 @@ class Resolver(threading.Thread):
             item = self.q.get()
             if item is None:
                 return
+            if isinstance(item, threading.Event):               # drain(): everything submitted before it is resolved
+                item.set()
+                continue
             recs, counts, first_call, last_call, timed, done = item
             try:
                 if first_call:
@@ -86,6 +89,12 @@ class Resolver(threading.Thread):
                     if ev is not None:
                         ev.set()
 
+    def drain(self):
+        """Block until everything submitted so far is resolved (a released buffer only says its records were taken over)."""
+        ev = threading.Event()
+        self.q.put(ev)
+        ev.wait()
+
     def stop(self):
         self.q.put(None)
         self.join()
@@ -105,7 +114,7 @@ def split_calls(first_block, nblocks, ncalls, lo, total_bytes):
 
 def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, rank=0, dist=None, coll_device=None,
               cap_records=1 << 16, streams=(None,), device_sync=lambda: None, time_every=8, resolve_threads=1,
-              gather=None):
+              gather=None, oplog=None):
     """`warm` untimed + `steps` timed steps of the hot path over this rank's shard `iq` (stream bytes from `lo`;
     a CUDA uint8 tensor - anything sliceable that make_demod()'s detect accepts); a step is the sequence `calls`
     of GPU calls (split_calls).  `depth` contexts (make_demod() each) are used in rotation, so that the GPU always
@@ -123,7 +132,13 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     are exercised on a one-GPU box).
     world > 1: `dist` = torch.distributed (initialised), coll_device = where the gathered bytes travel (the CUDA
     device with RCCL; "cpu" with gloo: the lists are fetched to the host first).  Returns a dict of measurements
-    (rank 0: also the --raw listing of the last step)."""
+    (rank 0: also the --raw listing of the last step).
+
+    Every rank issues its communication calls in the SAME order - per call n: detect(n), count all_gather(n), list
+    transfers(n - 1); at a flush: the transfers of the newest call - whatever its resolver thread is doing: RCCL
+    executes a communicator's operations in issue order, so a rank that queued "transfers(n - 1), all_gather(n)" against
+    peers that queued "all_gather(n), transfers(n - 1)" would deadlock.  oplog (a list): receives ("detect" | "counts" |
+    "records", call number) as they are issued (tests/test_pipeline.py compares the ranks' logs)."""
     import torch
     from .distributed import RecordGather
 
@@ -132,12 +147,18 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     works = list(streams)
     slots = None
     on_gpu = coll_device is not None and torch.device(coll_device).type == "cuda"
+    # the detector writes its ordered list and count straight into the gather buffers (modes_gpu_set_output): always on
+    # the GPU; a CPU stand-in may offer the same (tests: the schedule of the RCCL path on gloo)
+    inplace = on_gpu or bool(getattr(demods[0], "cpu_output", False))
+    log = oplog.append if oplog is not None else (lambda item: None)
     if dist_on:
         rg = RecordGather(cap_records, device=coll_device)
         slots = [rg.slot() for _ in range(depth)]
-        if on_gpu:
+        comms = [None] * depth
+        if inplace:
             for d, s in zip(demods, slots):
                 d.set_output(s.own_records, s.count)
+        if on_gpu:
             # the exchanges of a call are queued on a stream of their own, behind the call's results (with overlap the
             # detect's launch stream does not wait for the demod and order kernels)
             comms = [torch.cuda.Stream(device=coll_device) for _ in range(depth)]
@@ -164,15 +185,17 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             order_ms.append(info["order_ms"])
 
     # phase 1 of a call in flight (N > 1): its counts are on the host -> queue the transfers of the lists
-    def phase_records(k, stream, timed):
+    def phase_records(k, stream, timed, n):
         d, s = demods[k], slots[k]
-        if on_gpu:
+        if inplace:
             _, info = d.fetch_device()
         else:                                                   # --backend gloo smoke mode: the lists travel as CPU tensors
             recs, _, info = d.fetch()
             s.own_records[: recs.size * 64] = torch.from_numpy(recs.view(np.uint8).reshape(-1))
             s.count[0] = recs.size
+            log(("counts", n))
             s.exchange_counts()
+        log(("records", n))
         s.exchange_records(stream=stream)
         note(info, timed)
 
@@ -189,7 +212,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             free[k].clear()
             resolver.submit(recs, counts, tag[0], tag[1], timed, free[k])
 
-    stage = {}                                                  # context -> [phase, stream, timed, (first call, last call of its step)]
+    stage = {}                                                  # context -> [phase, stream, timed, (first call, last call of its step), call number]
     order = []                                                  # contexts with a call in flight, oldest first
 
     def advance(k, upto):
@@ -197,7 +220,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         if st is None:
             return
         if st[0] == 0 and dist_on and upto >= 1:
-            phase_records(k, st[1], st[2])
+            phase_records(k, st[1], st[2], st[4])
             st[0] = 1
         if upto >= 2:
             phase_resolve(k, st[3], st[2])
@@ -213,6 +236,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                 advance(k, 2)
             for e in free:
                 e.wait()
+            if resolver is not None:
+                resolver.drain()
             sync_all()
             t0 = time.perf_counter()
         timed = step >= warm
@@ -225,7 +250,11 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                         break
             # ... and resolved: the record buffer is reused.  (Rank 0 with several calls per step: the resolver releases a
             # step's buffers together, when it has the step's last call - hand it everything that is still in flight.)
-            while not free[k].is_set() and order:
+            # Only calls whose transfers are already queued: the newest call's are queued at ITS point of the schedule
+            # (below, behind the next call's all_gather) on every rank, never from this rank-0-only wait.  The buffer
+            # waited for never depends on the newest call: the resolver holds a step's buffers only when depth >
+            # len(calls), and then the step that last used context k ended at least two calls ago.
+            while not free[k].is_set() and order and not (dist_on and stage[order[0]][0] == 0):
                 advance(order[0], 2)
             free[k].wait()
             stream = works[ncall % len(works)]
@@ -242,16 +271,19 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                 for w in works:
                     if w is not stream:
                         stream.wait_stream(w)
+            log(("detect", ncall))
             demods[k].detect(iq[clo - lo: chi - lo], stream_byte0=clo, first_block=b0, nblocks=nb, stream=stream)
             if alone:
                 for w in works:
                     if w is not stream:
                         demods[k].stream_wait(w)
-            if dist_on and on_gpu:
-                demods[k].stream_wait(comms[k])
+            if dist_on and inplace:
+                if on_gpu:
+                    demods[k].stream_wait(comms[k])
+                    stream = comms[k]
+                log(("counts", ncall))
                 slots[k].exchange_counts(stream=comms[k])
-                stream = comms[k]
-            stage[k] = [0, stream, timed, (ci == 0, ci == len(calls) - 1)]
+            stage[k] = [0, stream, timed, (ci == 0, ci == len(calls) - 1), ncall]
             order.append(k)
             ncall += 1
             # keep the older calls moving: the previous one gets its transfers queued, the one before is handed over
@@ -263,6 +295,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         advance(k, 2)
     for e in free:
         e.wait()
+    if resolver is not None:
+        resolver.drain()                                        # the timed region ends when the last message is out
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist_on:

@@ -17,8 +17,17 @@ class OracleDetector:
     """Quacks like dump1090_amd.Demodulator for run_steps' host-list mode: detect() remembers the buffers,
     fetch() returns their records (ascending, RECORD_DTYPE) from the oracle."""
 
-    def __init__(self, data, maxfix):
+    def __init__(self, data, maxfix, cpu_output=False):
         self.data, self.maxfix, self.span, self.calls = data, maxfix, None, 0
+        self.cpu_output = cpu_output        # run_steps: give me the gather buffers (the schedule of the RCCL path, on gloo)
+        self.out = None
+
+    def set_output(self, records, count):
+        self.out = (records, count)
+
+    def fetch_device(self):
+        recs, _, info = self.fetch()
+        return recs.size, info
 
     def detect(self, iq, stream_byte0=0, first_block=0, nblocks=None, stream=None):
         from dump1090_amd import shard_byte_range
@@ -28,6 +37,12 @@ class OracleDetector:
         assert np.array_equal(iq, self.data[lo:hi])
         self.span = (first_block, nblocks)
         self.calls += 1
+        if self.out is not None:            # "the kernels" leave the ordered list and its length in the caller's buffers
+            import torch
+            recs = self.fetch()[0]
+            self.span = (first_block, nblocks)
+            self.out[0][: recs.size * 64] = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy())
+            self.out[1][0] = recs.size
 
     def fetch(self, copy=True):
         from helpers import oracle_records
@@ -48,7 +63,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, case, ncalls, depth, outdir):
+def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_resolver=0.0):
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -69,12 +84,30 @@ def _run(rank, world, port, case, ncalls, depth, outdir):
     made = []
 
     def make():
-        made.append(OracleDetector(data, 1))
+        made.append(OracleDetector(data, 1, cpu_output=inplace))
         return made[-1]
 
+    if slow_resolver:                                            # rank 0's sequential half falls behind its GPU
+        import time
+        from dump1090_amd import pipeline
+        fast = pipeline.Resolver._resolve
+        pipeline.Resolver._resolve = lambda self, recs, timed: (time.sleep(slow_resolver), fast(self, recs, timed))[1]
+    oplog = []
     out = run_steps(make, data[lo:hi], lo, calls, dict(fix=True, aggressive=False), steps=2, warm=1, depth=depth,
-                    world=world, rank=rank, dist=dist, coll_device="cpu", cap_records=4096)
+                    world=world, rank=rank, dist=dist, coll_device="cpu", cap_records=4096, oplog=oplog)
     assert sum(d.calls for d in made) == 3 * ncalls and out["calls_per_step"] == ncalls
+    if world > 1:
+        # every rank issued its communication calls in the same order (RCCL executes them in issue order: a rank that
+        # deviates deadlocks the job) - per call n: detect(n), counts(n), records(n - 1)
+        logs = [None] * world
+        dist.all_gather_object(logs, oplog)
+        assert all(l == logs[0] for l in logs), "ranks issued their communication calls in different orders"
+        if inplace:
+            at = {op: i for i, op in enumerate(oplog)}
+            for n in range(1, 3 * ncalls):
+                assert at[("detect", n)] < at[("counts", n)]
+                if ("records", n - 1) in at and at[("records", n - 1)] > at[("detect", n)]:
+                    assert at[("counts", n)] < at[("records", n - 1)]
     if rank == 0:
         with open(os.path.join(outdir, "out.txt"), "wb") as f:
             f.write(out["listing"])
@@ -82,6 +115,18 @@ def _run(rank, world, port, case, ncalls, depth, outdir):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _spawn2(args, deadline=180.0):
+    """Two ranks; a hang (ranks waiting for each other) is a failure, not a stuck test run."""
+    import time
+    ctx = mp.spawn(_run, args=args, nprocs=2, join=False)
+    t0 = time.time()
+    while not ctx.join(timeout=2.0):
+        if time.time() - t0 > deadline:
+            for p in ctx.processes:
+                p.terminate()
+            pytest.fail("the ranks hung - communication calls issued in different orders?")
 
 
 @pytest.mark.parametrize("case,ncalls,depth", [("frames", 1, 3), ("edges", 2, 3), ("edges", 3, 2), ("frames", 2, 1)])
@@ -92,5 +137,14 @@ def test_single_rank_pipeline(tmp_path, golden, case, ncalls, depth):
 
 @pytest.mark.parametrize("case,ncalls,depth", [("frames", 1, 3), ("edges", 2, 3), ("edges", 2, 2), ("edges", 2, 1), ("edges", 3, 4)])
 def test_two_ranks_gather_over_gloo(tmp_path, golden, case, ncalls, depth):
-    mp.spawn(_run, args=(2, _free_port(), case, ncalls, depth, str(tmp_path)), nprocs=2, join=True)
+    _spawn2((2, _free_port(), case, ncalls, depth, str(tmp_path)))
+    assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
+
+
+@pytest.mark.parametrize("case,ncalls,depth,slow", [("edges", 1, 3, 0.05), ("edges", 2, 3, 0.05), ("edges", 3, 4, 0.03), ("frames", 2, 2, 0.03),
+                                                     ("edges", 3, 2, 0.0)])
+def test_two_ranks_same_communication_order(tmp_path, golden, case, ncalls, depth, slow):
+    """The schedule of the RCCL path (lists written in place, counts all_gather behind the detect) on gloo, with rank 0's
+    resolver slower than its detector: the ranks' sequences of communication calls must not diverge."""
+    _spawn2((2, _free_port(), case, ncalls, depth, str(tmp_path), True, slow))
     assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
