@@ -96,6 +96,49 @@ __device__ __forceinline__ uint4 power16_sat(uint4 v) {
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// The scan kernel's powers by the byte dot product: w ^ 0x7f7f7f7f turns every byte b into the signed byte 127 - b
+// (0 -> 127, 255 -> -128: it always fits), v_dot4_i32_i8 against the same dword with one sample's two bytes kept
+// gives (127-I)^2 + (127-Q)^2 in one instruction, and its clamp against the accumulator 0x7fff8000 saturates the one
+// power that needs 16 bits (32768: I = Q = 255) to 32767: the low half of the result is 0x8000 | min(s, 32767).  The
+// constant bit 15 changes no ordering and no difference; the level bound of the beta pass accounts for it (kPowBias).
+constexpr uint32_t kPowBias = 0x8000u;
+__device__ __forceinline__ uint4 power16_scan(uint4 v) {
+    // One block, hand-ordered: hipcc fuses the xor into the two ANDs (v_bitop3, a half-rate VOP3 - 12 of them instead of
+    // 12 full-rate VOP2) and leaves s_nops between a dot product and the v_perm that packs it; here the eight dot
+    // products sit between their producers and consumers (a dot result is read no sooner than 3 instructions later).
+    uint32_t o0, o1, o2, o3, t0, t1, t2, t3, a0, a1, a2, a3, b0, b1, b2, b3;
+    asm("v_xor_b32 %4, %20, %16\n\t"
+        "v_xor_b32 %5, %20, %17\n\t"
+        "v_xor_b32 %6, %20, %18\n\t"
+        "v_xor_b32 %7, %20, %19\n\t"
+        "v_and_b32 %8, %21, %4\n\t"
+        "v_and_b32 %12, %22, %4\n\t"
+        "v_and_b32 %9, %21, %5\n\t"
+        "v_and_b32 %13, %22, %5\n\t"
+        "v_and_b32 %10, %21, %6\n\t"
+        "v_and_b32 %14, %22, %6\n\t"
+        "v_and_b32 %11, %21, %7\n\t"
+        "v_and_b32 %15, %22, %7\n\t"
+        "v_dot4_i32_i8 %8, %4, %8, %23 clamp\n\t"
+        "v_dot4_i32_i8 %12, %4, %12, %23 clamp\n\t"
+        "v_dot4_i32_i8 %9, %5, %9, %23 clamp\n\t"
+        "v_dot4_i32_i8 %13, %5, %13, %23 clamp\n\t"
+        "v_dot4_i32_i8 %10, %6, %10, %23 clamp\n\t"
+        "v_dot4_i32_i8 %14, %6, %14, %23 clamp\n\t"
+        "v_dot4_i32_i8 %11, %7, %11, %23 clamp\n\t"
+        "v_dot4_i32_i8 %15, %7, %15, %23 clamp\n\t"
+        "v_perm_b32 %0, %12, %8, %24\n\t"
+        "v_perm_b32 %1, %13, %9, %24\n\t"
+        "v_perm_b32 %2, %14, %10, %24\n\t"
+        "v_perm_b32 %3, %15, %11, %24\n\t"
+        "s_nop 0"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),
+          "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+        : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "s"(0x7F7F7F7Fu), "s"(0x0000FFFFu), "s"(0xFFFF0000u), "s"(0x7FFF8000u),
+          "s"(0x05040100u));
+    return make_uint4(o0, o1, o2, o3);
+}
+
 // Reference magnitude of buffer sample q (0 outside the stream).
 struct MagAt {
     const uint8_t *iq;
@@ -158,14 +201,20 @@ __global__ __launch_bounds__(256) void magnitude_kernel(const uint8_t *__restric
     }
 }
 
-// Debug tap: the powers the scan kernel works on.
+// Debug tap: the saturated powers, computed both ways the kernels compute them - the packed multiply / multiply-add the
+// demod kernel indexes its table with (power16_sat) and the byte dot product of the scan kernel (power16_scan, which
+// carries a constant bit 15).  A sample on which the two disagree reads 0xffff.
 __global__ __launch_bounds__(256) void power_kernel(const uint8_t *__restrict__ iq, uint64_t nsamples,
                                                     uint16_t *__restrict__ out) {
     const uint64_t ngroups = (nsamples + 7) / 8;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * blockDim.x) {
-        uint4 s = power16_sat(load_iq16(iq, (int64_t)(g * 16), 0, (int64_t)(nsamples * 2)));
-        uint32_t w[4] = {s.x, s.y, s.z, s.w};
-        for (int t = 0; t < 8 && g * 8 + t < nsamples; t++) out[g * 8 + t] = (uint16_t)(w[t >> 1] >> (16 * (t & 1)));
+        const uint4 v = load_iq16(iq, (int64_t)(g * 16), 0, (int64_t)(nsamples * 2));
+        const uint4 s = power16_sat(v), d = power16_scan(v);
+        const uint32_t w[4] = {s.x, s.y, s.z, s.w}, x[4] = {d.x, d.y, d.z, d.w};
+        for (int t = 0; t < 8 && g * 8 + t < nsamples; t++) {
+            const uint32_t a = (w[t >> 1] >> (16 * (t & 1))) & 0xffffu, b = (x[t >> 1] >> (16 * (t & 1))) & 0xffffu;
+            out[g * 8 + t] = (uint16_t)(b == (a | kPowBias) ? a : 0xffffu);
+        }
     }
 }
 
@@ -368,6 +417,12 @@ struct DemodParams {
 //
 // Forwarded positions of a run ARE in ascending order (scan_beta), and so is the concatenation over runs.
 // ------------------------------------------------------------------------------------
+// Cache policy of the stream loads (gfx940+ bits: 1 = sc0, 2 = nt, 16 = sc1).  Every byte is read once: nt | sc1
+// takes the kernel from 0.206 to 0.194 ms per GiB (nt alone 0.196, sc0 / sc1 alone: nothing; tools/ab_scan.py).
+#ifndef SCAN_AUX
+#define SCAN_AUX 18
+#endif
+constexpr int kScanAux = SCAN_AUX;
 constexpr int kQCap = 64;             // queue entries per wavefront: one beta pass
 constexpr int kQStride = 17;          // dwords per entry: 11 window + 4 results + 1 position + 1 pad (odd: no bank conflicts)
 constexpr int kScan2Waves = 2;
@@ -381,36 +436,65 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One pass over the queue: a lane per entry.  Everything that is the same for (almost) every entry is kept out of the
+// per-survivor loop - the pass costs ~12 % of the kernel, and all of it is instruction issue:
+//   * the eight ordering flags of an entry (bits 15 / 31 of its four result words) are gathered with two v_perm and
+//     walked in whatever bit order that leaves them in (the level bound does not care);
+//   * the span and framing rules (p_begin <= p < p_end, j < 131070) hold for all eight positions of an entry except
+//     at the two ends of a call and for one window per buffer: one test per entry, a per-position loop only there;
+//   * a lane forwards at most one position in all but ~1 pass in 200: one ballot ranks the lanes; the general
+//     prefix (a ballot per bit of the per-lane count) runs only when some lane has two.
 __device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *queue, uint32_t nb, int lane,
                                           uint32_t *my_slots, uint32_t &count) {
     const bool act = (uint32_t)lane < nb;
     const uint32_t *e = queue + lane * kQStride;
-    uint32_t m8 = 0, p0 = 0;
+    uint32_t f = 0, p0 = 0;
     if (act) {
-        const uint32_t r[4] = {e[11], e[12], e[13], e[14]};
-        m8 = modes_order8_mask(r);
+        // byte k of `lo` = the flag byte of position k (its bit 7), byte k of `hi` = position 4 + k
+        const uint32_t lo = __builtin_amdgcn_perm(e[12], e[11], 0x07050301u), hi = __builtin_amdgcn_perm(e[14], e[13], 0x07050301u);
+        f = ((lo & 0x80808080u) >> 7) | ((hi & 0x80808080u) >> 3);          // bit 8k <-> position k, bit 8k + 4 <-> position 4 + k
         p0 = e[15];
     }
     const uint16_t *w = reinterpret_cast<const uint16_t *>(e);
-    const uint32_t p_begin32 = (uint32_t)P.p_begin, p_span32 = (uint32_t)(P.p_end - P.p_begin), g0_lo = (uint32_t)P.g0;
     uint32_t fwd8 = 0;                                                       // bit i: position p0 + i is forwarded
-    while (m8) {                                                             // lanes with alpha survivors only
-        const int i = __builtin_ctz(m8);
-        m8 &= m8 - 1;
+    while (f) {                                                              // lanes with alpha survivors only
+        const uint32_t b = (uint32_t)__builtin_ctz(f);
+        f &= f - 1;
+        const uint32_t i = (b >> 3) | (b & 4u);
         const uint16_t *x = w + i;
         const uint32_t s0 = x[0], s2 = x[2], s4 = x[4], s5 = x[5], s7 = x[7], s9 = x[9], s11 = x[11], s12 = x[12],
                        s13 = x[13], s14 = x[14];
         const uint32_t quiet = max(max(max(s4, s5), max(s11, s12)), max(s13, s14));
-        const uint32_t p = p0 + (uint32_t)i;                                 // wraps for the 16 look-back positions of chunk 0
-        // 32-bit forms of p_begin <= p < p_end and of the framing rule j < 131070 (:1593): positions of a call are
-        // below 2^32 - 2^15, so a wrapped look-back position fails the first test, and j only needs p + g0 mod 2^17
-        const bool fwd = modes_level_bound(s0, s2, s7, s9, quiet) && (p - p_begin32) < p_span32 &&
-                         ((p + g0_lo) & (MODES_BLOCK_STRIDE - 1)) < MODES_BLOCK_POSITIONS;
-        fwd8 |= (fwd ? 1u : 0u) << i;
+        // (with kPowBias b on every value: 9 (q + b) < sum + 4 b + 4 + 5 b)
+        fwd8 |= (modes_level_bound(s0, s2, s7, s9 + 5u * kPowBias, quiet) ? 1u : 0u) << i;
+    }
+    // 32-bit forms of p_begin <= p < p_end and of the framing rule j < 131070 (:1593): positions of a call are below
+    // 2^32 - 2^15, so a wrapped look-back position (the 16 positions in front of chunk 0) fails the first test, and j
+    // only needs p + g0 mod 2^17.  `plain`: they hold for p0 .. p0 + 7 alike.
+    const uint32_t p_begin32 = (uint32_t)P.p_begin, p_span32 = (uint32_t)(P.p_end - P.p_begin), g0_lo = (uint32_t)P.g0;
+    const uint32_t span_m7 = p_span32 >= 8u ? p_span32 - 7u : 0u;            // wave-uniform
+    const bool plain = (p0 - p_begin32) < span_m7 && ((p0 + g0_lo) & (MODES_BLOCK_STRIDE - 1)) < MODES_BLOCK_POSITIONS - 7;
+    if (fwd8 != 0 && !plain) {                                               // ends of the call, one window per buffer
+        uint32_t keep = 0;
+        for (uint32_t m = fwd8; m; m &= m - 1) {
+            const uint32_t i = (uint32_t)__builtin_ctz(m), p = p0 + i;
+            if ((p - p_begin32) < p_span32 && ((p + g0_lo) & (MODES_BLOCK_STRIDE - 1)) < MODES_BLOCK_POSITIONS) keep |= 1u << i;
+        }
+        fwd8 = keep;
     }
     // Entries were queued in ascending p0 and own disjoint 8-position windows, so (lane, bit) order is position
     // order: the slot list of a run is ASCENDING, and so is the concatenation over runs - the demod kernel ranks
-    // its records by position without a sort.  Exclusive prefix over the lanes of a count <= 8: one ballot per bit.
+    // its records by position without a sort.
+    const uint64_t any = __ballot(fwd8 != 0);
+    if (any == 0) return;                                                    // wave-uniform
+    const uint64_t multi = __ballot((fwd8 & (fwd8 - 1)) != 0);
+    if (multi == 0) {                                                        // one position per forwarding lane
+        const uint32_t idx = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+        if (fwd8 != 0 && idx < P.slot_cap) my_slots[idx] = p0 + (uint32_t)__builtin_ctz(fwd8);
+        count += (uint32_t)__builtin_popcountll(any);
+        return;
+    }
+    // exclusive prefix over the lanes of a count <= 8: one ballot per bit
     const uint32_t cnt = (uint32_t)__builtin_popcount(fwd8);
     uint32_t excl = 0, total = 0;
 #pragma unroll
@@ -453,15 +537,15 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t *>(iq + (GUARD ? 0 : base_off)), 0, 0x7fffffff, 0x00020000);
-    // chunk c0 + k.  The prefetch runs two chunks ahead; past the end of the run it re-reads the run's
-    // last chunk (a cache hit, one s_min) instead of pulling the next run's first two chunks from
-    // HBM a second time (that cost 6 % extra traffic).
-    const uint32_t klast = (uint32_t)(c1 - c0 - 1);
-    auto load = [&](int64_t k) -> uint4 {
-        const uint32_t kk = (uint32_t)k < klast ? (uint32_t)k : klast;
+    // Chunk c0 + k is at byte offset k * 1024 of the run.  The prefetch runs two chunks ahead; past the end of the
+    // run it re-reads the run's last chunk (a cache hit, one s_min) instead of pulling the next run's first two
+    // chunks from HBM a second time (that cost 6 % extra traffic).  The offset is a scalar that just counts.
+    const uint32_t nk = (uint32_t)(c1 - c0), last_off = (nk - 1) * kChunkBytes;
+    auto load_at = [&](uint32_t off) -> uint4 {
+        const uint32_t o = off < last_off ? off : last_off;
         if (!GUARD)
-            return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, kk * kChunkBytes, 0));
-        return load_iq16(iq, base_off + (int64_t)kk * kChunkBytes + lane_off, lo, hi);
+            return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, o, kScanAux));
+        return load_iq16(iq, base_off + (int64_t)o + lane_off, lo, hi);
     };
 
     uint32_t count = 0, qn = 0;                                              // wave-uniform
@@ -484,10 +568,17 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
         // ---- alpha survivors -> queue; beta (level bound) whenever the next push might not fit ----
         const bool any = (((r[0] | r[1]) | (r[2] | r[3])) & MODES_ORDER_FLAGS) != 0;
         const uint64_t hb = __ballot(any);
+#if defined(SCAN_ABL)
+        count += (uint32_t)__builtin_popcountll(hb);        // ablation build (timing only): alpha kept alive, no hand-off
+        if (false) {
+#else
         if (hb) {
+#endif
             const uint32_t npush = (uint32_t)__builtin_popcountll(hb);
             if (qn + npush > kQCap) {
+#if !defined(SCAN_ABL_NOBETA)
                 scan_beta(P, queue, qn, lane, my_slots, count);
+#endif
                 qn = 0;
                 wave_lds_fence();
             }
@@ -508,22 +599,23 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
 
     // prologue: the last 16 samples of chunk c0-1 go to the tail of slot 1 (lanes 62, 63)
     {
-        const uint4 s = power16_sat(load_iq16(iq, base_off - kChunkBytes + lane_off, lo, hi));
+        const uint4 s = power16_scan(load_iq16(iq, base_off - kChunkBytes + lane_off, lo, hi));
         if (lane >= 62) *wr1 = s;
     }
-    uint4 x = load(0), y = load(1);                                          // two chunks in flight
-    int64_t c = c0;
-    for (; c + 2 <= c1; c += 2) {
-        const int64_t k = c - c0;
-        const uint4 sx = power16_sat(x);
-        x = load(k + 2);                                                     // back into the registers just consumed
-        step(sx, wr0, rd0a, rd0b, c);
-        const uint4 sy = power16_sat(y);
-        y = load(k + 3);
-        step(sy, wr1, rd1a, rd1b, c + 1);
+    uint4 x = load_at(0), y = load_at(kChunkBytes);                          // two chunks in flight
+    uint32_t k = 0, off = 2 * kChunkBytes;
+    for (; k + 2 <= nk; k += 2, off += 2 * kChunkBytes) {
+        const uint4 sx = power16_scan(x);
+        x = load_at(off);
+        step(sx, wr0, rd0a, rd0b, c0 + k);
+        const uint4 sy = power16_scan(y);
+        y = load_at(off + kChunkBytes);
+        step(sy, wr1, rd1a, rd1b, c0 + k + 1);
     }
-    if (c < c1) step(power16_sat(x), wr0, rd0a, rd0b, c);                    // odd tail (last run only)
+    if (k < nk) step(power16_scan(x), wr0, rd0a, rd0b, c0 + k);             // odd tail (last run only)
+#if !defined(SCAN_ABL_NOBETA)
     if (qn) scan_beta(P, queue, qn, lane, my_slots, count);
+#endif
     if (lane == 0) P.counts[run] = count;                 // true count; demod_kernel flags count > slot_cap
 }
 

@@ -191,8 +191,9 @@ int modes_gpu_submit_host(modes_gpu *ctx, const uint8_t *iq, uint64_t nbytes,
 int  modes_gpu_host_alloc(modes_gpu *ctx, size_t nbytes, void **out);
 void modes_gpu_host_free(modes_gpu *ctx, void *p);
 
-/* Debug / test taps of the scan kernel's inputs: s = (I-127)^2 + (Q-127)^2 per
- * sample (u16) for nsamples at d_iq.  Ordering compares on s equal ordering
+/* Debug / test tap of the kernels' powers: min((I-127)^2 + (Q-127)^2, 32767) per sample (u16) for nsamples at d_iq,
+ * computed on the device both ways the kernels do (packed multiply-add: the demod kernel's table index; byte dot
+ * product: the scan kernel) - a sample on which the two differ reads 0xffff.  Ordering compares on s equal ordering
  * compares on the magnitude (the LUT is strictly monotone in s). */
 int modes_gpu_compute_power(modes_gpu *ctx, const void *d_iq, uint64_t nsamples,
                             void *d_s, void *stream);

@@ -36,6 +36,7 @@ def streams():
         "smear": synth.case_smear,
         "lowsnr": synth.case_lowsnr,
         "noise": synth.case_noise,
+        "saturated": synth.case_saturated,
     }
     cache = {}
 

@@ -50,6 +50,7 @@ CASES = {
     "smear": synth.case_smear,
     "lowsnr": synth.case_lowsnr,
     "noise": synth.case_noise,
+    "saturated": synth.case_saturated,
 }
 
 

@@ -377,6 +377,41 @@ def case_lowsnr(seed: int = 17, nblocks: int = 3) -> np.ndarray:
                          smear=(3, 4, 5, 6), flip1=10, flip2=20)[0]
 
 
+def case_saturated(seed: int = 19, nblocks: int = 2) -> np.ndarray:
+    """Clipped receiver: frames whose pulses sit at the ADC rails on a silent (127, 127) background.  Two kinds, at
+    even and odd sample offsets alike:
+      A  pulses (255,255) - the one byte pair whose power needs 16 bits (32768) - between samples of power 0: the
+         largest difference two samples can have (the packed-halves compare of the scan kernel has to survive it
+         together with a borrow from the other half);
+      B  the same pulses with the unconstrained preamble samples 1, 3, 6, 8 at (255,254) / (254,255) - power 32513,
+         the largest a non-saturated pair reaches: the preamble holds only because 32768 stays above 32513.
+    Kind C puts the rail value on samples 1 and 3 and 32513 on the pulses: no preamble (sample 1 > sample 0)."""
+    iq = np.full(nblocks * DATA_LEN, 127, dtype=np.uint8)
+    rng = np.random.default_rng(seed)
+
+    def put(sample, i, q):
+        iq[2 * sample], iq[2 * sample + 1] = i, q
+
+    pos = 1000
+    k = 0
+    while pos + 400 < nblocks * DATA_LEN // 2 - 300:
+        kind = "ABC"[k % 3]
+        frame = make_frame(17 if k % 2 else 11, _payload(seed, 14, k))
+        e = frame_envelope(frame)
+        hi = (255, 255) if kind != "C" else ((255, 254) if k % 2 else (254, 255))
+        for t in np.nonzero(e)[0]:
+            put(pos + int(t), *hi)
+        if kind == "B":
+            for t in (1, 3, 6, 8):
+                put(pos + t, *((255, 254) if (t + k) % 2 else (254, 255)))
+        if kind == "C":
+            put(pos + 1, 255, 255)
+            put(pos + 3, 255, 255)
+        pos += 331 + int(rng.integers(0, 40))            # every parity and every lane offset comes up
+        k += 1
+    return finish_stream(iq)
+
+
 def case_noise(seed: int = 18, nblocks: int = 4) -> np.ndarray:
     """BASELINE config 2 in miniature: sigma=3 noise only."""
     return finish_stream(noise_bytes(seed, 0, nblocks * DATA_LEN, 941))

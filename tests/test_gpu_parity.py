@@ -12,7 +12,7 @@ from helpers import assert_records_equal, maxfix_of, oracle_records
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["modes1", "uniform", "coarse", "edges", "edges_smear", "frames", "smear", "lowsnr", "noise"]
+CASES = ["modes1", "uniform", "coarse", "edges", "edges_smear", "frames", "smear", "lowsnr", "noise", "saturated"]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

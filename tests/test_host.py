@@ -12,7 +12,7 @@ from dump1090_amd import (HostResolver, _native as N, block_count, onlyaddr_text
                           shard_byte_range, verbose_text)
 from helpers import maxfix_of, oracle_records
 
-CASES = ["modes1", "uniform", "coarse", "edges", "edges_smear", "frames", "smear", "lowsnr"]
+CASES = ["modes1", "uniform", "coarse", "edges", "edges_smear", "frames", "smear", "lowsnr", "saturated"]
 
 
 @pytest.mark.parametrize("case", CASES)

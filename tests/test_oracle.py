@@ -20,7 +20,7 @@ import pytest
 import oracle as orc
 import synth
 
-CASES = ["modes1", "uniform", "coarse", "edges", "edges_smear", "frames", "smear", "lowsnr", "noise"]
+CASES = ["modes1", "uniform", "coarse", "edges", "edges_smear", "frames", "smear", "lowsnr", "noise", "saturated"]
 
 # BASELINE.md section 4 / SURVEY.md 4.2 (reference stdout on the padded fixture)
 PUBLISHED_MODES1 = {
