@@ -297,7 +297,12 @@ MODES_HD void modes_order8_swar(const uint32_t E[12], uint32_t r[4]) {
                        x6 = E[q + 3], x7 = O[q + 3], x8 = E[q + 4], x9 = O[q + 4];
         const uint32_t m13 = pk_max(x1, x3);
         const uint32_t big = pk_max(pk_max(m13, pk_max(x4, x5)), x6);
+#if defined(__HIP_DEVICE_COMPILE__)
+        /* three-input AND: one v_bitop3 (left to itself hipcc spends three two-input ANDs on half of the pairs) */
+        r[q] = __builtin_amdgcn_bitop3_b32(big - x0, m13 - x2, x8 - pk_min(x7, x9), 0x80) & (x6 - x9);
+#else
         r[q] = (big - x0) & (m13 - x2) & (x8 - pk_min(x7, x9)) & (x6 - x9);
+#endif
     }
 }
 /* bit i of the result <-> position i of the window */

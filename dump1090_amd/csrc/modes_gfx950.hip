@@ -584,8 +584,9 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
             }
             if (any) {
                 // rank among the pushing lanes: v_mbcnt counts the mask bits below this lane
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u));
-                uint32_t *e = queue + __umul24(qn + below, (uint32_t)kQStride);      // v_mad_u32_u24, not a 32-bit multiply
+                // (v_mbcnt adds the count to its last operand: the queue fill comes in for free)
+                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, qn));
+                uint32_t *e = queue + __umul24(slot, (uint32_t)kQStride);            // v_mad_u32_u24, not a 32-bit multiply
 #pragma unroll
                 for (int t = 0; t < 11; t++) e[t] = E[t];
 #pragma unroll
