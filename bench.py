@@ -259,7 +259,7 @@ def main():
         lo, hi = shard_byte_range(first_block, nblocks, total_bytes)
         return first_block, nblocks, lo, hi
 
-    def leg(iq, lo, calls, flags, steps, warm, cap_records, nstreams, timing):
+    def leg(iq, lo, calls, flags, steps, warm, cap_records, nstreams, timing, time_every=None):
         """K timed steps over this rank's HBM-resident shard (dump1090_amd/pipeline.py).  timing: one call in --time-every
         carries HIP timing events around its kernels (one launch stream only: the times are then the kernels' own); without:
         no events at all - pure throughput."""
@@ -281,11 +281,11 @@ def main():
             return d if timing else NoTiming(d)
         return run_steps(make, iq, lo, calls, flags, steps, warm, args.depth, world=world, rank=rank, dist=dist,
                          coll_device=coll_dev, cap_records=cap_records, streams=works,
-                         device_sync=lambda: torch.cuda.synchronize(dev), time_every=max(1, args.time_every),
+                         device_sync=lambda: torch.cuda.synchronize(dev), time_every=max(1, time_every or args.time_every),
                          resolve_threads=args.resolve_threads or max(1, min(32, (os.cpu_count() or 4) // 4)), gather=dist_on)
 
     line = {}
-    noise = noise1 = None
+    noise = noise1 = noise_s1 = None
     iq_noise = None
     if args.workload in ("all", "noise"):
         per_gpu = args.mib << 20
@@ -299,16 +299,22 @@ def main():
         torch.cuda.synchronize(dev)
         gen.close()
         calls = split_calls(first_block, nblocks, 1, lo, total)
-        # Two timed regions of K steps each over the same resident input:
-        #   throughput  --streams (2) launch streams, no events in the streams: `value`, `ms_per_step`
-        #   kernels     ONE launch stream, timing events on one call in --time-every: every kernel runs alone, so the
-        #               durations are the kernels' own -> `kernel_ms`, `roofline`; its own step time is `one_launch_stream`
-        # (--streams 1: one region serves both.)
+        # Timed regions over the same resident input:
+        #   throughput  K steps, --streams (2) launch streams, no events in the streams: `value`, `ms_per_step`
+        #   one stream  K steps, ONE launch stream, no events either: `one_launch_stream` (what a single-stream caller gets)
+        #   kernels     max(K, 96) steps on ONE launch stream, timing events on one call in 4: every kernel runs alone, so
+        #               the durations are the kernels' own -> `kernel_ms`, `roofline` (>= 24 launches in the average; each
+        #               timed call costs the stream a host round trip, so this region's step time means nothing)
+        # (--streams 1: one region serves all three; its kernel times come from one call in --time-every.)
         noflags = dict(fix=False, aggressive=False)
-        noise1 = leg(iq_noise, lo, calls, noflags, args.steps, args.settle + args.warmup, 1 << 16, 1, True)
-        noise = noise1 if args.streams <= 1 else leg(iq_noise, lo, calls, noflags, args.steps, args.settle + args.warmup, 1 << 16,
-                                                    args.streams, False)
-        for x in (noise, noise1):
+        settle = args.settle + args.warmup
+        if args.streams <= 1:
+            noise = noise1 = noise_s1 = leg(iq_noise, lo, calls, noflags, args.steps, settle, 1 << 16, 1, True)
+        else:
+            noise1 = leg(iq_noise, lo, calls, noflags, max(args.steps, 96), settle, 1 << 16, 1, True, time_every=4)
+            noise_s1 = leg(iq_noise, lo, calls, noflags, args.steps, settle, 1 << 16, 1, False)
+            noise = leg(iq_noise, lo, calls, noflags, args.steps, settle, 1 << 16, args.streams, False)
+        for x in (noise, noise1, noise_s1):
             x.update(total=total, span=hi - lo, per_gpu=per_gpu)
 
     frames = None
@@ -376,27 +382,30 @@ def main():
                    "sharding": "buffers over %d rank(s)" % world, "settle_steps": args.settle if noise is not None else 6,
                    "step": "scan + demod + order kernels, record fetch%s, host resolve + --raw formatting on a second thread; "
                            "%d detect(s) in flight; overlap=%d; completion by a host-visible word (no event in the stream), kernel timing events on "
-                           "one call in %d of the one-stream region; %d launch stream(s) in the throughput region" % (
+                           "one call in %d of the kernel-timing region only; %d launch stream(s) in the throughput region" % (
                                ", device-resident lists gathered to rank 0 over %s (counts all_gather + exact-size send/recv)" % (
                                    "RCCL" if args.backend == "nccl" else args.backend) if world > 1 else "",
-                               head["depth"], args.overlap, args.time_every, max(1, args.streams))},
+                               head["depth"], args.overlap, 4 if (noise is not None and args.streams > 1) else args.time_every,
+                               max(1, args.streams))},
         "msgs_per_s": round(head.get("msgs", 0) / head["elapsed"], 2) if rank == 0 else None,
         "preambles_per_step_rank0": int(head["last"].get("n_preambles", 0)),
         "forwarded_per_step_rank0": int(head["last"].get("n_forwarded", 0)),
         "kernel_ms": {"scan": round(kern["scan_ms"], 4), "demod": round(kern["demod_ms"], 4), "order": round(kern["order_ms"], 4),
+                      "scan_median": round(kern["scan_ms_median"], 4),
                       "timed_calls": kern["timed_calls"], "of_calls": kern["steps"] * kern["calls_per_step"],
-                      "measured_in": "a timed region of the same K steps on ONE launch stream (every kernel alone)" if kern is not head
+                      "measured_in": "a region of %d steps of the same workload on ONE launch stream, HIP events on one call in 4 (every "
+                                     "kernel alone; averages over the timed calls)" % kern["steps"] if kern is not head
                       else "the timed region"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": "scan_kernel", "algorithmic_bytes_per_launch": int(kern["call_bytes"])},
     }
-    if noise1 is not None and noise1 is not noise:
+    if noise1 is not None and noise_s1 is not noise:
         line["one_launch_stream"] = {
-            "Msamples_per_s": round(noise1["total"] // 2 * noise1["steps"] / noise1["elapsed"] / 1e6, 1),
-            "ms_per_step": round(noise1["elapsed"] / noise1["steps"] * 1e3, 4),
-            "what": "the same K steps with every call on one launch stream (scan, demod, finalize strictly in order; timing events on "
-                    "one call in %d): the region kernel_ms and roofline are measured in - there the kernel times add up to the step" % args.time_every}
+            "Msamples_per_s": round(noise_s1["total"] // 2 * noise_s1["steps"] / noise_s1["elapsed"] / 1e6, 1),
+            "ms_per_step": round(noise_s1["elapsed"] / noise_s1["steps"] * 1e3, 4),
+            "what": "the same K steps with every call on ONE launch stream (scan, demod, finalize strictly in order, no events): "
+                    "the kernel times plus the ~6 us in front of every scan kernel add up to this step"}
     if frames is not None and noise is not None:
         f = leg_summary(frames, frames["steps"], "BASELINE.json configs[%d]: %d MiB per GPU, sigma=3 noise + DF11/DF17 frames "
                         "(1 per 65,536 samples, 10 %% with a flipped bit, seam offsets), --fix" % (2 if world == 1 else 3, args.frames_mib))

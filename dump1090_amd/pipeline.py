@@ -230,6 +230,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     t0 = None
     ncall = 0
     first_timed_call = warm * len(calls)
+    timed_phase = (min(time_every, steps * len(calls)) - 1) % time_every
     for step in range(warm + steps):
         if step == warm:
             for k in list(order):
@@ -258,8 +259,10 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                 advance(order[0], 2)
             free[k].wait()
             stream = works[ncall % len(works)]
-            # the first call of the timed region and every time_every-th after it carry timing events (none while warming up)
-            timed_call = timed and (ncall - first_timed_call) % time_every == 0 and hasattr(demods[k], "set_timing")
+            # the LAST call of every group of time_every calls of the timed region carries timing events (of a region shorter
+            # than that: its last call; none while warming up) - never the first call after the flush, which starts on an
+            # idle chip and runs up to 30 % longer
+            timed_call = timed and (ncall - first_timed_call) % time_every == timed_phase and hasattr(demods[k], "set_timing")
             if hasattr(demods[k], "set_timing"):
                 demods[k].set_timing(timed_call)
             # With several launch streams the kernels of consecutive calls overlap (the next scan fills the gaps and the
@@ -305,6 +308,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         elapsed = float(t.item())
     mean = lambda v: float(np.mean(v)) if v else 0.0
     out = {"elapsed": elapsed, "scan_ms": mean(scan_ms), "demod_ms": mean(demod_ms), "order_ms": mean(order_ms),
+           "scan_ms_median": float(np.median(scan_ms)) if scan_ms else 0.0,
            "timed_calls": len(scan_ms), "last": dict(last), "depth": depth, "calls_per_step": len(calls),
            "call_bytes": float(np.mean([chi - clo for _, _, clo, chi in calls])), "steps": steps}
     if rank == 0:
