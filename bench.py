@@ -189,7 +189,8 @@ def main():
     ap.add_argument("--run-chunks", type=int, default=0)
     ap.add_argument("--scan-variant", type=int, default=0, help="0 = production scan kernel, 1 = fused single-pass scan")
     ap.add_argument("--demod-variant", type=int, default=0, help="0 = production demod kernel, 1 = 4-wave / small-table kernel that fits next to the scan")
-    ap.add_argument("--depth", type=int, default=4, help="detect calls in flight (contexts used in rotation)")
+    ap.add_argument("--depth", type=int, default=0, help="detect calls in flight (contexts used in rotation); default 4, and 6 when "
+                                                        "the record lists are gathered (N > 1): that pipeline has two more stages")
     ap.add_argument("--settle", type=int, default=80,
                     help="extra untimed steps before the W warmup steps: the chip's power management needs ~40 "
                          "back-to-back steps (13 ms) to settle - the scan kernel runs 0.22, 0.27, 0.21 ms at steps "
@@ -238,6 +239,8 @@ def main():
     dev = torch.device("cuda", local)
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")     # where the gathered bytes travel
     dist_on = world > 1 or args.force_gather
+    if args.depth <= 0:
+        args.depth = 6 if dist_on else 4
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
@@ -355,7 +358,7 @@ def main():
         d = {"workload": name, "Msamples_per_s": round(samples_per_step * steps / el / 1e6, 1),
              "ms_per_step": round(el / steps * 1e3, 4),
              "kernel_ms": {"scan": round(leg["scan_ms"], 4), "demod": round(leg["demod_ms"], 4), "order": round(leg["order_ms"], 4)},
-             "records_per_step_rank0": int(leg["last"].get("n_records", 0))}
+             "records_per_step_rank0": int(leg["last"].get("n_records", 0)), "host_ms_per_call": leg.get("host_ms_per_call")}
         if rank == 0:
             d["msgs_per_s"] = round(leg["msgs"] / el, 1)
             d["msgs_per_step"] = int(leg["lines"])
@@ -388,6 +391,7 @@ def main():
                                head["depth"], args.overlap, 4 if (noise is not None and args.streams > 1) else args.time_every,
                                max(1, args.streams))},
         "msgs_per_s": round(head.get("msgs", 0) / head["elapsed"], 2) if rank == 0 else None,
+        "host_ms_per_call": head.get("host_ms_per_call"),          # rank 0's host thread, by phase of the step loop
         "preambles_per_step_rank0": int(head["last"].get("n_preambles", 0)),
         "forwarded_per_step_rank0": int(head["last"].get("n_forwarded", 0)),
         "kernel_ms": {"scan": round(kern["scan_ms"], 4), "demod": round(kern["demod_ms"], 4), "order": round(kern["order_ms"], 4),

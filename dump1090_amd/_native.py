@@ -39,6 +39,7 @@ class GpuConfig(C.Structure):
 
 
 GPU_NO_RETRY = 1
+GPU_ORDER_IN_STREAM = 2
 
 
 class Attempt(C.Structure):

@@ -423,6 +423,10 @@ struct DemodParams {
 #define SCAN_AUX 18
 #endif
 constexpr int kScanAux = SCAN_AUX;
+#ifndef DEMOD_AUX
+#define DEMOD_AUX 0
+#endif
+constexpr int kDemodAux = DEMOD_AUX;   // the demod kernel's sample loads (candidates only: ~150 MB per GiB)
 constexpr int kQCap = 64;             // queue entries per wavefront: one beta pass
 constexpr int kQStride = 17;          // dwords per entry: 11 window + 4 results + 1 position + 1 pad (odd: no bank conflicts)
 constexpr int kScan2Waves = 2;
@@ -852,7 +856,7 @@ __device__ __forceinline__ bool preamble_eval(const uint32_t (&idx)[8], const Lu
 }
 template <class Lut>
 __device__ __forceinline__ bool preamble_at_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const Lut lut) {
-    const u32x4 wa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0), wb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16u, 0, 0);
+    const u32x4 wa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, kDemodAux), wb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16u, 0, kDemodAux);
     const uint32_t w[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
     if constexpr (!Lut::kHybrid) {                                           // index and look up dword by dword
         int m[16];
@@ -888,9 +892,9 @@ constexpr int kGateLanes = 4;                   // lanes per preamble in the gat
 __device__ __forceinline__ void half_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, int t, u32x4 (&w)[4]) {
     const uint32_t o = voff + 16u * (uint32_t)t;
 #pragma unroll
-    for (int i = 0; i < 3; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 64u * i, 0, 0);
+    for (int i = 0; i < 3; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 64u * i, 0, kDemodAux);
     w[3] = u32x4{0, 0, 0, 0};                                                // four equal bytes: a pair with |lo - hi| = 0
-    if (t < 2) w[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 192u, 0, 0);
+    if (t < 2) w[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 192u, 0, kDemodAux);
 }
 // Returns this lane's part of the sum.  *first: flags of the lane's first four pairs (pairs 4t .. 4t+3 of
 // the 56), bit k = |lo - hi| < 256, bit 4 + k = lo > hi, bit 8 = (lo == hi) of its first pair.
@@ -2017,11 +2021,11 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
         hipExtLaunchKernelGGL((demod_kernel<8, LutFull>), dim3(ctx->demod_grid), dim3(512), 0, st2, ev(2), ev(3), 0, dp);
     fp.ntotals = ctx->demod_grid;
     hipExtLaunchKernelGGL(finalize_kernel, dim3(1), dim3(512), 0, st2, nullptr, nullptr, 0, fp);
-    // Lists of up to direct_records records are put in order by finalize_kernel.  order_kernel only
-    // follows in the stream when the caller consumes the list on the device (modes_gpu_set_output: it must be complete
-    // in stream order whatever its length); otherwise modes_gpu_fetch launches it when a list turns out to be long.
+    // Lists of up to direct_records records are put in order by finalize_kernel.  order_kernel only follows in the
+    // stream when the caller consumes the list on the device in stream order (MODES_GPU_ORDER_IN_STREAM); otherwise
+    // modes_gpu_fetch / modes_gpu_fetch_device launch it when a list turns out to be long.
     const bool tail = ctx->cfg.keep_candidates != 0;                       // prefix_kernel follows
-    ctx->order_launched = ctx->d_user_records != nullptr;
+    ctx->order_launched = ctx->d_user_records != nullptr && (ctx->cfg.flags & MODES_GPU_ORDER_IN_STREAM) != 0;
     ctx->order_params = op;
     if (ctx->order_launched) {
         if (ctx->cfg.overlap == 2 && st != ctx->own_stream) {              // only the order kernel leaves the caller's stream

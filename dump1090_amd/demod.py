@@ -247,12 +247,13 @@ class Demodulator:
     def __init__(self, device: int = 0, fix: bool = True, aggressive: bool = False, check_crc: bool = True,
                  keep_candidates: bool = False, run_chunks: int = 0, slot_cap: int = 0, max_records: int = 0,
                  scan_variant: int = 0, overlap: int = 0, no_retry: bool = False, direct_records: int = 0,
-                 demod_variant: int = 0):
+                 demod_variant: int = 0, order_in_stream: bool = False):
         self._lib = N.gpu_lib()
         self.flags = dict(fix=fix, aggressive=aggressive, check_crc=check_crc)
         self.device = device
         cfg = N.GpuConfig(device, int(fix), int(aggressive), int(keep_candidates), run_chunks, slot_cap, max_records,
-                          scan_variant, int(overlap), N.GPU_NO_RETRY if no_retry else 0, direct_records, demod_variant)
+                          scan_variant, int(overlap), (N.GPU_NO_RETRY if no_retry else 0) | (N.GPU_ORDER_IN_STREAM if order_in_stream else 0),
+                          direct_records, demod_variant)
         h = C.c_void_p()
         rc = self._lib.modes_gpu_create(C.byref(cfg), C.byref(h))
         if rc != N.MODES_OK:

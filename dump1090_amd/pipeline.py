@@ -114,15 +114,20 @@ def split_calls(first_block, nblocks, ncalls, lo, total_bytes):
 
 def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, rank=0, dist=None, coll_device=None,
               cap_records=1 << 16, streams=(None,), device_sync=lambda: None, time_every=8, resolve_threads=1,
-              gather=None, oplog=None):
+              gather=None, oplog=None, lag=None):
     """`warm` untimed + `steps` timed steps of the hot path over this rank's shard `iq` (stream bytes from `lo`;
     a CUDA uint8 tensor - anything sliceable that make_demod()'s detect accepts); a step is the sequence `calls`
     of GPU calls (split_calls).  `depth` contexts (make_demod() each) are used in rotation, so that the GPU always
     has the next call queued while the host fetches, gathers and resolves the previous ones:
 
-        call i       detect queued on streams[i mod len]; N > 1: all_gather of the record counts queued behind it
-        call i - 1   N > 1: counts on the host -> exact-size transfers of the device-resident lists to rank 0 queued
-        call i - 2   records on rank 0's host -> resolver thread (sequential resolve + --raw formatting)
+        call i           detect queued on streams[i mod len] (three kernels, nothing else in that stream)
+        call i - lag     N > 1: its kernels are done (a word in pinned memory) -> all_gather of the record counts queued
+        call i - lag - 1 N > 1: counts on the host -> exact-size transfers of the device-resident lists to rank 0 queued
+        call i - lag - 2 records on rank 0's host -> resolver thread (sequential resolve + --raw formatting)
+                         (N = 1: call i - 2 goes straight to the resolver)
+    lag (default: the number of launch streams) = the calls that stay queued on the GPU while the host waits for an older
+    one: with two launch streams two calls run concurrently, and the host must not wait for the older of them before
+    the next one is queued.
 
     Kernel times cost idle GPU time (events around the kernels: ~9 us per boundary), so only one call in `time_every`
     carries them (modes_gpu_set_timing); the averages returned are over those calls of the timed steps.
@@ -134,8 +139,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     device with RCCL; "cpu" with gloo: the lists are fetched to the host first).  Returns a dict of measurements
     (rank 0: also the --raw listing of the last step).
 
-    Every rank issues its communication calls in the SAME order - per call n: detect(n), count all_gather(n), list
-    transfers(n - 1); at a flush: the transfers of the newest call - whatever its resolver thread is doing: RCCL
+    Every rank issues its communication calls in the SAME order - per call n: detect(n), count all_gather(n - 1), list
+    transfers(n - 2); at a flush: what is left of the newest calls - whatever its resolver thread is doing: RCCL
     executes a communicator's operations in issue order, so a rank that queued "transfers(n - 1), all_gather(n)" against
     peers that queued "all_gather(n), transfers(n - 1)" would deadlock.  oplog (a list): receives ("detect" | "counts" |
     "records", call number) as they are issued (tests/test_pipeline.py compares the ranks' logs)."""
@@ -159,11 +164,17 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             for d, s in zip(demods, slots):
                 d.set_output(s.own_records, s.count)
         if on_gpu:
-            # the exchanges of a call are queued on a stream of their own, behind the call's results (with overlap the
-            # detect's launch stream does not wait for the demod and order kernels)
-            comms = [torch.cuda.Stream(device=coll_device) for _ in range(depth)]
+            # the exchanges of a call are queued on a stream of their own, after the host has seen the call's results
+            # complete: no event, no order kernel in the detect's stream (they cost it ~11 us per call)
+            # ONE stream for all calls: HIP multiplexes its streams onto a few hardware queues, and a communication stream
+            # that lands in the queue of a launch stream puts its copies between the scans (measured with one stream per
+            # context: +60 us per step on two launch streams)
+            comms = [torch.cuda.Stream(device=coll_device)] * depth
+    # (the resolver may keep a step's gather buffers until the step's last call arrives only if that call's transfers are
+    # queued before the buffers are needed again: see the wait below)
+    lag = max(1, len(works) if lag is None else int(lag))
     resolver = Resolver(dict(fix=flags["fix"], aggressive=flags["aggressive"], check_crc=True), resolve_threads,
-                        hold_views=depth > len(calls)) if rank == 0 else None
+                        hold_views=depth >= len(calls) + (1 + lag if dist_on else 1)) if rank == 0 else None
     free = [threading.Event() for _ in range(depth)]          # the resolver is done with context k's record buffer
     for e in free:
         e.set()
@@ -176,6 +187,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
 
     scan_ms, demod_ms, order_ms = [], [], []
     last = {}
+    host = dict(wait_kernels=0.0, queue_counts=0.0, queue_records=0.0, wait_records=0.0, detect=0.0, wait_free=0.0)   # host seconds by phase
 
     def note(info, timed):
         last.update({k: v for k, v in info.items() if not k.endswith("_ms")})
@@ -184,26 +196,38 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             demod_ms.append(info["demod_ms"])
             order_ms.append(info["order_ms"])
 
-    # phase 1 of a call in flight (N > 1): its counts are on the host -> queue the transfers of the lists
-    def phase_records(k, stream, timed, n):
+    # phase 1 of a call in flight (N > 1): wait for its kernels (the host-visible word; a long list is put in order here),
+    # then queue the all_gather of the record counts - on the communication stream, with no event in the detect's stream
+    def phase_counts(k, timed, n):
         d, s = demods[k], slots[k]
+        t_a = time.perf_counter()
         if inplace:
             _, info = d.fetch_device()
         else:                                                   # --backend gloo smoke mode: the lists travel as CPU tensors
             recs, _, info = d.fetch()
             s.own_records[: recs.size * 64] = torch.from_numpy(recs.view(np.uint8).reshape(-1))
             s.count[0] = recs.size
-            log(("counts", n))
-            s.exchange_counts()
-        log(("records", n))
-        s.exchange_records(stream=stream)
+        t_b = time.perf_counter()
+        log(("counts", n))
+        s.exchange_counts(stream=comms[k])
+        host["wait_kernels"] += t_b - t_a
+        host["queue_counts"] += time.perf_counter() - t_b
         note(info, timed)
 
-    # phase 2: the records are on rank 0's host -> resolver thread
+    # phase 2 (N > 1): its counts are on the host -> queue the transfers of the lists
+    def phase_records(k, n):
+        log(("records", n))
+        t_a = time.perf_counter()
+        slots[k].exchange_records(stream=comms[k])
+        host["queue_records"] += time.perf_counter() - t_a
+
+    # last phase: the records are on rank 0's host -> resolver thread
     def phase_resolve(k, tag, timed):
         counts = None
         if dist_on:
+            t_a = time.perf_counter()
             recs = slots[k].wait()
+            host["wait_records"] += time.perf_counter() - t_a
             counts = slots[k].counts
         else:
             recs, _, info = demods[k].fetch(copy=False)         # a view of the context's pinned list
@@ -212,18 +236,23 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             free[k].clear()
             resolver.submit(recs, counts, tag[0], tag[1], timed, free[k])
 
-    stage = {}                                                  # context -> [phase, stream, timed, (first call, last call of its step), call number]
+    stage = {}                                                  # context -> [phase, timed, (first call, last call of its step), call number]
     order = []                                                  # contexts with a call in flight, oldest first
+    QUEUED = 2 if dist_on else 0                                # phase in which nothing is left to queue but the hand-over
 
     def advance(k, upto):
+        """upto: 1 = counts queued, 2 = transfers queued, 3 = handed to the resolver"""
         st = stage.get(k)
         if st is None:
             return
-        if st[0] == 0 and dist_on and upto >= 1:
-            phase_records(k, st[1], st[2], st[4])
+        if dist_on and st[0] == 0 and upto >= 1:
+            phase_counts(k, st[1], st[3])
             st[0] = 1
-        if upto >= 2:
-            phase_resolve(k, st[3], st[2])
+        if dist_on and st[0] == 1 and upto >= 2:
+            phase_records(k, st[3])
+            st[0] = 2
+        if upto >= 3:
+            phase_resolve(k, st[2], st[1])
             stage.pop(k)
             order.remove(k)
 
@@ -234,7 +263,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     for step in range(warm + steps):
         if step == warm:
             for k in list(order):
-                advance(k, 2)
+                advance(k, 3)
             for e in free:
                 e.wait()
             if resolver is not None:
@@ -246,18 +275,20 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             k = ncall % depth
             if k in stage:                                      # its previous call must be complete first
                 for kk in list(order):
-                    advance(kk, 2)
+                    advance(kk, 3)
                     if kk == k:
                         break
             # ... and resolved: the record buffer is reused.  (Rank 0 with several calls per step: the resolver releases a
             # step's buffers together, when it has the step's last call - hand it everything that is still in flight.)
-            # Only calls whose transfers are already queued: the newest call's are queued at ITS point of the schedule
-            # (below, behind the next call's all_gather) on every rank, never from this rank-0-only wait.  The buffer
-            # waited for never depends on the newest call: the resolver holds a step's buffers only when depth >
-            # len(calls), and then the step that last used context k ended at least two calls ago.
-            while not free[k].is_set() and order and not (dist_on and stage[order[0]][0] == 0):
-                advance(order[0], 2)
+            # Only calls that have nothing left to queue: the communication calls of the newer ones are issued at THEIR
+            # point of the schedule (below) on every rank, never from this rank-0-only wait.  The buffer waited for never
+            # depends on those: the resolver holds a step's buffers only when depth >= len(calls) + 1 + lag, and then the
+            # step that last used context k ended at least 2 + lag calls ago - its transfers are queued.
+            while not free[k].is_set() and order and stage[order[0]][0] >= QUEUED:
+                advance(order[0], 3)
+            t_a = time.perf_counter()
             free[k].wait()
+            host["wait_free"] += time.perf_counter() - t_a
             stream = works[ncall % len(works)]
             # the LAST call of every group of time_every calls of the timed region carries timing events (of a region shorter
             # than that: its last call; none while warming up) - never the first call after the flush, which starts on an
@@ -275,27 +306,28 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                     if w is not stream:
                         stream.wait_stream(w)
             log(("detect", ncall))
+            t_a = time.perf_counter()
             demods[k].detect(iq[clo - lo: chi - lo], stream_byte0=clo, first_block=b0, nblocks=nb, stream=stream)
+            host["detect"] += time.perf_counter() - t_a
             if alone:
                 for w in works:
                     if w is not stream:
                         demods[k].stream_wait(w)
-            if dist_on and inplace:
-                if on_gpu:
-                    demods[k].stream_wait(comms[k])
-                    stream = comms[k]
-                log(("counts", ncall))
-                slots[k].exchange_counts(stream=comms[k])
-            stage[k] = [0, stream, timed, (ci == 0, ci == len(calls) - 1), ncall]
+            stage[k] = [0, timed, (ci == 0, ci == len(calls) - 1), ncall]
             order.append(k)
             ncall += 1
-            # keep the older calls moving: the previous one gets its transfers queued, the one before is handed over
-            if len(order) >= 2:
-                advance(order[-2], 1)
-            if len(order) >= 3:
-                advance(order[0], 2)
+            # keep the older calls moving - the same communication calls at the same point on every rank
+            if dist_on:
+                if len(order) >= 1 + lag:
+                    advance(order[-1 - lag], 1)
+                if len(order) >= 2 + lag:
+                    advance(order[-2 - lag], 2)
+                if len(order) >= 3 + lag:
+                    advance(order[0], 3)
+            elif len(order) >= 3:
+                advance(order[0], 3)
     for k in list(order):
-        advance(k, 2)
+        advance(k, 3)
     for e in free:
         e.wait()
     if resolver is not None:
@@ -310,6 +342,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     out = {"elapsed": elapsed, "scan_ms": mean(scan_ms), "demod_ms": mean(demod_ms), "order_ms": mean(order_ms),
            "scan_ms_median": float(np.median(scan_ms)) if scan_ms else 0.0,
            "timed_calls": len(scan_ms), "last": dict(last), "depth": depth, "calls_per_step": len(calls),
+           "host_ms_per_call": {k: round(v / max(1, ncall) * 1e3, 4) for k, v in host.items()},
            "call_bytes": float(np.mean([chi - clo for _, _, clo, chi in calls])), "steps": steps}
     if rank == 0:
         if resolver.error is not None:

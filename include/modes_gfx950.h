@@ -75,6 +75,11 @@ typedef struct {
 /* modes_gpu_config.flags */
 #define MODES_GPU_NO_RETRY 1u  /* never repeat a call inside modes_gpu_fetch(): a list overflow returns
                                   MODES_ERR_OVERFLOW (the lists are enlarged; the caller resubmits)      */
+#define MODES_GPU_ORDER_IN_STREAM 2u  /* with modes_gpu_set_output: the kernel that puts a LONG list (more than
+                                  direct_records) in order follows the detect in its stream, and so does an event -
+                                  ~11 us of the stream per call - so that a device consumer queued behind the detect
+                                  sees the complete list without a host round trip.  Default: that kernel runs
+                                  inside modes_gpu_fetch_device() when a list turns out to be long */
 
 /* One demodulation attempt at a preamble position: dump1090.c:1666-1726 (bit
  * slicing, packing, noise gate) plus the syndrome / repair lookup of
@@ -168,9 +173,11 @@ int modes_gpu_set_timing(modes_gpu *ctx, int on);
 
 /* Caller-owned device output: the ordered list is written to d_records (16-byte aligned, room for
  * `capacity` records; more records than that are MODES_ERR_OVERFLOW at fetch) and, if d_count is not
- * NULL, the number of records of the call to the 8-byte device word d_count - both by the kernels of
- * modes_gpu_detect, in stream order, so that a collective queued behind the detect can consume them without
- * a host round trip.  (NULL, 0, NULL) returns to the context's own list (which keeps the capacity it has). */
+ * NULL, the number of records of the call to the 8-byte device word d_count.  The count and a list of up to
+ * direct_records records are written by the kernels of modes_gpu_detect, in stream order; a longer list is complete
+ * when modes_gpu_fetch_device() has returned (or in stream order too, with MODES_GPU_ORDER_IN_STREAM) - a host that
+ * gathers the lists over RCCL queues its collectives after that call, with no event in the detect's stream.
+ * (NULL, 0, NULL) returns to the context's own list (which keeps the capacity it has). */
 int modes_gpu_set_output(modes_gpu *ctx, void *d_records, uint64_t capacity, void *d_count);
 
 /* Host-buffer convenience used by the C host: stages `nbytes` stream bytes that

@@ -71,15 +71,25 @@ def test_device_output_and_direct_host_path_agree(torch_cuda, streams):
         recs, _, info = d.fetch()
         assert_records_equal(recs, want, ("direct_records", direct))
         d.close()
-    d = Demodulator()
     out = torch.zeros(8192 * 64, dtype=torch.uint8, device="cuda:0")
     cnt = torch.zeros(1, dtype=torch.int64, device="cuda:0")
-    d.set_output(out, cnt)
-    d.detect(iq)
-    n, info = d.fetch_device()
-    assert n == want.size and int(cnt.item()) == n
-    got = out[: n * 64].cpu().numpy().view(RECORD_DTYPE)
-    assert_records_equal(got, want, "device list")
+    # short list: in order with the kernels; "long" list (direct_records = 1): put in order inside fetch_device, or
+    # by a kernel that follows the detect in its stream (MODES_GPU_ORDER_IN_STREAM: complete in stream order)
+    for direct, eager in ((0, False), (1, False), (1, True)):
+        d = Demodulator(direct_records=direct, order_in_stream=eager)
+        out.zero_()
+        d.set_output(out, cnt)
+        d.detect(iq)
+        if eager:
+            torch.cuda.synchronize()                     # no fetch yet: the list is already complete
+            got = out[: want.size * 64].cpu().numpy().view(RECORD_DTYPE)
+            assert_records_equal(got, want, "device list in stream order")
+        n, info = d.fetch_device()
+        assert n == want.size and int(cnt.item()) == n
+        got = out[: n * 64].cpu().numpy().view(RECORD_DTYPE)
+        assert_records_equal(got, want, ("device list", direct, eager))
+        d.close()
+    d = Demodulator()
     small = torch.zeros(64 * 64, dtype=torch.uint8, device="cuda:0")      # 64 records of room for 559
     d.set_output(small, cnt)
     d.detect(iq)

@@ -63,7 +63,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_resolver=0.0):
+def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_resolver=0.0, lag=None):
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -94,20 +94,17 @@ def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_res
         pipeline.Resolver._resolve = lambda self, recs, timed: (time.sleep(slow_resolver), fast(self, recs, timed))[1]
     oplog = []
     out = run_steps(make, data[lo:hi], lo, calls, dict(fix=True, aggressive=False), steps=2, warm=1, depth=depth,
-                    world=world, rank=rank, dist=dist, coll_device="cpu", cap_records=4096, oplog=oplog)
+                    world=world, rank=rank, dist=dist, coll_device="cpu", cap_records=4096, oplog=oplog, lag=lag)
     assert sum(d.calls for d in made) == 3 * ncalls and out["calls_per_step"] == ncalls
     if world > 1:
         # every rank issued its communication calls in the same order (RCCL executes them in issue order: a rank that
-        # deviates deadlocks the job) - per call n: detect(n), counts(n), records(n - 1)
+        # deviates deadlocks the job) - per call n: detect(n), counts(n - 1), records(n - 2)
         logs = [None] * world
         dist.all_gather_object(logs, oplog)
         assert all(l == logs[0] for l in logs), "ranks issued their communication calls in different orders"
-        if inplace:
-            at = {op: i for i, op in enumerate(oplog)}
-            for n in range(1, 3 * ncalls):
-                assert at[("detect", n)] < at[("counts", n)]
-                if ("records", n - 1) in at and at[("records", n - 1)] > at[("detect", n)]:
-                    assert at[("counts", n)] < at[("records", n - 1)]
+        at = {op: i for i, op in enumerate(oplog)}
+        for n in range(3 * ncalls):
+            assert at[("detect", n)] < at[("counts", n)] < at[("records", n)]
     if rank == 0:
         with open(os.path.join(outdir, "out.txt"), "wb") as f:
             f.write(out["listing"])
@@ -141,10 +138,13 @@ def test_two_ranks_gather_over_gloo(tmp_path, golden, case, ncalls, depth):
     assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
 
 
-@pytest.mark.parametrize("case,ncalls,depth,slow", [("edges", 1, 3, 0.05), ("edges", 2, 3, 0.05), ("edges", 3, 4, 0.03), ("frames", 2, 2, 0.03),
-                                                     ("edges", 3, 2, 0.0)])
-def test_two_ranks_same_communication_order(tmp_path, golden, case, ncalls, depth, slow):
-    """The schedule of the RCCL path (lists written in place, counts all_gather behind the detect) on gloo, with rank 0's
-    resolver slower than its detector: the ranks' sequences of communication calls must not diverge."""
-    _spawn2((2, _free_port(), case, ncalls, depth, str(tmp_path), True, slow))
+@pytest.mark.parametrize("case,ncalls,depth,slow,lag", [("edges", 1, 3, 0.05, 1), ("edges", 2, 4, 0.05, 1), ("edges", 3, 4, 0.03, 1),
+                                                         ("frames", 2, 2, 0.03, 1), ("edges", 3, 2, 0.0, 1),
+                                                         ("edges", 2, 6, 0.04, 2), ("edges", 2, 5, 0.04, 2), ("edges", 3, 4, 0.03, 2),
+                                                         ("frames", 1, 6, 0.03, 3)])
+def test_two_ranks_same_communication_order(tmp_path, golden, case, ncalls, depth, slow, lag):
+    """The schedule of the RCCL path (lists written in place; per call n: detect(n), counts(n - lag), transfers(n - lag - 1))
+    on gloo, with rank 0's resolver slower than its detector, buffers held by the resolver (depth >= calls + 1 + lag) or
+    copied: the ranks' sequences of communication calls must not diverge."""
+    _spawn2((2, _free_port(), case, ncalls, depth, str(tmp_path), True, slow, lag))
     assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
