@@ -184,7 +184,8 @@ def main():
                          "fields); all (default): both, frames as a secondary object")
     ap.add_argument("--mib", type=int, default=1024, help="MiB of I/Q per GPU of the noise leg (default: the 1 GiB workload)")
     ap.add_argument("--frames-mib", type=int, default=8192, help="MiB of I/Q per GPU of the frames leg (default: 8 GiB)")
-    ap.add_argument("--frames-steps", type=int, default=6)
+    ap.add_argument("--frames-steps", type=int, default=40,
+                    help="timed steps of the frames leg (8 GiB each: with 6 the fill and drain of the pipeline were a fifth of the time)")
     ap.add_argument("--cpu-mib", type=int, default=1024, help="MiB of the workload timed on the CPU baseline")
     ap.add_argument("--run-chunks", type=int, default=0)
     ap.add_argument("--scan-variant", type=int, default=0, help="0 = production scan kernel, 1 = fused single-pass scan")
