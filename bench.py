@@ -177,8 +177,8 @@ def check_listing(listing: bytes, expected: list[str]):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="all", choices=("all", "noise", "frames"),
                     help="noise: the headline leg only; frames: the configs[2]/[3] leg only (its numbers then fill the headline "
                          "fields); all (default): both, frames as a secondary object")
