@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-GPU_LIB = os.path.join(PKG_DIR, "libmodes_gfx950.so")
+GPU_LIB = os.environ.get("MODES_GPU_LIB") or os.path.join(PKG_DIR, "libmodes_gfx950.so")      # (MODES_GPU_LIB: another build of the library - tools/ab_scan.py, experiments)
 HOST_LIB = os.path.join(PKG_DIR, "libmodes_host.so")
 
 DATA_LEN = 262144
