@@ -119,7 +119,7 @@ GPU_SYMBOLS = ("modes_gpu_create", "modes_gpu_destroy", "modes_gpu_last_error", 
                "modes_gpu_host_alloc", "modes_gpu_host_free", "modes_gpu_compute_power", "modes_gpu_debug_tables",
                "modes_gpu_synth_noise", "modes_gpu_fill", "modes_gpu_abi_version")
 HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_set_time", "modes_host_resolve", "modes_host_resolve_to_array",
-                "modes_host_resolve_raw", "modes_host_resolve_raw_mt", "modes_host_wants",
+                "modes_host_resolve_raw", "modes_host_resolve_raw_mt", "modes_host_resolve_raw_mtv", "modes_host_wants",
                 "modes_host_get_stats", "modes_host_decode", "modes_host_decode_frame", "modes_format_raw", "modes_format_raw_net",
                 "modes_format_onlyaddr", "modes_format_verbose", "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
                 "modes_block_count",
@@ -194,6 +194,9 @@ def host_lib():
         L.modes_host_resolve_raw.restype = C.c_uint64
         L.modes_host_resolve_raw_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]
         L.modes_host_resolve_raw_mt.restype = C.c_uint64
+        L.modes_host_resolve_raw_mtv.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_uint64,
+                                                 C.POINTER(C.c_uint64), C.c_int]
+        L.modes_host_resolve_raw_mtv.restype = C.c_uint64
         L.modes_host_wants.argtypes = [C.c_void_p, C.POINTER(ModesMessage)]
         L.modes_host_get_stats.argtypes = [C.c_void_p, C.POINTER(HostStats)]
         L.modes_host_get_stats.restype = None

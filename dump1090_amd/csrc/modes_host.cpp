@@ -487,11 +487,15 @@ private:
 };
 
 struct Piece {
-    uint64_t lo = 0, hi = 0;
+    const modes_record *recs = nullptr;   // the segment the piece lies in
+    uint64_t lo = 0, hi = 0;              // records [lo, hi) of it: whole buffers
     modes_host host;                 // private copy: config, clock, whitelist (guess, then the piece's own writes), stats of the piece
     IcaoLog log;
     std::string text;
     uint64_t msgs = 0;
+    // guess: what the piece's clean DF11/17/18 frames would write to the whitelist (last write per slot)
+    uint32_t guess_addr[kIcaoSlots];
+    bool guess_set[kIcaoSlots];
 };
 struct TextSink {
     modes_host *h;
@@ -506,7 +510,26 @@ void text_sink(const struct modesMessage *mm, uint32_t, uint32_t, void *user) {
     s->text->append(line, (size_t)n);
     s->msgs++;
 }
-void run_piece(Piece &p, const modes_record *recs) {
+// The addresses a piece's clean DF11/17/18 frames put on the whitelist (dump1090.c:1198: crcok without repair).  Which of
+// them really get decoded depends on skip windows: a guess, checked when the pieces are confirmed.
+void guess_piece(Piece &p, bool aggressive) {
+    memset(p.guess_set, 0, sizeof p.guess_set);
+    for (uint64_t i = p.lo; i < p.hi; i++) {
+        for (int a = 0; a < 2; a++) {
+            const modes_attempt &at = p.recs[i].att[a];
+            const int df = at.msg[0] >> 3;
+            if (at.gate_ok && at.syndrome == 0 && (df == 11 || df == 17 || df == 18) && (at.errors == 0 || (aggressive && at.errors < 3))) {
+                const uint32_t addr = ((uint32_t)at.msg[1] << 16) | ((uint32_t)at.msg[2] << 8) | at.msg[3];
+                const uint32_t sl = icao_slot(addr);
+                p.guess_addr[sl] = addr;
+                p.guess_set[sl] = true;
+                break;                                                            // a good first attempt ends the position
+            }
+        }
+    }
+}
+void run_piece(Piece &p) {
+    const modes_record *recs = p.recs;
     p.log = IcaoLog{};
     p.text.clear();
     p.host.st = modes_host_stats{};
@@ -521,52 +544,78 @@ void run_piece(Piece &p, const modes_record *recs) {
 
 uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint64_t nrecs, char *out, uint64_t cap,
                                    uint64_t *nbytes, int threads) {
+    return modes_host_resolve_raw_mtv(h, &recs, &nrecs, 1, out, cap, nbytes, threads);
+}
+
+uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
+                                    char *out, uint64_t cap, uint64_t *nbytes, int threads) {
+    uint64_t nrecs = 0;
+    for (uint32_t g = 0; g < nsegs; g++) nrecs += seg_nrecs[g];
     // threads < 0: exactly -threads pieces however short the list (tests); otherwise at least 2048 records per thread
     const uint64_t kMinPiece = threads < 0 ? 1 : 2048;
     int T = threads < 0 ? -threads : threads;
     T = T < 1 ? 1 : (T > 64 ? 64 : T);
     if ((uint64_t)T > nrecs / kMinPiece) T = (int)(nrecs / kMinPiece);
-    if (T <= 1) return modes_host_resolve_raw(h, recs, nrecs, nullptr, 0, out, cap, nbytes);
-    // pieces: equal shares of the records, cut where the buffer changes (the skip window resets there)
+    if (T <= 1) {                                                                 // one thread: segment after segment
+        uint64_t msgs = 0, total = 0;
+        for (uint32_t g = 0; g < nsegs; g++) {
+            uint64_t nb = 0;
+            msgs += modes_host_resolve_raw(h, segs[g], seg_nrecs[g], nullptr, 0, out ? out + total : nullptr, cap > total ? cap - total : 0, &nb);
+            total += nb;
+        }
+        if (nbytes) *nbytes = total;
+        return msgs;
+    }
+    // pieces: about nrecs / T records each, inside one segment, cut where the buffer changes (the skip window resets
+    // there; a segment ends with a whole buffer)
     std::vector<Piece> pieces;
-    uint64_t lo = 0;
-    for (int t = 0; t < T && lo < nrecs; t++) {
-        uint64_t hi = t == T - 1 ? nrecs : nrecs * (uint64_t)(t + 1) / (uint64_t)T;
-        if (hi < lo) hi = lo;
-        while (hi < nrecs && hi > 0 && recs[hi].block == recs[hi - 1].block) hi++;
-        if (hi == lo) continue;
-        pieces.emplace_back();
-        pieces.back().lo = lo;
-        pieces.back().hi = hi;
-        lo = hi;
+    pieces.reserve((size_t)T + nsegs);
+    const uint64_t share = (nrecs + (uint64_t)T - 1) / (uint64_t)T;
+    for (uint32_t g = 0; g < nsegs; g++) {
+        const modes_record *recs = segs[g];
+        const uint64_t n = seg_nrecs[g];
+        uint64_t lo = 0;
+        while (lo < n) {
+            uint64_t hi = lo + share < n ? lo + share : n;
+            while (hi < n && recs[hi].block == recs[hi - 1].block) hi++;
+            if (n - hi < share / 4) hi = n;                                       // no sliver at the end of a segment
+            pieces.emplace_back();
+            pieces.back().recs = recs;
+            pieces.back().lo = lo;
+            pieces.back().hi = hi;
+            lo = hi;
+        }
     }
     const size_t P = pieces.size();
+    if (P > 64) {                                                                 // many short segments: fewer, longer pieces are not worth the code
+        uint64_t msgs = 0, total = 0;
+        for (uint32_t g = 0; g < nsegs; g++) {
+            uint64_t nb = 0;
+            msgs += modes_host_resolve_raw_mt(h, segs[g], seg_nrecs[g], out ? out + total : nullptr, cap > total ? cap - total : 0, &nb, threads);
+            total += nb;
+        }
+        if (nbytes) *nbytes = total;
+        return msgs;
+    }
     const bool dbg = getenv("MODES_HOST_MT_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    // guesses: the batch's initial state, plus - piece by piece - what the clean DF11/17/18 frames of the earlier pieces write
-    // (dump1090.c:1198: crcok without repair).  Which of them really get decoded depends on skip windows: a guess, checked below.
+    // guesses, in parallel: every piece lists what its clean frames would write; the state a piece starts from is the
+    // batch's initial state with the lists of the pieces before it applied in order
+    const bool aggressive = h->cfg.aggressive != 0;
+    WorkerPool::instance().run(P, [&](size_t t) { guess_piece(pieces[t], aggressive); });
     {
         modes_host g = *h;
         g.log = nullptr;
         for (size_t t = 0; t < P; t++) {
             pieces[t].host = g;
-            for (uint64_t i = pieces[t].lo; i < pieces[t].hi; i++) {
-                for (int a = 0; a < 2; a++) {
-                    const modes_attempt &at = recs[i].att[a];
-                    const int df = at.msg[0] >> 3;
-                    if (at.gate_ok && at.syndrome == 0 && (df == 11 || df == 17 || df == 18) &&
-                        (at.errors == 0 || (h->cfg.aggressive && at.errors < 3))) {
-                        icao_remember(&g, ((uint32_t)at.msg[1] << 16) | ((uint32_t)at.msg[2] << 8) | at.msg[3]);
-                        break;                                                    // a good first attempt ends the position
-                    }
-                }
-            }
+            for (uint32_t sl = 0; sl < kIcaoSlots; sl++)
+                if (pieces[t].guess_set[sl]) { g.icao[sl] = pieces[t].guess_addr[sl]; g.icao_seen[sl] = g.now_s; }
         }
     }
     const double t1 = now();
     // speculative resolve, one worker per piece
-    WorkerPool::instance().run(P, [&](size_t t) { run_piece(pieces[t], recs); });
+    WorkerPool::instance().run(P, [&](size_t t) { run_piece(pieces[t]); });
     const double t2 = now();
     int reruns = 0;
     // confirm in order: the true state at the start of piece t is the confirmed state at the end of piece t - 1
@@ -582,7 +631,7 @@ uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint
             const modes_host_config cfg = p.host.cfg;
             p.host = truth;
             p.host.cfg = cfg;
-            run_piece(p, recs);
+            run_piece(p);
             reruns++;
         }
         // true state after the piece: its writes over the true state before it
@@ -610,8 +659,8 @@ uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint
     if (out && total < cap) out[total] = 0;
     if (nbytes) *nbytes = total;
     if (dbg)
-        fprintf(stderr, "resolve_raw_mt: %zu pieces, %llu records: guess %.2f ms, speculative %.2f ms, confirm %.2f ms (%d re-run), merge %.2f ms\n",
-                P, (unsigned long long)nrecs, t1 - t0, t2 - t1, t3 - t2, reruns, now() - t3);
+        fprintf(stderr, "resolve_raw_mt: %zu pieces in %u segment(s), %llu records: guess %.2f ms, speculative %.2f ms, confirm %.2f ms (%d re-run), merge %.2f ms\n",
+                P, nsegs, (unsigned long long)nrecs, t1 - t0, t2 - t1, t3 - t2, reruns, now() - t3);
     return msgs;
 }
 

@@ -151,6 +151,23 @@ class HostResolver:
                                                  C.byref(nbytes))
         return int(n), C.string_at(_RAWBUF, nbytes.value)     # copies the listing only, not the whole buffer
 
+    def raw_listing_segments(self, segments, threads: int = 1) -> tuple[int, bytes]:
+        """raw_listing of a batch that lies in several record arrays (in stream order, whole buffers each), resolved as ONE
+        batch by up to `threads` threads without concatenating them (modes_host_resolve_raw_mtv)."""
+        segs = [np.ascontiguousarray(a, dtype=N.RECORD_DTYPE) for a in segments if len(a)]
+        if not segs:
+            return 0, b""
+        total = sum(a.size for a in segs)
+        cap = 62 * total + 64
+        global _RAWBUF
+        if _RAWBUF is None or len(_RAWBUF) < cap:
+            _RAWBUF = (C.c_char * (cap + cap // 4))()
+        ptrs = (C.c_void_p * len(segs))(*[a.ctypes.data for a in segs])
+        lens = (C.c_uint64 * len(segs))(*[a.size for a in segs])
+        nbytes = C.c_uint64()
+        n = self._lib.modes_host_resolve_raw_mtv(self._h, ptrs, lens, len(segs), _RAWBUF, len(_RAWBUF), C.byref(nbytes), max(1, threads))
+        return int(n), C.string_at(_RAWBUF, nbytes.value)
+
     def stats(self) -> dict:
         st = N.HostStats()
         self._lib.modes_host_get_stats(self._h, C.byref(st))

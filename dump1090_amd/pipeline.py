@@ -72,9 +72,14 @@ class Resolver(threading.Thread):
                         self._parts.append(([recs[offs[r]: offs[r + 1]].copy() for r in range(len(counts))], None))
                         done.set()
                     if last_call:
-                        for r in range(len(counts)):
-                            for call, _ in self._parts:
-                                self._resolve(call[r], timed)
+                        # rank-major = stream order; ONE parallel resolve over all the pieces where they lie
+                        # (modes_host_resolve_raw_mtv): with a call per (rank, call) piece rank 0 of an 8-GPU run spent
+                        # 16 x 0.5 ms per step here against 2.2 ms of kernels
+                        segs = [call[r] for r in range(len(counts)) for call, _ in self._parts]
+                        n, text = self._res.raw_listing_segments(segs, threads=self.threads)
+                        self.step_text.append(text)
+                        if timed:
+                            self.msgs += n
                         for _, ev in self._parts:
                             if ev is not None:
                                 ev.set()

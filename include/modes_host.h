@@ -169,6 +169,12 @@ uint64_t modes_host_resolve_raw(modes_host *h, const modes_record *recs, uint64_
 uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint64_t nrecs,
                                    char *out, uint64_t cap, uint64_t *nbytes, int threads);
 
+/* The same for a batch that lies in several arrays - segs[0], segs[1], ... in stream order, each a list of WHOLE
+ * buffers (e.g. the lists of N ranks and several calls as they sit in the gather buffers): one parallel resolve over
+ * all of them, no concatenation copy.  With more segments than 64 pieces allow it falls back to one call per segment. */
+uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
+                                    char *out, uint64_t cap, uint64_t *nbytes, int threads);
+
 /* dump1090.c:1803: would useModesMessage() display/forward this message? */
 int modes_host_wants(const modes_host *h, const struct modesMessage *mm);
 

@@ -174,6 +174,45 @@ def test_multithreaded_resolve_equals_the_sequential_one(streams, golden, case):
         seq.close()
 
 
+@pytest.mark.parametrize("case", ["modes1", "frames", "smear", "saturated"])
+def test_segmented_resolve_equals_the_sequential_one(streams, golden, case):
+    """modes_host_resolve_raw_mtv: the batch handed over as several arrays of whole buffers (how the gathered lists of N
+    ranks and several calls lie in rank 0's buffers) - one parallel resolve over all of them gives the sequential listing
+    and leaves the same whitelist, however the buffers are distributed over the arrays and the pieces over the threads."""
+    data = streams[case]
+    rng = np.random.default_rng(5)
+    for fs in ("default", "aggressive"):
+        flags = orc.FLAGSETS[fs]
+        recs, _ = oracle_records(data, maxfix_of(flags))
+        seq = HostResolver(**flags)
+        want = seq.raw_listing(recs, None)
+        assert want[1].decode() == golden[case]["raw"][fs]["text"]
+        follow = seq.raw_listing(recs, None)
+        seq.close()
+        blocks = np.unique(recs["block"])
+        for nseg, pieces in ((1, 3), (2, 2), (3, 5), (len(blocks), 2), (4, 64)):
+            # cut points at buffer boundaries; empty segments are legal
+            cuts = sorted(rng.choice(np.concatenate([blocks, blocks[-1:] + 1]), size=nseg - 1, replace=True)) if nseg > 1 else []
+            bounds = [0] + [int(np.searchsorted(recs["block"], c)) for c in cuts] + [recs.size]
+            segs = [recs[bounds[i]: bounds[i + 1]].copy() for i in range(len(bounds) - 1)]     # separate allocations
+            mt = HostResolver(**flags)
+            assert mt.raw_listing_segments(segs, threads=1) == want, (case, fs, nseg, "one thread")
+            mt.close()
+            mt = HostResolver(**flags)
+            got = mt.raw_listing_segments(segs, threads=pieces) if recs.size >= 2048 * pieces else None
+            mt.close()
+            assert got is None or got == want
+            mt = HostResolver(**flags)
+            lens = (C.c_uint64 * len(segs))(*[a.size for a in segs])
+            ptrs = (C.c_void_p * len(segs))(*[a.ctypes.data for a in segs])
+            buf = C.create_string_buffer(62 * recs.size + 64)
+            nb = C.c_uint64()
+            n = N.host_lib().modes_host_resolve_raw_mtv(mt._h, ptrs, lens, len(segs), buf, len(buf), C.byref(nb), -pieces)   # forced pieces
+            assert (int(n), buf.raw[: nb.value]) == want, (case, fs, nseg, pieces)
+            assert mt.raw_listing(recs, None) == follow, "whitelist after the batch"
+            mt.close()
+
+
 def test_multithreaded_resolve_rejects_wrong_guesses():
     """A piece whose speculation was wrong is resolved again: an AP-validated frame (DF4) whose address is only known
     from a frame that sits INSIDE another frame's skip window of an earlier piece looks validated to the guess (the guess

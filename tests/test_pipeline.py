@@ -89,9 +89,10 @@ def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_res
 
     if slow_resolver:                                            # rank 0's sequential half falls behind its GPU
         import time
-        from dump1090_amd import pipeline
-        fast = pipeline.Resolver._resolve
-        pipeline.Resolver._resolve = lambda self, recs, timed: (time.sleep(slow_resolver), fast(self, recs, timed))[1]
+        from dump1090_amd import demod
+        fast1, fastv = demod.HostResolver.raw_listing, demod.HostResolver.raw_listing_segments
+        demod.HostResolver.raw_listing = lambda self, *a, **k: (time.sleep(slow_resolver), fast1(self, *a, **k))[1]
+        demod.HostResolver.raw_listing_segments = lambda self, *a, **k: (time.sleep(2 * slow_resolver), fastv(self, *a, **k))[1]
     oplog = []
     out = run_steps(make, data[lo:hi], lo, calls, dict(fix=True, aggressive=False), steps=2, warm=1, depth=depth,
                     world=world, rank=rank, dist=dist, coll_device="cpu", cap_records=4096, oplog=oplog, lag=lag)
