@@ -273,7 +273,7 @@ def config3_stream(seed: int, nblocks: int, *, per: int = 65536, sigma_q16: int 
     # a multi-GPU run builds its part without walking the other ranks' frames)
     k_lo, k_hi = 0, max(0, (nsamp - per + per - 1) // per)
     if only_samples is not None:
-        k_lo = max(k_lo, only_samples[0] // per - 1)
+        k_lo = max(k_lo, (only_samples[0] - BLOCK_STRIDE) // per - 1)     # a seam frame sits up to a buffer behind its slot
         k_hi = min(k_hi, only_samples[1] // per + 2)
     hashes = hash_at(seed ^ 0xC0F3, np.arange(k_lo, max(k_lo, k_hi), dtype=np.uint64))
     for k in range(k_lo, k_hi):
