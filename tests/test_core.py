@@ -300,3 +300,25 @@ def test_df_from_first_six_pairs_equals_df_of_the_full_slicing_pass(shim):
         assert shim.shim_df_first6(win.ctypes.data) == df, (trial, kind[:6])
         seen.add(df)
     assert len(seen) == 32
+
+
+def test_scan_power_by_byte_dot_product_formula():
+    """The arithmetic of power16_scan (modes_gfx950.hip), restated with numpy for all 65,536 byte pairs: b ^ 0x7f read as a
+    signed byte is 127 - b; the signed dot product of a sample's two bytes with themselves, accumulated onto 0x7fff8000
+    with saturation at INT32_MAX, has 0x8000 | min(s, 32767) in its low half - and the level bound of the beta pass with
+    that constant bit on every value is the same predicate as without it.  (The device's instruction is checked by
+    tests/test_gpu_parity.py::test_magnitude_all_byte_pairs.)"""
+    i, q = np.meshgrid(np.arange(256, dtype=np.int64), np.arange(256, dtype=np.int64), indexing="ij")
+    sb = lambda b: ((b ^ 0x7F).astype(np.uint8)).astype(np.int8).astype(np.int64)
+    assert np.array_equal(sb(i), 127 - i) and sb(i).min() == -128 and sb(i).max() == 127
+    acc = 0x7FFF8000 + sb(i) * sb(i) + sb(q) * sb(q)
+    acc = np.minimum(acc, 0x7FFFFFFF)                                    # v_dot4_i32_i8 ... clamp
+    s = (i - 127) ** 2 + (q - 127) ** 2
+    assert np.array_equal(acc & 0xFFFF, 0x8000 | np.minimum(s, 32767))
+    assert (s == 32768).sum() == 1 and not (s == 32767).any()            # only I = Q = 255 saturates; nothing collides with it
+    rng = np.random.default_rng(9)
+    v = rng.integers(0, 32768, size=(200000, 5))
+    b = 0x8000
+    plain = 9 * v[:, 4] < v[:, 0] + v[:, 1] + v[:, 2] + v[:, 3] + 4
+    biased = 9 * (v[:, 4] + b) < (v[:, 0] + b) + (v[:, 1] + b) + (v[:, 2] + b) + (v[:, 3] + b + 5 * b) + 4
+    assert np.array_equal(plain, biased)
