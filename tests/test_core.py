@@ -322,3 +322,26 @@ def test_scan_power_by_byte_dot_product_formula():
     plain = 9 * v[:, 4] < v[:, 0] + v[:, 1] + v[:, 2] + v[:, 3] + 4
     biased = 9 * (v[:, 4] + b) < (v[:, 0] + b) + (v[:, 1] + b) + (v[:, 2] + b) + (v[:, 3] + b + 5 * b) + 4
     assert np.array_equal(plain, biased)
+
+
+def test_beta_pass_flag_gather_formula():
+    """scan_beta (modes_gfx950.hip) gathers the eight ordering flags of a queue entry - bits 15 / 31 of the four result
+    words r[q] <-> positions 2q / 2q + 1 - with two v_perm into the bytes of two words, and walks
+    f = ((lo & 0x80808080) >> 7) | ((hi & 0x80808080) >> 3) bit by bit with position = (b >> 3) | (b & 4): every subset of
+    positions must come back, whatever else the result words hold."""
+    rng = np.random.default_rng(10)
+    for mask in range(256):
+        r = rng.integers(0, 1 << 32, size=4, dtype=np.uint64) & np.uint64(0x7FFF7FFF)          # garbage in the other bits
+        for p in range(8):
+            if mask >> p & 1:
+                r[p >> 1] |= np.uint64(1 << (31 if p & 1 else 15))
+        byte = lambda w, k: (int(w) >> (8 * k)) & 0xFF
+        lo = byte(r[0], 1) | byte(r[0], 3) << 8 | byte(r[1], 1) << 16 | byte(r[1], 3) << 24   # v_perm(r1, r0, 0x07050301)
+        hi = byte(r[2], 1) | byte(r[2], 3) << 8 | byte(r[3], 1) << 16 | byte(r[3], 3) << 24
+        f = ((lo & 0x80808080) >> 7) | ((hi & 0x80808080) >> 3)
+        got = 0
+        while f:
+            b = (f & -f).bit_length() - 1
+            f &= f - 1
+            got |= 1 << ((b >> 3) | (b & 4))
+        assert got == mask
