@@ -5,6 +5,7 @@ import glob
 import os
 import sys
 from collections import defaultdict
+trace_avg_us = {}
 
 out = sys.argv[1]
 
@@ -49,6 +50,7 @@ for f in find("*kernel_trace.csv"):
         if n in order and len(order[n]) > 92:
             tail = order[n][82:]                        # bench.py's timed steps (after its 80 settle + 2 warmup steps)
             print("  %-24s the %d launches of the timed region: avg %9.1f us" % (n, len(tail), sum(tail) / len(tail) / 1e3))
+            trace_avg_us[n] = sum(tail) / len(tail) / 1e3
     kt_log = os.path.join(out, "kt.log")
     if os.path.exists(kt_log):
         import json
@@ -97,6 +99,8 @@ if traffic:
         h.update(open(os.path.join(root, rel), "rb").read())
     traffic["kernel_source_sha256_16"] = h.hexdigest()[:16]      # bench.py reports the counters only for these very sources
     traffic["tag"] = os.path.basename(os.path.normpath(out))
+    for k, us in trace_avg_us.items():                           # the kernel trace's own average over bench.py's timed launches
+        traffic.setdefault(k, {})["trace_avg_us_timed_region"] = round(us, 2)
     traffic["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on bench.py's default workload "
                         "(1 GiB per launch); FETCH_SIZE doubled (gfx950 correction for 16 B/lane streaming reads)")
     with open(os.path.join(out, "traffic.json"), "w") as fh:
