@@ -117,7 +117,8 @@ SINK_FN = C.CFUNCTYPE(None, C.POINTER(ModesMessage), C.c_uint32, C.c_uint32, C.c
 GPU_SYMBOLS = ("modes_gpu_create", "modes_gpu_destroy", "modes_gpu_last_error", "modes_gpu_compute_magnitude",
                "modes_gpu_detect", "modes_gpu_fetch", "modes_gpu_fetch_device", "modes_gpu_set_output", "modes_gpu_stream_wait", "modes_gpu_set_timing", "modes_gpu_demod_host", "modes_gpu_submit_host",
                "modes_gpu_host_alloc", "modes_gpu_host_free", "modes_gpu_compute_power", "modes_gpu_debug_tables",
-               "modes_gpu_synth_noise", "modes_gpu_fill", "modes_gpu_abi_version")
+               "modes_gpu_synth_noise", "modes_gpu_fill", "modes_gpu_abi_version", "modes_gpu_host_profile",
+               "modes_gpu_stream_ceiling")
 HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_set_time", "modes_host_resolve", "modes_host_resolve_to_array",
                 "modes_host_resolve_raw", "modes_host_resolve_raw_mt", "modes_host_resolve_raw_mtv", "modes_host_wants",
                 "modes_host_get_stats", "modes_host_decode", "modes_host_decode_frame", "modes_format_raw", "modes_format_raw_net",
@@ -167,6 +168,9 @@ def gpu_lib():
         L.modes_gpu_synth_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                             C.c_void_p]
         L.modes_gpu_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint8, C.c_void_p]
+        L.modes_gpu_host_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        L.modes_gpu_stream_ceiling.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
+                                               C.POINTER(C.c_float), C.c_void_p]
         _gpu = L
     return _gpu
 

@@ -30,6 +30,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1084,8 +1085,11 @@ __device__ __forceinline__ bool demod_full(const DemodParams &P, const Lut lut, 
 // Lists live in LDS; appends from stages 2a/2b reserve their slots with one LDS atomic per wavefront.
 // finalize_kernel (one workgroup, next in the stream) turns the per-batch record counts into offsets.
 // ------------------------------------------------------------------------------------
-template <int kDemodWaves, class Lut>
-__global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80))) void demod_kernel(DemodParams P) {
+// kMinWaves: wavefronts per SIMD the register allocation must leave room for (amdgpu_waves_per_eu): 4 = whatever the code
+// needs (~120 VGPRs, stage 3 sets it); 6 = at most 80 VGPRs (stage 3 spills a few values to scratch) - then a wavefront of
+// this kernel fits into the registers the scan kernel's six 56-VGPR wavefronts leave free on every SIMD.
+template <int kDemodWaves, class Lut, int kMinWaves = 4>
+__global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(kMinWaves))) void demod_kernel(DemodParams P) {
     constexpr int kDemodThreads = kDemodWaves * 64;
     constexpr int kGatePerRound = kDemodThreads / kGateLanes;   // preambles a workgroup tests per round
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[Lut::kEntries];
@@ -1584,6 +1588,40 @@ __global__ __launch_bounds__(256) void fill_kernel(uint8_t *out, uint64_t nbytes
         out[i] = value;
 }
 
+// ------------------------------------------------------------------------------------
+// stream_read_kernel - the chip's read-only streaming rate with the scan kernel's own access pattern: runs of
+// `run_chunks` 1 KiB chunks per wavefront, 16 B per lane through a raw buffer descriptor with the same cache policy
+// (nt | sc1), two chunks in flight, two wavefronts per workgroup - and nothing else (an XOR keeps the loads alive).
+// bench.py reports it next to the 8 TB/s specification as roofline.measured_ceiling.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kScan2Waves * kWave) void stream_read_kernel(const uint8_t *__restrict__ iq, uint32_t nchunks,
+                                                                          uint32_t run_chunks, uint32_t nruns, uint32_t *out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t run = blockIdx.x * kScan2Waves + wave;
+    if (run >= nruns) return;
+    const uint32_t c0 = run * run_chunks;
+    const uint32_t nk = min(run_chunks, nchunks - c0), last_off = (nk - 1) * kChunkBytes;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(iq) + (uint64_t)c0 * kChunkBytes, 0,
+                                                                    0x7fffffff, 0x00020000);
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    auto load_at = [&](uint32_t off) -> u32x4 {
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, off < last_off ? off : last_off, kScanAux);
+    };
+    u32x4 acc = {0, 0, 0, 0};
+    u32x4 x = load_at(0), y = load_at(kChunkBytes);
+    uint32_t k = 0, off = 2 * kChunkBytes;
+    for (; k + 2 <= nk; k += 2, off += 2 * kChunkBytes) {
+        acc ^= x;
+        x = load_at(off);
+        acc ^= y;
+        y = load_at(off + kChunkBytes);
+    }
+    if (k < nk) acc ^= x;
+    const uint32_t v = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+    if (v == 0x9E3779B9u) out[run] = v;                                      // (practically) never: the loads stay, nothing is written
+}
+
 }  // namespace
 
 // ======================================================================================
@@ -1634,6 +1672,12 @@ struct modes_gpu {
     std::vector<uint64_t> h_cands;
 
     uint8_t *d_stage = nullptr;       size_t stage_bytes = 0;
+    uint32_t *d_ceiling = nullptr;    size_t ceiling_bytes = 0;     // modes_gpu_stream_ceiling's (unused) output words
+
+    // host-side cost of modes_gpu_detect, seconds, accumulated (modes_gpu_host_profile): 0 hipSetDevice, 1 geometry + list
+    // growth + parameter blocks, 2 scan launch, 3 demod launch, 4 finalize launch, 5 the rest (order / prefix kernels,
+    // hipGetLastError, event records), 6 calls
+    double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     uint32_t demod_wgs = 1024;        // workgroups of demod_kernel that are resident at once (occupancy x CUs)
     bool auto_records = false;        // max_records was 0: the record list grows when a call needs more
@@ -1732,8 +1776,9 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
         hipDeviceProp_t prop;
         int per_cu = 0;
         CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
-        if (ctx->cfg.demod_variant == 1) CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<4, LutSmall>, 256, 0));
-        else                             CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<8, LutFull>, 512, 0));
+        if (ctx->cfg.demod_variant == 2)      CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<4, LutSmall, 6>, 256, 0));
+        else if (ctx->cfg.demod_variant == 1) CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<4, LutSmall>, 256, 0));
+        else                                  CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<8, LutFull>, 512, 0));
         ctx->demod_wgs = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, prop.multiProcessorCount);
     }
     for (auto &e : ctx->ev_k) CREATE_TRY(hipEventCreate(&e));
@@ -1769,7 +1814,7 @@ void modes_gpu_destroy(modes_gpu *ctx) {
     if (ctx->in_flight) (void)wait_results(ctx);                            // kernels of a detect nobody fetched
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     void *dev[] = {ctx->d_lut, ctx->d_esyn, ctx->d_slots, ctx->d_cand_slots, ctx->d_counts, ctx->d_cand_offsets,
-                   ctx->d_cand_dense, ctx->d_staging, ctx->d_keys, ctx->d_records, ctx->d_hdr, ctx->d_stage, ctx->d_totals};
+                   ctx->d_cand_dense, ctx->d_staging, ctx->d_keys, ctx->d_records, ctx->d_hdr, ctx->d_stage, ctx->d_totals, ctx->d_ceiling};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (ctx->h_hdr) (void)hipHostFree(ctx->h_hdr);
@@ -1874,7 +1919,11 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     if (span->stream_byte0 > carry0)
         return fail(ctx, MODES_ERR_ARG, "detect: span starts at stream byte %llu, buffer %llu needs bytes from %llu",
                     (unsigned long long)span->stream_byte0, (unsigned long long)span->first_block, (unsigned long long)carry0);
+    using clk = std::chrono::steady_clock;
+    clk::time_point t_mark = clk::now();
+    auto mark = [&](int k) { const clk::time_point now = clk::now(); ctx->prof[k] += std::chrono::duration<double>(now - t_mark).count(); t_mark = now; };
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    mark(0);
     hipStream_t st = pick_stream(ctx, stream);
 
     // The kernels address the stream from a 16-byte aligned base; a span that starts inside a
@@ -2001,10 +2050,12 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     hipEvent_t *ek = ctx->ev_k;
     auto ev = [&](int k) -> hipEvent_t { return timed ? ek[k] : nullptr; };
     const dim3 scan_grid(ctx->cfg.scan_variant == 1 ? (nruns + kScanWaves - 1) / kScanWaves : (nruns + kScan2Waves - 1) / kScan2Waves);
+    mark(1);
     if (ctx->cfg.scan_variant == 1)
         hipExtLaunchKernelGGL(scan_fused_kernel, scan_grid, dim3(kScanWaves * kWave), 0, st, ev(0), ev(1), 0, sp);
     else
         hipExtLaunchKernelGGL(scan_kernel, scan_grid, dim3(kScan2Waves * kWave), 0, st, ev(0), ev(1), 0, sp);
+    mark(2);
     // cfg.overlap == 1: everything after the scan moves to the context's own stream (ordered behind the
     // scan), so the next kernel on the caller's stream - typically another context's scan -
     // may run concurrently with this latency-bound tail (in practice a demod workgroup's 77 KiB of LDS only
@@ -2016,12 +2067,16 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
         HIP_TRY(ctx, hipStreamWaitEvent(st2, ek[1], 0));
     }
     ctx->demod_grid = std::min<uint32_t>(nbatches, ctx->demod_wgs);        // every workgroup's first batch; the rest are dealt dynamically
-    if (ctx->cfg.demod_variant == 1)
+    if (ctx->cfg.demod_variant == 2)
+        hipExtLaunchKernelGGL((demod_kernel<4, LutSmall, 6>), dim3(ctx->demod_grid), dim3(256), 0, st2, ev(2), ev(3), 0, dp);
+    else if (ctx->cfg.demod_variant == 1)
         hipExtLaunchKernelGGL((demod_kernel<4, LutSmall>), dim3(ctx->demod_grid), dim3(256), 0, st2, ev(2), ev(3), 0, dp);
     else
         hipExtLaunchKernelGGL((demod_kernel<8, LutFull>), dim3(ctx->demod_grid), dim3(512), 0, st2, ev(2), ev(3), 0, dp);
+    mark(3);
     fp.ntotals = ctx->demod_grid;
     hipExtLaunchKernelGGL(finalize_kernel, dim3(1), dim3(512), 0, st2, nullptr, nullptr, 0, fp);
+    mark(4);
     // Lists of up to direct_records records are put in order by finalize_kernel.  order_kernel only follows in the
     // stream when the caller consumes the list on the device in stream order (MODES_GPU_ORDER_IN_STREAM); otherwise
     // modes_gpu_fetch / modes_gpu_fetch_device launch it when a list turns out to be long.
@@ -2043,6 +2098,8 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     ctx->done_recorded = ctx->order_launched || tail;
     if (ctx->done_recorded) HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st2));
     ctx->tail_stream = st2;
+    mark(5);
+    ctx->prof[6] += 1.0;
 
     ctx->last_stream = st;
     ctx->last_span = *span;
@@ -2173,6 +2230,55 @@ static int finish_detect(modes_gpu *ctx, modes_gpu_result *res, bool to_host) {
         (void)hipEventElapsedTime(&res->demod_ms, ctx->ev_k[2], ctx->ev_k[3]);
         if (ctx->order_launched || ordered_late) (void)hipEventElapsedTime(&res->order_ms, ctx->ev_k[4], ctx->ev_k[5]);
     }
+    return MODES_OK;
+}
+
+int modes_gpu_host_profile(modes_gpu *ctx, double out[8], int reset) {
+    if (!ctx || !out) return MODES_ERR_ARG;
+    for (int k = 0; k < 8; k++) out[k] = ctx->prof[k];
+    if (reset)
+        for (double &v : ctx->prof) v = 0.0;
+    return MODES_OK;
+}
+
+int modes_gpu_stream_ceiling(modes_gpu *ctx, const void *d_iq, uint64_t nbytes, uint32_t launches, uint32_t time_every,
+                             float *avg_ms, float *min_ms, void *stream) {
+    if (!ctx) return MODES_ERR_ARG;
+    if (!d_iq || !avg_ms || launches == 0 || time_every == 0) return fail(ctx, MODES_ERR_ARG, "stream_ceiling: bad argument");
+    if (reinterpret_cast<uintptr_t>(d_iq) & 15) return fail(ctx, MODES_ERR_ARG, "stream_ceiling: d_iq must be 16-byte aligned");
+    const uint64_t nchunks64 = nbytes / kChunkBytes;
+    if (nchunks64 == 0 || nchunks64 > 0x7fffffffull / 2) return fail(ctx, MODES_ERR_ARG, "stream_ceiling: 1 KiB .. 1 TiB");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    hipStream_t st = pick_stream(ctx, stream);
+    const uint32_t nchunks = (uint32_t)nchunks64, R = 32, nruns = (nchunks + R - 1) / R;
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_ceiling, &ctx->ceiling_bytes, (size_t)nruns * sizeof(uint32_t))) != MODES_OK) return rc;
+    // the launches are queued back to back without a host round trip (an idle chip boosts its clocks: DESIGN.md 3.1); one
+    // in time_every carries start / stop events attached to its dispatch - the scan kernel's own timing method
+    const uint32_t ntimed = (launches + time_every - 1) / time_every;
+    std::vector<hipEvent_t> evs(2 * (size_t)ntimed, nullptr);
+    for (auto &e : evs) HIP_TRY(ctx, hipEventCreate(&e));
+    uint32_t t = 0;
+    for (uint32_t i = 0; i < launches; i++) {
+        const bool timed = (i % time_every) == time_every - 1 || (i == launches - 1 && t < ntimed);
+        hipExtLaunchKernelGGL(stream_read_kernel, dim3((nruns + kScan2Waves - 1) / kScan2Waves), dim3(kScan2Waves * kWave), 0, st,
+                              timed ? evs[2 * t] : nullptr, timed ? evs[2 * t + 1] : nullptr, 0,
+                              static_cast<const uint8_t *>(d_iq), nchunks, R, nruns, ctx->d_ceiling);
+        if (timed) t++;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    double sum = 0.0;
+    float best = 1e30f;
+    for (uint32_t k = 0; k < t; k++) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, evs[2 * k], evs[2 * k + 1]));
+        sum += ms;
+        best = std::min(best, ms);
+    }
+    for (auto &e : evs) (void)hipEventDestroy(e);
+    *avg_ms = t ? (float)(sum / t) : 0.f;
+    if (min_ms) *min_ms = t ? best : 0.f;
     return MODES_OK;
 }
 

@@ -419,6 +419,7 @@ void raw_sink(const struct modesMessage *mm, uint32_t, uint32_t, void *user) {
 uint64_t modes_host_resolve_raw(modes_host *h, const modes_record *recs, uint64_t nrecs, const uint64_t *cands, uint64_t ncand,
                                 char *out, uint64_t cap, uint64_t *nbytes) {
     RawSink s{h, out, cap, 0, 0};
+    if (out && cap) out[0] = 0;                                                   // an empty (or wholly cut) listing is ""
     modes_host_resolve(h, recs, nrecs, cands, ncand, raw_sink, &s);
     if (nbytes) *nbytes = s.n;
     return s.msgs;
@@ -642,7 +643,8 @@ uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *se
     // merge: whitelist, counters, text
     memcpy(h->icao, truth.icao, sizeof h->icao);
     memcpy(h->icao_seen, truth.icao_seen, sizeof h->icao_seen);
-    uint64_t total = 0, msgs = 0;
+    uint64_t total = 0, msgs = 0, stored = 0;
+    bool full = false;
     for (Piece &p : pieces) {
         h->st.valid_preamble += p.host.st.valid_preamble;
         h->st.out_of_phase += p.host.st.out_of_phase;
@@ -652,11 +654,22 @@ uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *se
         h->st.fixed += p.host.st.fixed;
         h->st.single_bit_fix += p.host.st.single_bit_fix;
         h->st.two_bits_fix += p.host.st.two_bits_fix;
-        if (out && total + p.text.size() + 1 <= cap) memcpy(out + total, p.text.data(), p.text.size());
+        // what the header promises when the listing outgrows `cap`: whole lines, as many as fit, nothing behind them -
+        // the first piece that does not fit contributes the whole lines of its beginning, every later piece nothing
+        if (out && !full) {
+            size_t take = p.text.size();
+            if (total + take + 1 > cap) {
+                full = true;
+                take = cap > total + 1 ? (size_t)(cap - total - 1) : 0;
+                while (take > 0 && p.text[take - 1] != '\n') take--;
+            }
+            memcpy(out + total, p.text.data(), take);
+            stored = total + take;
+        }
         total += p.text.size();
         msgs += p.msgs;
     }
-    if (out && total < cap) out[total] = 0;
+    if (out && stored < cap) out[stored] = 0;
     if (nbytes) *nbytes = total;
     if (dbg)
         fprintf(stderr, "resolve_raw_mt: %zu pieces in %u segment(s), %llu records: guess %.2f ms, speculative %.2f ms, confirm %.2f ms (%d re-run), merge %.2f ms\n",

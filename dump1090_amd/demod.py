@@ -82,9 +82,6 @@ def _to_message(e: N.Emitted, check_crc: bool = True) -> Message:
                    mm.phase_corrected, mm.iid, e.block, e.j, extra, buf.value.decode("ascii", "replace"))
 
 
-_RAWBUF = None
-
-
 class HostResolver:
     """The sequential half: records -> messages (libmodes_host.so).  No GPU needed."""
 
@@ -95,6 +92,13 @@ class HostResolver:
         self._h = self._lib.modes_host_create(C.byref(cfg))
         if not self._h:
             raise N.ModesError(-3, "modes_host_create failed")
+        self._rawbuf = None          # grow-only text buffer of raw_listing*: per resolver (ctypes drops the GIL inside the C call,
+                                     # two resolvers on two threads must not format into one buffer)
+
+    def _text_buffer(self, cap):
+        if self._rawbuf is None or len(self._rawbuf) < cap:
+            self._rawbuf = (C.c_char * (cap + cap // 4))()
+        return self._rawbuf
 
     def close(self):
         if getattr(self, "_h", None):
@@ -138,18 +142,15 @@ class HostResolver:
         if candidates is not None:
             candidates = np.ascontiguousarray(candidates, dtype=np.uint64)
             cptr, ncand = candidates.ctypes.data, candidates.size
-        cap = 62 * records.size + 64                      # at most two 31-byte lines per record
-        global _RAWBUF
-        if _RAWBUF is None or len(_RAWBUF) < cap:         # one grow-only buffer per process (resolvers are short-lived)
-            _RAWBUF = (C.c_char * (cap + cap // 4))()
+        buf = self._text_buffer(62 * records.size + 64)   # at most two 31-byte lines per record
         nbytes = C.c_uint64()
         if threads > 1 and candidates is None:
-            n = self._lib.modes_host_resolve_raw_mt(self._h, records.ctypes.data, records.size, _RAWBUF, len(_RAWBUF),
+            n = self._lib.modes_host_resolve_raw_mt(self._h, records.ctypes.data, records.size, buf, len(buf),
                                                     C.byref(nbytes), threads)
         else:
-            n = self._lib.modes_host_resolve_raw(self._h, records.ctypes.data, records.size, cptr, ncand, _RAWBUF, len(_RAWBUF),
+            n = self._lib.modes_host_resolve_raw(self._h, records.ctypes.data, records.size, cptr, ncand, buf, len(buf),
                                                  C.byref(nbytes))
-        return int(n), C.string_at(_RAWBUF, nbytes.value)     # copies the listing only, not the whole buffer
+        return int(n), C.string_at(buf, nbytes.value)     # copies the listing only, not the whole buffer
 
     def raw_listing_segments(self, segments, threads: int = 1) -> tuple[int, bytes]:
         """raw_listing of a batch that lies in several record arrays (in stream order, whole buffers each), resolved as ONE
@@ -158,15 +159,12 @@ class HostResolver:
         if not segs:
             return 0, b""
         total = sum(a.size for a in segs)
-        cap = 62 * total + 64
-        global _RAWBUF
-        if _RAWBUF is None or len(_RAWBUF) < cap:
-            _RAWBUF = (C.c_char * (cap + cap // 4))()
+        buf = self._text_buffer(62 * total + 64)
         ptrs = (C.c_void_p * len(segs))(*[a.ctypes.data for a in segs])
         lens = (C.c_uint64 * len(segs))(*[a.size for a in segs])
         nbytes = C.c_uint64()
-        n = self._lib.modes_host_resolve_raw_mtv(self._h, ptrs, lens, len(segs), _RAWBUF, len(_RAWBUF), C.byref(nbytes), max(1, threads))
-        return int(n), C.string_at(_RAWBUF, nbytes.value)
+        n = self._lib.modes_host_resolve_raw_mtv(self._h, ptrs, lens, len(segs), buf, len(buf), C.byref(nbytes), max(1, threads))
+        return int(n), C.string_at(buf, nbytes.value)
 
     def stats(self) -> dict:
         st = N.HostStats()
@@ -367,6 +365,27 @@ class Demodulator:
     def set_timing(self, on: bool):
         """Kernel times in the result of every detect that follows (default on; ~9 us of idle GPU per kernel boundary)."""
         self._check(self._lib.modes_gpu_set_timing(self._h, int(bool(on))))
+
+    def host_profile(self, reset: bool = False) -> dict:
+        """Host seconds inside modes_gpu_detect so far, by section (modes_gpu_host_profile)."""
+        out = (C.c_double * 8)()
+        self._check(self._lib.modes_gpu_host_profile(self._h, out, int(reset)))
+        names = ("set_device", "setup", "launch_scan", "launch_demod", "launch_finalize", "rest")
+        d = {n: float(out[i]) for i, n in enumerate(names)}
+        d["calls"] = int(out[6])
+        return d
+
+    def stream_ceiling(self, iq, launches: int = 96, time_every: int = 4, stream=None):
+        """(average, shortest) ms of a read-only pass over the CUDA uint8 tensor `iq` with the scan kernel's loads and
+        nothing else (modes_gpu_stream_ceiling): the measured HBM streaming ceiling of this box."""
+        import torch
+        assert iq.is_cuda and iq.dtype == torch.uint8 and iq.is_contiguous()
+        st = stream if stream is not None else torch.cuda.current_stream(iq.device)
+        avg, best = C.c_float(), C.c_float()
+        n = iq.numel() // 1024 * 1024
+        self._check(self._lib.modes_gpu_stream_ceiling(self._h, iq.data_ptr(), n, launches, time_every, C.byref(avg), C.byref(best),
+                                                       self._stream_ptr(st)))
+        return float(avg.value), float(best.value), n
 
     def stream_wait(self, stream):
         """Make `stream` wait for the results of the detect in flight (modes_gpu_stream_wait)."""

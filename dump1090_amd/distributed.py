@@ -37,21 +37,27 @@ class GatherSlot:
         g = self.g = owner
         dev = g.device
         own = g.cap * 64
-        # rank dst: room for every rank's list, its own first; the others: their own list only
-        self.records = torch.zeros(own * (g.world if g.rank == g.dst else 1), dtype=torch.uint8, device=dev)
+        # rank dst: room for every rank's list, its own first; the others: their own list only.  A group of ONE rank
+        # (bench.py --force-gather on a one-GPU box) sends its list to itself into a second half - the point-to-point
+        # calls of the N > 1 path executed over RCCL on the hardware at hand (loopback)
+        self.records = torch.zeros(own * (max(2, g.world) if g.rank == g.dst else 1), dtype=torch.uint8, device=dev)
         self.count = torch.zeros(1, dtype=torch.int64, device=dev)
         self.all_counts = torch.zeros(g.world, dtype=torch.int64, device=dev)
         if g.on_gpu:
             self.all_counts_h = torch.zeros(g.world, dtype=torch.int64).pin_memory()
             self.records_h = torch.zeros(self.records.numel(), dtype=torch.uint8).pin_memory() if g.rank == g.dst else None
-            self.ev_counts = torch.cuda.Event()
-            self.ev_records = torch.cuda.Event()
+            self.ev_counts = torch.cuda.Event(enable_timing=True)
+            self.ev_records = torch.cuda.Event(enable_timing=True)
+            self.ev_c0 = torch.cuda.Event(enable_timing=True)       # in front of the count all_gather / of the transfers:
+            self.ev_r0 = torch.cuda.Event(enable_timing=True)       # on the communication stream, never in a launch stream
         else:
             self.all_counts_h = self.all_counts
             self.records_h = self.records
             self.ev_counts = self.ev_records = None
         self.counts = None          # list[int] once exchange_records() has run
         self._works = []
+        self.p2p_ops = 0            # point-to-point operations this rank issued for the call (exchange_records)
+        self.loopback = None        # group of one: did the list that travelled through send / recv arrive unchanged?
 
     @property
     def own_records(self):
@@ -66,6 +72,7 @@ class GatherSlot:
         self.counts = None
         if g.on_gpu:
             with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(g.device)):
+                self.ev_c0.record()
                 dist.all_gather_into_tensor(self.all_counts, self.count, group=g.group)
                 self.all_counts_h.copy_(self.all_counts, non_blocking=True)
                 self.ev_counts.record()
@@ -94,13 +101,25 @@ class GatherSlot:
                 nb = self.counts[r] * 64
                 ops.append(dist.P2POp(dist.irecv, self.records[offs: offs + nb], g.global_rank(r), group=g.group))
                 offs += nb
+            if g.world == 1 and g.on_gpu and self.counts[0]:          # loopback: the root's list through isend / irecv to itself
+                nb = self.counts[0] * 64
+                me = g.global_rank(g.dst)
+                ops.append(dist.P2POp(dist.irecv, self.records[g.cap * 64: g.cap * 64 + nb], me, group=g.group))
+                ops.append(dist.P2POp(dist.isend, self.records[:nb], me, group=g.group))
         elif self.counts[g.rank]:
             ops.append(dist.P2POp(dist.isend, self.records[: self.counts[g.rank] * 64], g.global_rank(g.dst), group=g.group))
+        self.p2p_ops = len(ops)
+        self.loopback = None
         if g.on_gpu:
             with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(g.device)):
+                self.ev_r0.record()
                 if ops:
                     for w in dist.batch_isend_irecv(ops):
                         w.wait()                                  # stream-ordered (the host does not block)
+                if g.world == 1 and ops:
+                    nb = self.counts[0] * 64
+                    # compared on the device, in stream order; the verdict is read in wait()
+                    self.loopback = (self.records[:nb] == self.records[g.cap * 64: g.cap * 64 + nb]).all()
                 if g.rank == g.dst:
                     total = sum(self.counts) * 64
                     if total:
@@ -118,10 +137,28 @@ class GatherSlot:
             for w in self._works:
                 w.wait()
             self._works = []
+        if self.loopback is not None and not bool(self.loopback):
+            raise N.ModesError(-2, "loopback: the record list that went through isend / irecv differs from the one sent")
         if g.rank != g.dst:
             return None
         total = sum(self.counts) * 64
         return self.records_h[:total].numpy().view(N.RECORD_DTYPE)
+
+    def comm_ms(self):
+        """GPU time of this call's two exchanges on the communication stream (count all_gather + its copy; list transfers +
+        the copy to the host), ms - after wait().  0.0 on the CPU path."""
+        if not self.g.on_gpu:
+            return 0.0
+        return float(self.ev_c0.elapsed_time(self.ev_counts) + self.ev_r0.elapsed_time(self.ev_records))
+
+    def gathered_bytes(self):
+        """Bytes that travelled between ranks for this call: every list but the root's own (after exchange_records)."""
+        g = self.g
+        if self.counts is None:
+            return 0
+        if g.world == 1:
+            return self.counts[0] * 64 if self.p2p_ops else 0
+        return 64 * (sum(self.counts) - self.counts[g.dst])
 
 
 class RecordGather:

@@ -150,6 +150,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     peers that queued "all_gather(n), transfers(n - 1)" would deadlock.  oplog (a list): receives ("detect" | "counts" |
     "records", call number) as they are issued (tests/test_pipeline.py compares the ranks' logs)."""
     import torch
+    from ._native import ModesError
     from .distributed import RecordGather
 
     dist_on = world > 1 if gather is None else bool(gather)          # records travel through RecordGather
@@ -192,7 +193,9 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
 
     scan_ms, demod_ms, order_ms = [], [], []
     last = {}
-    host = dict(wait_kernels=0.0, queue_counts=0.0, queue_records=0.0, wait_records=0.0, detect=0.0, wait_free=0.0)   # host seconds by phase
+    host = dict(wait_kernels=0.0, queue_counts=0.0, queue_records=0.0, wait_records=0.0, detect=0.0, wait_free=0.0,
+                fetch=0.0)                                                   # host seconds by phase
+    comm = dict(calls=0, p2p_ops=0, bytes=0, ms=0.0)                         # the exchanges of the timed calls (this rank's view)
 
     def note(info, timed):
         last.update({k: v for k, v in info.items() if not k.endswith("_ms")})
@@ -206,12 +209,28 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     def phase_counts(k, timed, n):
         d, s = demods[k], slots[k]
         t_a = time.perf_counter()
+        # A list that outgrew the gather buffers must fail the JOB, not this rank alone: the other ranks are about to
+        # queue this call's all_gather and would wait for it until the watchdog fires.  So the overflow is swallowed here,
+        # the true count (> cap) still goes through the all_gather, and every rank raises from the shared check in
+        # GatherSlot.exchange_records.
+        info = {}
         if inplace:
-            _, info = d.fetch_device()
+            try:
+                _, info = d.fetch_device()
+            except ModesError as e:
+                if e.code != -4:
+                    raise                                       # (the kernels left the true count in s.count)
         else:                                                   # --backend gloo smoke mode: the lists travel as CPU tensors
-            recs, _, info = d.fetch()
-            s.own_records[: recs.size * 64] = torch.from_numpy(recs.view(np.uint8).reshape(-1))
-            s.count[0] = recs.size
+            try:
+                recs, _, info = d.fetch()
+                n_recs = recs.size
+            except ModesError as e:
+                if e.code != -4:
+                    raise
+                n_recs = s.g.cap + 1
+            if n_recs <= s.g.cap:
+                s.own_records[: n_recs * 64] = torch.from_numpy(recs.view(np.uint8).reshape(-1))
+            s.count[0] = n_recs
         t_b = time.perf_counter()
         log(("counts", n))
         s.exchange_counts(stream=comms[k])
@@ -234,8 +253,15 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             recs = slots[k].wait()
             host["wait_records"] += time.perf_counter() - t_a
             counts = slots[k].counts
+            if timed:
+                comm["calls"] += 1
+                comm["p2p_ops"] += slots[k].p2p_ops
+                comm["bytes"] += slots[k].gathered_bytes()
+                comm["ms"] += slots[k].comm_ms()
         else:
+            t_a = time.perf_counter()
             recs, _, info = demods[k].fetch(copy=False)         # a view of the context's pinned list
+            host["fetch"] += time.perf_counter() - t_a
             note(info, timed)
         if rank == 0:
             free[k].clear()
@@ -348,7 +374,11 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
            "scan_ms_median": float(np.median(scan_ms)) if scan_ms else 0.0,
            "timed_calls": len(scan_ms), "last": dict(last), "depth": depth, "calls_per_step": len(calls),
            "host_ms_per_call": {k: round(v / max(1, ncall) * 1e3, 4) for k, v in host.items()},
-           "call_bytes": float(np.mean([chi - clo for _, _, clo, chi in calls])), "steps": steps}
+           "call_bytes": float(np.mean([chi - clo for _, _, clo, chi in calls])), "steps": steps, "comm": comm}
+    prof = [d.host_profile() for d in demods if hasattr(d, "host_profile")]
+    if prof:                                                     # inside modes_gpu_detect, by section, microseconds per call
+        ncalls_p = max(1, sum(p["calls"] for p in prof))
+        out["detect_us_per_call"] = {k: round(sum(p[k] for p in prof) / ncalls_p * 1e6, 2) for k in prof[0] if k != "calls"}
     if rank == 0:
         if resolver.error is not None:
             raise resolver.error

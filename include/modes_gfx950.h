@@ -67,9 +67,10 @@ typedef struct {
     uint32_t flags;            /* MODES_GPU_* below                                                       */
     uint32_t direct_records;   /* lists of at most this many records reach the host with the kernels
                                   (zero-copy stores, no copy operation); 0 = 4096                          */
-    uint32_t demod_variant;    /* 0 = production demod kernel (8-wave workgroups, the whole 64 KiB magnitude table in
-                                  LDS); 1 = 4-wave workgroups with a 1 KiB table + exact square root beyond it, small
-                                  enough to sit on a CU next to the scan kernel (the cross-check kernel) */
+    uint32_t demod_variant;    /* 0 = 8-wave workgroups, the whole 64 KiB magnitude table in LDS; 1 = 4-wave workgroups
+                                  with a 1 KiB table + exact square root beyond it (8 KiB of LDS); 2 = the same held to
+                                  80 VGPRs, so that its wavefronts fit into what the scan kernel leaves free on a CU
+                                  (registers, LDS, wave slots) and run UNDER the next call's scan        */
 } modes_gpu_config;
 
 /* modes_gpu_config.flags */
@@ -217,8 +218,20 @@ int modes_gpu_synth_noise(modes_gpu *ctx, void *d_out, uint64_t first_byte, uint
 /* Fills d_out[0..nbytes) with `value` (127 = no signal) - tail padding helper. */
 int modes_gpu_fill(modes_gpu *ctx, void *d_out, uint64_t nbytes, uint8_t value, void *stream);
 
+/* Measurement taps (bench.py; no counterpart in the reference).
+ * modes_gpu_host_profile: host seconds spent inside modes_gpu_detect since creation / the last reset, by section -
+ *   out[0] hipSetDevice, [1] geometry, list growth and parameter blocks, [2] scan launch, [3] demod launch,
+ *   [4] finalize launch, [5] everything after it (order / prefix kernels, hipGetLastError, event records), [6] calls.
+ * modes_gpu_stream_ceiling: the chip's read-only streaming rate over the nbytes at d_iq (16-byte aligned) with the scan
+ *   kernel's own access pattern and cache policy and no arithmetic: `launches` kernels queued back to back on `stream`,
+ *   one in `time_every` timed by events attached to its dispatch (the scan kernel's timing method); *avg_ms / *min_ms =
+ *   average / shortest timed launch.  SURVEY.md 8d: the measured ceiling next to the 8 TB/s specification. */
+int modes_gpu_host_profile(modes_gpu *ctx, double out[8], int reset);
+int modes_gpu_stream_ceiling(modes_gpu *ctx, const void *d_iq, uint64_t nbytes, uint32_t launches, uint32_t time_every,
+                             float *avg_ms, float *min_ms, void *stream);
+
 /* ABI version of this header. */
-#define MODES_GFX950_ABI 3
+#define MODES_GFX950_ABI 4
 int modes_gpu_abi_version(void);
 
 #ifdef __cplusplus

@@ -22,7 +22,7 @@ def only(pred, what):
 i = only(lambda ln: ln.startswith("int main(int argc, char **argv) {"), "main")
 out[i:i] = ['#include "modes_dropin.c"   /* the gfx950 path: modesInitGpu, modesGpuDemod, modesGpuResolve */', ""]
 i = only(lambda ln: ln.strip() == "modesInit();", "modesInit call")
-out.insert(i + 1, "    modesInitGpu();")
+out.insert(i + 1, "    if (!Modes.net_only) modesInitGpu();   /* --net-only never demodulates: no GPU needed */")
 i = only(lambda ln: ln.strip() == "computeMagnitudeVector();", "computeMagnitudeVector call")
 out[i] = out[i].replace("computeMagnitudeVector();", "modesGpuDemod();")
 i = only(lambda ln: ln.strip() == "detectModeS(Modes.magnitude, Modes.data_len/2);", "detectModeS call")

@@ -74,6 +74,11 @@ static void dropin_sink(const struct modesMessage *mm, uint32_t block, uint32_t 
  * order the reference does; the --stats counters land where the reference prints them from. */
 static void modesGpuResolve(void) {
     modes_host_stats st;
+    /* the ICAO whitelist's 60 s TTL (dump1090.c:913,924) runs on the caller's clock in libmodes_host: this host also
+     * serves live input (RTL-SDR, --loop, a pipe), so it advances with the wall clock like the reference's does.
+     * (Frames that arrive over the raw TCP input port go through the reference's own decodeModesMessage and its own
+     * Modes.icao_cache - a second whitelist; INTEGRATION.md says what that means.) */
+    modes_host_set_time(dropin_host, (int64_t)time(NULL));
     modes_host_resolve(dropin_host, dropin_res.records, dropin_res.n_records, dropin_res.candidates,
                        dropin_res.n_candidates, dropin_sink, NULL);
     modes_host_get_stats(dropin_host, &st);

@@ -225,6 +225,7 @@ class SparseFrameStream:
         self.seed, self.nbytes, self.sigma_q16 = seed, nbytes, sigma_q16
         self.placements = sorted(placements, key=lambda p: p[0])
         self._starts = np.array([p[0] for p in self.placements], dtype=np.int64)
+        assert len(self._starts) < 2 or int(np.diff(self._starts).min()) >= self.SPAN, "frames overlap"
 
     def window(self, lo: int, hi: int) -> np.ndarray:
         """Bytes [lo, hi) of the stream (lo even)."""
@@ -257,6 +258,40 @@ class SparseFrameStream:
                 if first[k] + width > tail:
                     data[k, max(0, tail - int(first[k])):] = 127
         return first, data
+
+    def deltas(self):
+        """-> (first_byte int64[n], delta int16[n, 2*SPAN]): what every frame ADDS to the noise under its footprint
+        (interleaved dI, dQ per sample; the byte is clip(noise + delta, 0, 255): add_frame's arithmetic).  No hash in
+        here, so the frames of a 64 GiB stream take seconds instead of a minute: the device, which already holds the
+        noise, applies them (bench.py:build_frames_shard, tests: build_on_device).  Bytes past the end of the stream
+        and the 127-tail are the caller's business."""
+        n = len(self.placements)
+        first = 2 * self._starts
+        width = 2 * self.SPAN
+        delta = np.zeros((n, width), dtype=np.int16)
+        for lo in range(0, n, 32768):
+            hi = min(n, lo + 32768)
+            m = hi - lo
+            fr = np.zeros((m, 14), dtype=np.uint8)
+            nbits = np.empty(m, dtype=np.int64)
+            for k in range(m):
+                f = self.placements[lo + k][1]
+                fr[k, :len(f)] = np.frombuffer(f, dtype=np.uint8)
+                nbits[k] = 8 * len(f)
+            bits = np.unpackbits(fr, axis=1).astype(np.int32)                    # (m, 112), MSB first
+            live = (np.arange(112)[None, :] < nbits[:, None]).astype(np.int32)
+            e = np.zeros((m, self.SPAN + 1), dtype=np.int32)                     # frame_envelope, one row per frame
+            e[:, [0, 2, 7, 9]] = 1
+            e[:, 16:16 + 224:2] = bits * live
+            e[:, 17:17 + 224:2] = (1 - bits) * live
+            amp = np.array([p[2] for p in self.placements[lo:hi]], dtype=np.int32)[:, None]
+            phase = np.array([p[3] for p in self.placements[lo:hi]], dtype=np.int64)
+            sm = np.array([p[4] for p in self.placements[lo:hi]], dtype=np.int32)[:, None]
+            prev = np.concatenate([np.zeros((m, 1), dtype=np.int32), e[:, :-1]], axis=1)
+            a = ((amp * ((16 - sm) * e + sm * prev)) >> 4)[:, :self.SPAN]       # add_frame's amplitude per sample
+            delta[lo:hi, 0::2] = (a * COS64[phase & 63][:, None].astype(np.int32) + 512) >> 10
+            delta[lo:hi, 1::2] = (a * SIN64[phase & 63][:, None].astype(np.int32) + 512) >> 10
+        return first, delta
 
 
 def config3_stream(seed: int, nblocks: int, *, per: int = 65536, sigma_q16: int = 941, amp=(40, 100),
@@ -299,6 +334,15 @@ def config3_stream(seed: int, nblocks: int, *, per: int = 65536, sigma_q16: int 
         sm = smear[(h >> 52) % len(smear)]
         placements.append((o, bytes(fb), int(a), int((h >> 56) & 63), int(sm)))
         clean[o] = make_frame(df, bytes(pay))
+    # Frames must not overlap (SparseFrameStream): of two whose footprints touch - a seam frame can land next to the
+    # regular frame of the slot it falls into - the LATER one is dropped.  Decided on the raw placements, so a rank that
+    # builds only its own part (only_samples) drops the same frames as the whole stream does.
+    placements.sort(key=lambda p: p[0])
+    starts = [p[0] for p in placements]
+    dropped = {starts[i] for i in range(1, len(starts)) if starts[i] - starts[i - 1] < SparseFrameStream.SPAN}
+    if dropped:
+        placements = [p for p in placements if p[0] not in dropped]
+        clean = {o: f for o, f in clean.items() if o not in dropped}
     if only_samples is not None:
         keep = [p for p in placements if p[0] + SparseFrameStream.SPAN > only_samples[0] and p[0] < only_samples[1]]
         clean = {p[0]: clean[p[0]] for p in keep}

@@ -63,3 +63,52 @@ def test_listing_check_rejects_a_damaged_listing(small):
         bench.check_listing(join(lines[half:] + lines[:half]), expected)        # two ranks' lists swapped
     with pytest.raises(AssertionError, match="lines for"):
         bench.check_listing(join(lines + lines), expected)                      # every list delivered twice
+
+
+def test_listing_check_rejects_lines_that_are_no_frame_of_the_stream(small):
+    st, data, text = small
+    expected = bench.frames_expectation(st, 0, block_count(st.nbytes))
+    lines = text.decode().split()
+    join = lambda ls: ("\n".join(ls) + "\n").encode()
+    ok = bench.check_listing(join(lines), expected)
+    assert ok["spurious"] <= 2 and ok["missing"] == 0
+    junk = ["*5d%06x%06x;" % (k, k * 7919) for k in range(3)]
+    with pytest.raises(AssertionError, match="no frame of the stream"):
+        bench.check_listing(join(lines[:50] + junk + lines[50:]), expected)         # three invented messages: inside every other bound
+    bench.check_listing(join(lines[:50] + junk[:2] + lines[50:]), expected)          # a noise-born message or two do occur
+
+
+def test_launcher_command_is_the_documented_one():
+    cmd = bench.launcher_command(["--gpus", "8", "--steps", "20", "--warmup", "5"], 8, port=29999)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29999"
+    at = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[at + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    auto = bench.launcher_command([], 2)
+    assert 1024 < int(auto[auto.index("--master-port") + 1]) < 65536
+
+
+def test_self_launch_propagates_the_ranks_status(tmp_path):
+    """bench.py --gpus 2 without WORLD_SIZE re-runs itself under torch.distributed.run; here (no GPU) both ranks fail their
+    `needs a GPU` assertion at once - the parent must end non-zero and print no line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_bench.py runs the launcher for real")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"], capture_output=True,
+                       timeout=300, env=env)
+    assert p.returncode != 0
+    assert b"needs a GPU" in p.stderr and not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_committed_reference_listings_cover_the_default_runs():
+    """Every stream a default `bench.py --gpus N` (N = 1, 2, 4, 8) resolves has the reference's own verdict committed."""
+    for n in (1, 2, 4, 8):
+        g = bench.golden_listing("frames", 3 if n == 1 else 4, 32768 * n)
+        assert g and len(g["md5"]) == 32 and g["lines"] > 65000 * n
+        low = bench.golden_listing("lowsnr", 5, 4096 * n)
+        assert low and low["lines"] > 2000 * n and "--aggressive" in low["flags"]
+    assert bench.golden_listing("frames", 4, 262144)["lines"] > 520000          # the strong-scaling leg's stream at every N
+    assert bench.golden_listing("frames", 3, 32768)["md5"] == "71d130a9532b26ccef50568cc9966b53"   # = tests/golden/config2_listing.json

@@ -12,6 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--mib", "128", "--frames-mib", "256", "--steps", "3", "--warmup", "1", "--settle", "4", "--frames-steps", "3",
+         "--lowsnr-mib", "128", "--lowsnr-steps", "3", "--frames-total-mib", "512", "--strong-steps", "2",
          "--no-cpu-baseline", "--no-end-to-end"]
 
 
@@ -27,7 +28,14 @@ def check(j, n_gpus):
     f = j["frames"]
     lc = f["listing_check"]
     assert lc["missing"] == 0 and lc["lines"] >= lc["expected_frames"] > 0.9 * 256 * n_gpus * 2 ** 20 / 2 / 65536
-    assert f["msgs_per_step"] == lc["lines"]
+    assert f["msgs_per_step"] == lc["lines"] and lc["spurious"] <= 2
+    low, strong = j["lowsnr"], j["frames_strong"]
+    assert low["listing_check"]["lines"] > 50 and low["kernel_ms"]["demod"] > 0          # the weak frames do decode
+    assert strong["scaling"] == "strong" and strong["listing_check"]["missing"] == 0
+    assert strong["listing_check"]["expected_frames"] > 0.9 * 512 * 2 ** 20 / 2 / 65536     # the same stream at every N
+    ceil = j["roofline"]["measured_ceiling"]
+    assert ceil["GB_per_s"] > j["roofline"]["achieved"] * 0.9 and j["roofline"]["frac_of_measured_ceiling"] > 0.05
+    assert j["detect_us_per_call"]["launch_scan"] > 0
     if "one_launch_stream" in j:
         one = j["one_launch_stream"]
         k = j["kernel_ms"]
@@ -39,6 +47,34 @@ def test_bench_small_single_rank(extra):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, capture_output=True, timeout=600)
     assert p.returncode == 0, p.stderr[-1500:]
     check(parse(p.stdout), 1)
+
+
+def test_force_gather_runs_point_to_point_over_rccl():
+    """One rank, the N > 1 path: the count all_gather AND the list transfers (the root's list through isend / irecv to
+    itself) execute over RCCL on the GPU at hand; bench.py compares what arrived with what was sent."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--force-gather", "--workload", "frames", "--steps", "3"],
+                       capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-1500:]
+    j = parse(p.stdout)
+    r = j["rccl"]
+    assert r["backend"] == "RCCL" and r["p2p_ops_per_step"] == 2 and r["bytes_gathered_per_step"] > 64 * 1000 and r["gather_ms"] > 0
+    assert j["listing_check"]["missing"] == 0
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command) starts two ranks itself
+    and prints one line; a failing rank makes the whole command fail."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + SMALL,
+                       capture_output=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-1500:]
+    j = parse(p.stdout)
+    check(j, 2)
+    assert j["frames"]["rccl"]["nranks"] == 2 and j["frames"]["rccl"]["p2p_ops_per_step"] >= 1
+    assert len(j["kernel_ms_per_rank"]) == 2
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "no-such-backend"] + SMALL,
+                         capture_output=True, timeout=300, env=env)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.decode().splitlines() if ln.startswith("{")]
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo():

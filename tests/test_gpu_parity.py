@@ -35,7 +35,7 @@ def test_native_library_is_loaded(torch_cuda):
     maps = open("/proc/self/maps").read()
     assert os.path.realpath(N.GPU_LIB) in maps, "libmodes_gfx950.so is not mapped"
     assert os.path.realpath(N.HOST_LIB) in maps, "libmodes_host.so is not mapped"
-    assert N.gpu_lib().modes_gpu_abi_version() == 3
+    assert N.gpu_lib().modes_gpu_abi_version() == 4
     r.close()
     d.close()
 

@@ -250,3 +250,35 @@ def test_multithreaded_resolve_rejects_wrong_guesses():
     assert mt.raw_listing(recs, None, threads=-2) == want
     seq.close()
     mt.close()
+
+
+def test_a_listing_that_outgrows_its_buffer_is_cut_at_a_line(streams):
+    """include/modes_host.h: when the listing is longer than `cap`, *nbytes still reports the whole length and out holds
+    whole lines only, as many as fit - the same for the one-thread and the multi-threaded resolve (which used to copy
+    later, smaller pieces behind a gap)."""
+    flags = orc.FLAGSETS["default"]
+    recs, _ = oracle_records(streams["frames"], maxfix_of(flags))
+    seq = HostResolver(**flags)
+    n0, text0 = seq.raw_listing(recs, None)
+    seq.close()
+    assert n0 > 20
+    lib = N.host_lib()
+    for cap in (len(text0) // 2, len(text0) // 3 + 7, 40, 1):
+        for pieces in (0, 3, 7):
+            h = HostResolver(**flags)
+            buf = C.create_string_buffer(b"\xee" * (len(text0) + 64), len(text0) + 64)
+            nb = C.c_uint64()
+            if pieces:
+                n = lib.modes_host_resolve_raw_mt(h._h, recs.ctypes.data, recs.size, buf, cap, C.byref(nb), -pieces)
+            else:
+                n = lib.modes_host_resolve_raw(h._h, recs.ctypes.data, recs.size, None, 0, buf, cap, C.byref(nb))
+            h.close()
+            assert (int(n), nb.value) == (n0, len(text0)), (cap, pieces)
+            stored = buf.raw[:cap].split(b"\x00")[0]
+            assert text0.startswith(stored) and (stored == b"" or stored.endswith(b"\n")), (cap, pieces, stored[-40:])
+            assert len(stored) <= cap - 1 or cap <= 1
+            assert buf.raw[cap:cap + 8] == b"\xee" * 8, "wrote past cap"
+            if pieces:
+                # as many whole lines as fit: the next line would not have
+                nxt = text0[len(stored):].split(b"\n")[0] + b"\n"
+                assert len(stored) + len(nxt) + 1 > cap, (cap, pieces)

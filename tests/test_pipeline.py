@@ -27,6 +27,9 @@ class OracleDetector:
 
     def fetch_device(self):
         recs, _, info = self.fetch()
+        if self.out is not None and recs.size > self.out[0].numel() // 64:
+            from dump1090_amd._native import ModesError
+            raise ModesError(-4, "%d records exceed max_records=%d" % (recs.size, self.out[0].numel() // 64))
         return recs.size, info
 
     def detect(self, iq, stream_byte0=0, first_block=0, nblocks=None, stream=None):
@@ -41,7 +44,8 @@ class OracleDetector:
             import torch
             recs = self.fetch()[0]
             self.span = (first_block, nblocks)
-            self.out[0][: recs.size * 64] = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy())
+            fit = min(recs.size, self.out[0].numel() // 64)     # like the kernels: the true count, no store past the capacity
+            self.out[0][: fit * 64] = torch.from_numpy(recs[:fit].view(np.uint8).reshape(-1).copy())
             self.out[1][0] = recs.size
 
     def fetch(self, copy=True):
@@ -149,3 +153,51 @@ def test_two_ranks_same_communication_order(tmp_path, golden, case, ncalls, dept
     copied: the ranks' sequences of communication calls must not diverge."""
     _spawn2((2, _free_port(), case, ncalls, depth, str(tmp_path), True, slow, lag))
     assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
+
+
+def _run_overflow(rank, world, port, outdir, inplace):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import synth
+    import torch.distributed as dist
+    from dump1090_amd import block_count, shard_blocks, shard_byte_range
+    from dump1090_amd._native import ModesError
+    from dump1090_amd.pipeline import run_steps, split_calls
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    # frames only in the LAST rank's buffers: rank 1's list outgrows the gather buffers, rank 0's is empty
+    data = synth.case_noise(seed=18, nblocks=6)
+    data[4 * 262144: 6 * 262144] = synth.case_frames(seed=15, nblocks=2)
+    total = block_count(data.size)
+    first, n = shard_blocks(total - 1, world, rank)
+    if rank == world - 1:
+        n += 1
+    lo, hi = shard_byte_range(first, n, data.size)
+    calls = split_calls(first, n, 1, lo, data.size)
+    verdict = "no error"
+    try:
+        run_steps(lambda: OracleDetector(data, 1, cpu_output=inplace), data[lo:hi], lo, calls, dict(fix=True, aggressive=False), steps=2,
+                  warm=1, depth=3, world=world, rank=rank, dist=dist, coll_device="cpu", cap_records=8)
+    except ModesError as e:
+        verdict = "ModesError %d: %s" % (e.code, e)
+    with open(os.path.join(outdir, "rank%d.txt" % rank), "w") as f:
+        f.write(verdict)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("inplace", [False, True])
+def test_a_list_that_outgrows_the_gather_buffers_fails_every_rank(tmp_path, inplace):
+    """One rank's record list does not fit the gather buffers: the job must END - every rank raising the same overflow
+    from the shared check behind the count exchange - instead of the other ranks waiting in an all_gather the
+    overflowing rank never joins (until the watchdog fires)."""
+    import time
+    ctx = mp.spawn(_run_overflow, args=(2, _free_port(), str(tmp_path), inplace), nprocs=2, join=False)
+    t0 = time.time()
+    while not ctx.join(timeout=2.0):
+        if time.time() - t0 > 120:
+            for p in ctx.processes:
+                p.terminate()
+            pytest.fail("the ranks hung on a one-sided overflow")
+    for r in (0, 1):
+        text = open(tmp_path / ("rank%d.txt" % r)).read()
+        assert text.startswith("ModesError -4") and "rank 1 produced" in text, (r, text)
