@@ -162,14 +162,16 @@ template <int THREADS>
 __device__ __forceinline__ void stage_lut(uint16_t *s_lut, const uint16_t *lut) {
     const uint4 *src = reinterpret_cast<const uint4 *>(lut);
     uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
-    static_assert(kLutVec % (4 * THREADS) == 0, "whole batches");
+    constexpr bool kWhole = kLutVec % (4 * THREADS) == 0;                     // no bounds test needed
 #pragma unroll 1
     for (int i = (int)threadIdx.x; i < kLutVec; i += 4 * THREADS) {
         uint4 v[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = src[i + k * THREADS];
+        for (int k = 0; k < 4; k++)
+            if (kWhole || i + k * THREADS < kLutVec) v[k] = src[i + k * THREADS];
 #pragma unroll
-        for (int k = 0; k < 4; k++) dst[i + k * THREADS] = v[k];
+        for (int k = 0; k < 4; k++)
+            if (kWhole || i + k * THREADS < kLutVec) dst[i + k * THREADS] = v[k];
     }
 }
 
@@ -998,9 +1000,10 @@ __device__ __forceinline__ Front demod_front(const DemodParams &P, const Lut lut
 
 // Full demodulation (both attempts) -> the record in staging slot `slot`, keyed `key`.  Returns false when the first
 // noise gate fails after all (then nothing is written; the caller has already ruled that out for its entries).
-template <bool GUARD, class Lut>
+template <bool GUARD, bool KEYED = true, class Lut>
 __device__ __forceinline__ bool demod_full(const DemodParams &P, const Lut lut, const uint32_t *s_esyn, int lane, int64_t pc,
-                                           uint32_t known56, uint32_t known112, uint32_t slot, uint64_t key) {
+                                           uint32_t known56, uint32_t known112, uint32_t slot, uint64_t key,
+                                           modes_record *host_rec = nullptr) {
     const uint64_t g = (uint64_t)pc + P.g0;
     const uint32_t j = (uint32_t)(g & (MODES_BLOCK_STRIDE - 1));
     const bool two = lane < 48;
@@ -1054,13 +1057,14 @@ __device__ __forceinline__ bool demod_full(const DemodParams &P, const Lut lut, 
     // syndromes and repair positions: the whole wavefront, both attempts (wave-uniform results)
     const AttemptFix f0 = wave_finish_attempt(bits0, true, P.maxfix, lane, s_esyn);
     const AttemptFix f1 = wave_finish_attempt(bits1, gate1, P.maxfix, lane, s_esyn);
-    if (lane == 0 && slot < P.max_records) {
-        modes_record *rec = &P.staging[slot];
+    // lane 0 writes the record; with a host copy to fill (record_kernel, short lists) lane 1 writes the same values there
+    if (lane < (host_rec ? 2 : 1) && slot < P.max_records) {
+        modes_record *rec = lane == 0 ? &P.staging[slot] : host_rec;
         rec->block = (uint32_t)(g / MODES_BLOCK_STRIDE);
         rec->j = j;
         store_attempt(&rec->att[0], bits0, err0, true, f0);
         store_attempt(&rec->att[1], bits1, err1, gate1, f1);
-        P.keys[slot] = key;
+        if (KEYED && lane == 0) P.keys[slot] = key;
     }
     return true;
 }
@@ -1085,11 +1089,8 @@ __device__ __forceinline__ bool demod_full(const DemodParams &P, const Lut lut, 
 // Lists live in LDS; appends from stages 2a/2b reserve their slots with one LDS atomic per wavefront.
 // finalize_kernel (one workgroup, next in the stream) turns the per-batch record counts into offsets.
 // ------------------------------------------------------------------------------------
-// kMinWaves: wavefronts per SIMD the register allocation must leave room for (amdgpu_waves_per_eu): 4 = whatever the code
-// needs (~120 VGPRs, stage 3 sets it); 6 = at most 80 VGPRs (stage 3 spills a few values to scratch) - then a wavefront of
-// this kernel fits into the registers the scan kernel's six 56-VGPR wavefronts leave free on every SIMD.
-template <int kDemodWaves, class Lut, int kMinWaves = 4>
-__global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(kMinWaves))) void demod_kernel(DemodParams P) {
+template <int kDemodWaves, class Lut>
+__global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80))) void demod_kernel(DemodParams P) {
     constexpr int kDemodThreads = kDemodWaves * 64;
     constexpr int kGatePerRound = kDemodThreads / kGateLanes;   // preambles a workgroup tests per round
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[Lut::kEntries];
@@ -1377,6 +1378,449 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
 }
 
 // ------------------------------------------------------------------------------------
+// The demodulation in TWO kernels (demod_variant 0, production from round 3):
+//
+//   select_kernel   stages 1 and 2 for EVERY forwarded position - the exact preamble predicate and the noise-gate
+//                   pre-test - and nothing else: on noise that is all there is to do (~270,000 preambles per GiB, none of
+//                   which survives).  16-wave workgroups held to 64 VGPRs: two of them (32 wavefronts) per CU share the
+//                   two 64 KiB tables, twice the wavefronts per CU of demod_kernel, whose register count the record
+//                   stage sets - the stage is bound by how many wavefronts wait on its gathers at once.  The survivors
+//                   of a batch leave as a position list in ascending order.
+//   record_kernel   stage 3 for the survivors only: one wavefront per record, written straight to its FINAL place in the
+//                   ordered list (every workgroup derives the batch offsets from the batch counts itself: no staging
+//                   list, no keys, no order kernel).  A workgroup whose batches have no survivor retires before it
+//                   stages a table: on noise the kernel is a few microseconds.
+//
+// demod_kernel (one kernel, stage 3 inline, staging + keys + order) stays as demod_variant 1: the independent second
+// implementation the parity tests cross-check.
+// ------------------------------------------------------------------------------------
+constexpr int kSelWaves = 16;
+constexpr int kSelThreads = kSelWaves * 64;
+constexpr int kSelLanes = 8;                               // lanes per preamble in the gate pre-test
+constexpr int kSelPerRound = kSelThreads / kSelLanes;      // 128 preambles per round
+constexpr int kSelAhead = 2;                               // rounds whose loads are in flight together (640 preambles: a noise batch has ~530)
+// s_flag values (per preamble of the block); LONG carries the first half's delta sum in its low 22 bits (<= 56 * 65167)
+constexpr uint32_t kSelFail = 0u, kSelPass = 1u << 30, kSelEdge = 2u << 30, kSelLong = 3u << 30, kSelKind = 3u << 30;
+
+struct SelectParams {
+    const uint8_t *iq;
+    int64_t lo, hi;
+    uint32_t nruns, run_chunks, slot_cap;
+    const uint32_t *slots;      // [nruns][slot_cap] forwarded positions, ascending per run (scan kernel)
+    const uint32_t *counts;     // [nruns]
+    const uint16_t *lut;
+    uint32_t *cand_slots;       // [nbatches][kDemodGroup * slot_cap] preamble positions (keep_candidates) or nullptr
+    uint32_t *cand_counts;      // [nbatches]
+    uint32_t *surv;             // [nbatches][kDemodGroup * slot_cap] survivor positions of each batch, ascending
+    uint32_t *batch_count;      // [nbatches] survivors = records of each batch
+    uint32_t nbatches;
+    WgTotals *totals;           // [gridDim.x]
+};
+
+// 56 bit pairs = 224 bytes from byte offset voff (2-byte aligned: a sample is two bytes) by a group of 8 lanes: lane t takes
+// pairs 7t .. 7t + 6.  The loads are DWORD-ALIGNED - eight dwords from (voff + 28 t) rounded down to a dword, as two x4 loads -
+// and an odd sample offset is taken out afterwards with one v_alignbit per pair (2-byte-misaligned loads keep the texture
+// addresser busy ~47 cycles per wave instruction: TA_BUSY 63 % of the kernel, profiles/r05; aligned, the stage is ~1 us
+// shorter - it is bound by the lines it pulls from HBM either way).
+__device__ __forceinline__ void sel_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, int t, uint32_t (&d)[8]) {
+    const uint32_t o = (voff + 28u * (uint32_t)t) & ~3u;
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, kDemodAux), b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 16u, 0, kDemodAux);
+    d[0] = a[0]; d[1] = a[1]; d[2] = a[2]; d[3] = a[3]; d[4] = b[0]; d[5] = b[1]; d[6] = b[2]; d[7] = b[3];
+}
+// pair k of the lane: the dword at 2-byte phase `sh16` (0 or 16 bits) inside d[k], d[k + 1]
+__device__ __forceinline__ uint32_t sel_dword(const uint32_t (&d)[8], int k, uint32_t sh16) {
+    return __builtin_amdgcn_alignbit(d[k + 1], d[k], sh16);
+}
+// Table address of both samples of a pair (dword I0 Q0 I1 Q1) by the scan kernel's byte dot product (power16_scan):
+// x = w ^ 0x7f7f7f7f holds the signed bytes 127 - b; v_dot4_i32_i8 of x with x masked to one sample, clamped against the
+// accumulator 0x7fff8000, is 0x7fff0000 | 0x8000 | min(s, 32767); shifted left by one that is 0xffff0000 + 2 s (mod 2^32), so
+// adding (table base + 0x10000) gives the LDS byte address of entry s - five instructions per pair before the two
+// shift-adds, three of them full rate (the packed multiply / multiply-add form: six, one full rate, plus wait states).
+__device__ __forceinline__ void sel_pair(uint32_t w, uint32_t lut_adj, uint32_t &a, uint32_t &b) {
+    const uint32_t x = w ^ 0x7f7f7f7fu;
+    const uint32_t pa = (uint32_t)__builtin_amdgcn_sdot4((int)x, (int)(x & 0x0000ffffu), 0x7fff8000, true);
+    const uint32_t pb = (uint32_t)__builtin_amdgcn_sdot4((int)x, (int)(x & 0xffff0000u), 0x7fff8000, true);
+    // (an LDS pointer is its 32-bit byte address)
+    a = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)((pa << 1) + lut_adj));
+    b = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)((pb << 1) + lut_adj));
+}
+// sum over the 8 lanes of a group, in every lane of it: quad butterflies, then the mirrored half row (lane i <-> 7 - i
+// swaps the two quads, whose lanes all hold their quad's sum by then) - three DPP adds, no LDS round trip
+__device__ __forceinline__ uint32_t sel_reduce8(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);    // row_half_mirror
+    return v;
+}
+// This lane's part of the delta sum of the group's 56 pairs (its seven).  *first (FLAGS: meaningful in the group's lane 0, which
+// holds pairs 0 .. 6): bit k = |lo - hi| < 256 of pair k, bit 8 + k = lo > hi, k = 0 .. 5; bit 16 = (lo == hi) of pair 0.
+template <bool FLAGS>
+__device__ __forceinline__ uint32_t sel_sum(const uint32_t (&d)[8], uint32_t sh16, uint32_t lut_adj, uint32_t *first) {
+    uint32_t acc = 0, f = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        uint32_t a, b;
+        sel_pair(sel_dword(d, k, sh16), lut_adj, a, b);
+        if (FLAGS && k < 6) {
+            const uint32_t dd = __builtin_amdgcn_sad_u16(a, b, 0u);
+            f |= (dd < 256u ? 1u : 0u) << k | (a > b ? 1u : 0u) << (8 + k);
+            if (k == 0) f |= (a == b ? 1u : 0u) << 16;
+            acc += dd;
+        } else {
+            acc = __builtin_amdgcn_sad_u16(a, b, acc);
+        }
+    }
+    if (FLAGS) *first = f;
+    return acc;
+}
+
+__global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void select_kernel(SelectParams P) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[MODES_LUT_ENTRIES];
+    __shared__ uint32_t s_pre[kDemodGroup + 1];        // exclusive prefix of the batch's (clamped) run counts
+    __shared__ uint32_t s_list[kSelThreads];           // preamble positions of the block, ASCENDING
+    __shared__ uint32_t s_flag[kSelThreads];           // their state (kSel*)
+    __shared__ uint16_t s_work[kSelThreads];           // indices into s_list: the long ones, then (from the top) the edge ones
+    __shared__ uint32_t s_wcnt[kSelWaves + 1];         // per-wavefront counts -> exclusive prefix
+    __shared__ uint32_t s_n[2];                        // [0] long ones, [1] edge ones of the block
+    __shared__ uint32_t s_flags;                       // WgTotals.flags bits
+    __shared__ unsigned long long s_fwd;
+#ifdef MODES_TRACE
+    const unsigned long long t_start = wall_clock64();
+    unsigned long long tr_t[4] = {0, 0, 0, 0};          // batch set-up, stage 1 (+ compaction), stage 2a, stage 2b + edge + write-out
+#endif
+    stage_lut<kSelThreads>(s_lut, P.lut);              // (staged UNDER the first batch's position loads instead: 7 us longer - the
+                                                       //  table's loads queue behind them; profiles/r05)
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) { s_flags = 0; s_fwd = 0; s_n[0] = 0; s_n[1] = 0; }
+    __syncthreads();
+#ifdef MODES_TRACE
+    const unsigned long long t_lut = wall_clock64();
+#endif
+    const uint8_t *iq = P.iq;
+    const int64_t lo = P.lo, hi = P.hi;
+    const uint64_t below = (1ull << lane) - 1;
+    const uint32_t lut_adj = (uint32_t)reinterpret_cast<uintptr_t>(s_lut) + 0x10000u;     // sel_pair: LDS byte address of the table, adjusted
+    unsigned long long tot_fwd = 0, tot_cand = 0;      // tot_fwd: per lane of wavefront 0; tot_cand: workgroup-uniform
+
+    for (uint32_t batch = blockIdx.x; batch < P.nbatches; batch += gridDim.x) {
+        const uint32_t run0 = batch * kDemodGroup;
+        TRACE_T(tb0);
+        const int64_t gbase = (int64_t)run0 * P.run_chunks * kChunkSamples - 64;     // every position of the batch is >= gbase
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(iq) + 2 * gbase, 0, 0x7fffffff, 0x00020000);
+        if (wave == 0) {                                                     // one run per lane
+            uint32_t cnt = 0;
+            if (run0 + lane < P.nruns) {
+                const uint32_t true_count = P.counts[run0 + lane];
+                if (true_count > P.slot_cap) atomicOr(&s_flags, 1u);           // the scan dropped positions: the call fails
+                cnt = min(true_count, P.slot_cap);
+                tot_fwd += true_count;
+            }
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            s_pre[lane] = incl - cnt;
+            if (lane == 63) s_pre[64] = incl;
+        }
+        __syncthreads();
+        const uint32_t n = s_pre[kDemodGroup];
+        const uint64_t list_base = (uint64_t)batch * kDemodGroup * P.slot_cap;   // of the batch's candidate and survivor lists
+        uint32_t ncand = 0, prior = 0;
+        auto slot_of = [&](uint32_t e) -> uint32_t {
+            uint32_t rr = 0;
+#pragma unroll
+            for (int step = kDemodGroup / 2; step >= 1; step >>= 1)
+                if (s_pre[rr + step] <= e) rr += step;
+            return P.slots[(uint64_t)(run0 + rr) * P.slot_cap + (e - s_pre[rr])];
+        };
+        // exclusive prefix of one count per wavefront over the workgroup: -> (this wavefront's base, total); two barriers
+        auto wave_prefix = [&](uint32_t mine, uint32_t *total) -> uint32_t {
+            if (lane == 0) s_wcnt[wave] = mine;
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < kSelWaves; w++) {
+                const uint32_t c = s_wcnt[w];
+                before += w < wave ? c : 0u;
+                all += c;
+            }
+            __syncthreads();
+            *total = all;
+            return before;
+        };
+        uint32_t p_next = (uint32_t)tid < n ? slot_of((uint32_t)tid) : 0u;
+        TRACE_ADD(0, tb0);
+        for (uint32_t base = 0; base < n; base += kSelThreads) {
+            TRACE_T(ts1);
+            // ---------------- stage 1: the exact predicate, survivors compacted IN ORDER ----------------
+            const uint32_t e = base + (uint32_t)tid;
+            const bool active = e < n;
+            const uint32_t p = p_next;
+            p_next = e + kSelThreads < n ? slot_of(e + kSelThreads) : 0u;
+            const bool in1 = !active || samples_inside((int64_t)p, (int64_t)p + 15, lo, hi);
+            bool ok;
+            const LutFull lut{s_lut};
+            if (__all(in1)) ok = active && preamble_at_fast(rsrc, (uint32_t)(2 * ((int64_t)p - gbase)), lut);
+            else            ok = active && preamble_at_guarded(iq, lo, hi, lut, p);
+            // (two samples of slack behind the message window: the pre-test's dword-aligned loads read up to four bytes past it)
+            const bool whole = samples_inside((int64_t)p - 1, (int64_t)p + 241, lo, hi);
+            const uint64_t okb = __ballot(ok);
+            uint32_t nlist;
+            const uint32_t wbase = wave_prefix((uint32_t)__builtin_popcountll(okb), &nlist);
+            if (ok) {
+                const uint32_t c = wbase + (uint32_t)__builtin_popcountll(okb & below);
+                s_list[c] = p;
+                s_flag[c] = whole ? kSelFail : kSelEdge;
+                if (P.cand_slots) P.cand_slots[list_base + ncand + c] = p;
+            }
+            // the few next to an end of the span (their message window is not all inside): a list of their own
+            const uint64_t edgeb = __ballot(ok && !whole);
+            if (edgeb) {                                                      // wave-uniform, rare
+                uint32_t eb = 0;
+                if (lane == 0) eb = atomicAdd(&s_n[1], (uint32_t)__builtin_popcountll(edgeb));
+                eb = (uint32_t)__builtin_amdgcn_readfirstlane((int)eb);
+                if (ok && !whole) s_work[kSelThreads - 1 - (eb + (uint32_t)__builtin_popcountll(edgeb & below))] =
+                    (uint16_t)(wbase + (uint32_t)__builtin_popcountll(okb & below));
+            }
+            __syncthreads();
+            ncand += nlist;
+            TRACE_ADD(1, ts1);
+            TRACE_T(ts2);
+            // ---------------- stage 2a: the first 56 pairs and the DF of the first slicing pass, 8 lanes per preamble ----------------
+            const int grp = tid / kSelLanes, t = tid % kSelLanes;
+            const int head = lane & ~(kSelLanes - 1);
+            // The loads of kSelAhead rounds are issued together.  (It hardly matters - 1, 2, 3, 5 or 9 rounds in flight, 4 or 8 lanes
+            // per preamble, 8, 12 or 16 wavefronts, half the instructions: the stage takes 11-17 us for a 1 GiB call and 2 us
+            // when only 64 workgroups run.  What it waits for is HBM: ~2.75 lines of 128 B per preamble, 95 MB per GiB of noise
+            // at the ~6.5 TB/s the chip streams: DESIGN.md 3.2, profiles/r05.)
+            for (uint32_t s0 = 0; s0 < nlist; s0 += kSelAhead * kSelPerRound) {
+                uint32_t w[kSelAhead][8];
+                uint32_t sh[kSelAhead];
+                bool act[kSelAhead];
+#pragma unroll
+                for (int r = 0; r < kSelAhead; r++) {
+                    const uint32_t c = s0 + (uint32_t)r * kSelPerRound + (uint32_t)grp;
+                    act[r] = c < nlist && s_flag[c < nlist ? c : 0] != kSelEdge;
+                    const uint32_t pc = act[r] ? s_list[c] : 0u;
+                    const uint32_t voff = (uint32_t)(2 * ((int64_t)pc - gbase)) + 32u;
+                    sh[r] = ((voff + 28u * (uint32_t)t) & 2u) << 3;          // 16 when the lane's first pair starts in the middle of a dword
+#pragma unroll
+                    for (int k = 0; k < 8; k++) w[r][k] = 0;
+                    if (act[r]) sel_load(rsrc, voff, t, w[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < kSelAhead; r++) {
+                    if (s0 + (uint32_t)r * kSelPerRound >= nlist) break;      // workgroup-uniform
+                    const uint32_t c = s0 + (uint32_t)r * kSelPerRound + (uint32_t)grp;
+                    const bool gact = act[r];
+                    uint32_t first = 0, d56 = 0;
+                    if (gact) d56 = sel_sum<true>(w[r], sh[r], lut_adj, &first);
+                    d56 = sel_reduce8(d56);
+                    const uint32_t f0 = (uint32_t)__shfl((int)first, head, 64);   // pairs 0 .. 5 live in the group's first lane
+                    const bool is_long = modes_len_by_df(modes_df_first6(f0 & 0x3fu, (f0 >> 8) & 0x3fu, ((f0 >> 16) & 1u) != 0)) == 112;
+                    const bool mine = gact && t == 0;
+                    if (mine && !is_long) s_flag[c] = d56 / 28 >= 2550 ? kSelPass : kSelFail;     // dump1090.c:1717-1723, short message
+                    const bool more = mine && is_long;
+                    const uint64_t mb = __ballot(more);
+                    if (mb) {                                                 // wave-uniform
+                        uint32_t qb = 0;
+                        if (lane == 0) qb = atomicAdd(&s_n[0], (uint32_t)__builtin_popcountll(mb));
+                        qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+                        if (more) {
+                            s_work[qb + (uint32_t)__builtin_popcountll(mb & below)] = (uint16_t)c;
+                            s_flag[c] = kSelLong | d56;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            TRACE_ADD(2, ts2);
+            TRACE_T(ts3);
+            // ---------------- stage 2b: the other 56 pairs of the long ones ----------------
+            const uint32_t nlong = s_n[0], nedge = s_n[1];
+            for (uint32_t c0 = 0; c0 < nlong; c0 += kSelPerRound) {
+                const uint32_t k = c0 + (uint32_t)grp;
+                const bool gact = k < nlong;
+                const uint32_t c = gact ? s_work[k] : 0u;
+                const uint32_t pc = s_list[c];
+                uint32_t d = 0;
+                if (gact) {
+                    uint32_t w[8];
+                    const uint32_t voff = (uint32_t)(2 * ((int64_t)pc - gbase)) + 32u + 224u;
+                    sel_load(rsrc, voff, t, w);
+                    d = sel_sum<false>(w, ((voff + 28u * (uint32_t)t) & 2u) << 3, lut_adj, nullptr);
+                }
+                d = sel_reduce8(d);
+                if (gact && t == 0) s_flag[c] = (d + (s_flag[c] & ~kSelKind)) / 56 >= 2550 ? kSelPass : kSelFail;   // :1717-1723, long message
+            }
+            // ---------------- the edge ones: first slicing pass and gate with guarded loads, a wavefront each ----------------
+            for (uint32_t k = (uint32_t)wave; k < nedge; k += kSelWaves) {
+                const uint32_t c = s_work[kSelThreads - 1 - k];
+                const int64_t pc = (int64_t)s_list[c];
+                const bool two = lane < 48;
+                const int lo1 = mag_of(lut, load_sample<true>(iq, pc + 16 + 2 * lane, lo, hi));
+                const int hi1 = mag_of(lut, load_sample<true>(iq, pc + 17 + 2 * lane, lo, hi));
+                const int lo2 = two ? mag_of(lut, load_sample<true>(iq, pc + 144 + 2 * lane, lo, hi)) : 0;
+                const int hi2 = two ? mag_of(lut, load_sample<true>(iq, pc + 145 + 2 * lane, lo, hi)) : 0;
+                int sum56, sum112;
+                delta_sums(lane, lo1, hi1, lo2, hi2, &sum56, &sum112);
+                const int d1 = lo1 > hi1 ? lo1 - hi1 : hi1 - lo1;
+                const uint32_t weak = (uint32_t)__ballot(d1 < 256) & 0x3fu, gt = (uint32_t)__ballot(lo1 > hi1) & 0x3fu;
+                const bool eq0 = (__ballot(lo1 == hi1) & 1ull) != 0;
+                const bool is_long = modes_len_by_df(modes_df_first6(weak, gt, eq0)) == 112;
+                if (lane == 0) s_flag[c] = (is_long ? sum112 / 56 >= 2550 : sum56 / 28 >= 2550) ? kSelPass : kSelFail;
+            }
+            __syncthreads();
+            // ---------------- the survivors of the block, in order, behind those of the batch's earlier blocks ----------------
+            {
+                const bool pass = (uint32_t)tid < nlist && s_flag[tid] == kSelPass;
+                const uint64_t pb = __ballot(pass);
+                uint32_t nsurv;
+                const uint32_t sb = wave_prefix((uint32_t)__builtin_popcountll(pb), &nsurv);
+                if (pass) P.surv[list_base + prior + sb + (uint32_t)__builtin_popcountll(pb & below)] = s_list[tid];
+                prior += nsurv;
+                if (tid == 0) { s_n[0] = 0; s_n[1] = 0; }                      // (wave_prefix ended with a barrier: nobody reads them now)
+            }
+            __syncthreads();
+            TRACE_ADD(3, ts3);
+        }
+        tot_cand += ncand;
+        if (tid == 0) {
+            P.cand_counts[batch] = ncand;
+            P.batch_count[batch] = prior;
+        }
+        __syncthreads();                                                     // s_pre is rewritten by the next batch
+    }
+#ifdef MODES_TRACE
+    if (lane == 0) {
+        const uint32_t w = blockIdx.x * kSelWaves + (uint32_t)wave;
+        if (w < 8192) {
+            unsigned long long *tr = &g_trace[8 * w];
+            tr[0] = t_start; tr[1] = t_lut; tr[2] = wall_clock64(); tr[3] = tot_cand;
+            tr[4] = tr_t[0]; tr[5] = tr_t[1]; tr[6] = tr_t[2]; tr[7] = tr_t[3];
+        }
+    }
+#endif
+    if (wave == 0) {
+        tot_fwd = (unsigned long long)wave_sum((int)tot_fwd);
+        if (lane == 0) s_fwd = tot_fwd;
+    }
+    __syncthreads();
+    if (tid == 0) P.totals[blockIdx.x] = WgTotals{s_fwd, tot_cand, s_flags, 0};
+}
+
+struct RecordParams {
+    DemodParams d;                 // iq, lo, hi, g0, tab, maxfix, max_records, staging (= the ORDERED device list here)
+    const uint32_t *surv;          // [nbatches][kDemodGroup * slot_cap]
+    const uint32_t *batch_count;   // [nbatches]
+    modes_record *host_out;        // pinned host copy (device view) or nullptr: the first direct_cap records go there too
+    uint32_t direct_cap;
+    uint32_t *wg_flags;            // [gridDim.x] bit 1: the full demodulation disagreed with the pre-test (cannot happen)
+};
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(80))) void record_kernel(RecordParams R) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[MODES_LUT_ENTRIES];
+    __shared__ uint32_t s_esyn[112];
+    __shared__ uint32_t s_red[8];
+    __shared__ uint32_t s_bad;
+    const DemodParams &P = R.d;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // sum of batch_count[from, to) over the workgroup (to - from <= 512: the grid never exceeds 512 workgroups)
+    auto count_sum = [&](uint32_t from, uint32_t to) -> uint32_t {
+        uint32_t v = from + (uint32_t)tid < to ? R.batch_count[from + (uint32_t)tid] : 0u;
+        v = (uint32_t)wave_sum((int)v);
+        __syncthreads();                                                     // s_red of the previous call has been read
+        if (lane == 0) s_red[wave] = v;
+        __syncthreads();
+        uint32_t all = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) all += s_red[w];
+        return all;
+    };
+    if (tid == 0) s_bad = 0;
+    bool staged = false;
+    uint32_t off = 0, prev = 0;                                              // records in front of batch `prev`
+    for (uint32_t batch = blockIdx.x; batch < P.nbatches; batch += gridDim.x) {
+        off += count_sum(prev, batch);
+        prev = batch;
+        const uint32_t nb = R.batch_count[batch];
+        if (nb == 0) continue;                                               // workgroup-uniform: noise ends here, before any table is staged
+        if (!staged) {
+            stage_lut<512>(s_lut, P.tab.lut);
+            if (tid < 112) s_esyn[tid] = P.tab.esyn[tid];
+            __syncthreads();
+            staged = true;
+        }
+        const LutFull lut{s_lut};
+        const uint64_t list_base = (uint64_t)batch * kDemodGroup * P.slot_cap;
+        for (uint32_t r = (uint32_t)wave; r < nb; r += 8) {
+            const int64_t pc = (int64_t)R.surv[list_base + r];
+            const uint32_t slot = off + r;                                   // its place in the ordered list
+            // demod_full writes P.staging[slot] (here: the ordered list itself) and P.keys[slot]: keys are not used on this path
+            // the first direct_cap records also go to the host's pinned copy (a short list needs no copy operation then)
+            modes_record *host_rec = (R.host_out && slot < R.direct_cap) ? &R.host_out[slot] : nullptr;
+            bool done;
+            if (samples_inside(pc - 1, pc + 239, P.lo, P.hi)) done = demod_full<false, false>(P, lut, s_esyn, lane, pc, kUnknown, kUnknown, slot, 0, host_rec);
+            else                                              done = demod_full<true, false>(P, lut, s_esyn, lane, pc, kUnknown, kUnknown, slot, 0, host_rec);
+            if (!done && lane == 0) atomicOr(&s_bad, 2u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) R.wg_flags[blockIdx.x] = s_bad;
+}
+
+// finalize of the two-kernel path: totals, the number of records, the verdict for the host.  Nothing to put in order.
+struct Finalize2Params {
+    ResultHeader *hdr;
+    const WgTotals *totals;
+    uint32_t ntotals;
+    const uint32_t *wg_flags;
+    uint32_t nwg;
+    const uint32_t *batch_count;
+    uint32_t nbatches;
+    unsigned long long *d_count;
+    HostHeader *host_hdr;
+    uint32_t seq;
+};
+__global__ __launch_bounds__(512) void finalize2_kernel(Finalize2Params P) {
+    __shared__ unsigned long long s_sum[3][8];
+    __shared__ uint32_t s_fl[8];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long f = 0, c = 0, n = 0;
+    uint32_t fl = 0;
+    for (uint32_t i = (uint32_t)tid; i < P.ntotals; i += 512) { f += P.totals[i].n_forwarded; c += P.totals[i].n_preambles; fl |= P.totals[i].flags; }
+    for (uint32_t i = (uint32_t)tid; i < P.nwg; i += 512) fl |= P.wg_flags[i];
+    for (uint32_t i = (uint32_t)tid; i < P.nbatches; i += 512) n += P.batch_count[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        f += (unsigned long long)__shfl_xor((long long)f, off, 64);
+        c += (unsigned long long)__shfl_xor((long long)c, off, 64);
+        n += (unsigned long long)__shfl_xor((long long)n, off, 64);
+        fl |= (uint32_t)__shfl_xor((int)fl, off, 64);
+    }
+    if (lane == 0) { s_sum[0][wave] = f; s_sum[1][wave] = c; s_sum[2][wave] = n; s_fl[wave] = fl; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long nf = 0, nc = 0, nr = 0;
+        uint32_t flags = 0;
+        for (int w = 0; w < 8; w++) { nf += s_sum[0][w]; nc += s_sum[1][w]; nr += s_sum[2][w]; flags |= s_fl[w]; }
+        if (P.d_count) *P.d_count = nr;
+        P.hdr->n_records = (uint32_t)nr;
+        P.hdr->ordered = 1u;
+        HostHeader *h = P.host_hdr;
+        h->n_forwarded = nf;
+        h->n_preambles = nc;
+        h->n_records = (uint32_t)nr;
+        h->flags = flags;
+        h->ordered = 1u;
+        __hip_atomic_store(&h->seq, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // finalize_kernel - ONE workgroup behind the demod kernel: sums the workgroups' totals, turns the per-batch record
 // counts into offsets (exclusive prefix), puts a SHORT list (<= inline_cap records) in stream order right away - on the
 // device and in the host's pinned copy - and publishes the call's verdict to the host (HostHeader; the sequence number
@@ -1644,6 +2088,9 @@ struct modes_gpu {
 
     // per-detect scratch (grown on demand)
     uint32_t *d_slots = nullptr;      size_t slots_bytes = 0;
+    uint32_t *d_surv = nullptr;       size_t surv_bytes = 0;         // select_kernel's survivor lists (same geometry as the candidate lists)
+    uint32_t *d_wg_flags = nullptr;                                  // record_kernel: one word per workgroup (<= 512)
+    bool split_path = false;          // the detect in flight ran select + record + finalize2 (the list is complete and in order)
     uint32_t *d_cand_slots = nullptr; size_t cand_slots_bytes = 0;
     uint32_t *d_counts = nullptr;     size_t counts_elems = 0;       // counts | cand_counts | batch_count | batch_off
     uint64_t *d_cand_offsets = nullptr;
@@ -1760,6 +2207,8 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     modes_gpu *ctx = new (std::nothrow) modes_gpu;
     if (!ctx) return fail(nullptr, MODES_ERR_NOMEM, "out of memory");
     ctx->cfg = *cfg;
+    if (const char *v = getenv("MODES_GPU_DEMOD_VARIANT"))           // measurement / test knob: run a whole suite on another demod path
+        ctx->cfg.demod_variant = (uint32_t)atoi(v);
     ctx->auto_records = ctx->cfg.max_records == 0;
     if (ctx->auto_records) ctx->cfg.max_records = 1u << 18;          // 16 MiB of records; grows on demand
     if (ctx->cfg.direct_records == 0) ctx->cfg.direct_records = 4096;
@@ -1776,7 +2225,7 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
         hipDeviceProp_t prop;
         int per_cu = 0;
         CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
-        if (ctx->cfg.demod_variant == 2)      CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<4, LutSmall, 6>, 256, 0));
+        if (ctx->cfg.demod_variant == 2)      CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, select_kernel, kSelThreads, 0));
         else if (ctx->cfg.demod_variant == 1) CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<4, LutSmall>, 256, 0));
         else                                  CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<8, LutFull>, 512, 0));
         ctx->demod_wgs = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, prop.multiProcessorCount);
@@ -1799,6 +2248,7 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     CREATE_TRY(hipMemcpy(ctx->d_esyn, esyn, sizeof esyn, hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hdr), sizeof(ResultHeader)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_totals), sizeof(WgTotals) * ctx->demod_wgs));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_wg_flags), sizeof(uint32_t) * 512));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hdr), sizeof(HostHeader), hipHostMallocMapped));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_hdr_dev), ctx->h_hdr, 0));
     memset(ctx->h_hdr, 0, sizeof(HostHeader));
@@ -1814,7 +2264,7 @@ void modes_gpu_destroy(modes_gpu *ctx) {
     if (ctx->in_flight) (void)wait_results(ctx);                            // kernels of a detect nobody fetched
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     void *dev[] = {ctx->d_lut, ctx->d_esyn, ctx->d_slots, ctx->d_cand_slots, ctx->d_counts, ctx->d_cand_offsets,
-                   ctx->d_cand_dense, ctx->d_staging, ctx->d_keys, ctx->d_records, ctx->d_hdr, ctx->d_stage, ctx->d_totals, ctx->d_ceiling};
+                   ctx->d_cand_dense, ctx->d_staging, ctx->d_keys, ctx->d_records, ctx->d_hdr, ctx->d_stage, ctx->d_totals, ctx->d_ceiling, ctx->d_surv, ctx->d_wg_flags};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (ctx->h_hdr) (void)hipHostFree(ctx->h_hdr);
@@ -1962,6 +2412,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     const uint32_t nbatches = (nruns + kDemodGroup - 1) / kDemodGroup;      // demod_kernel's unit of work, of candidate lists and of record order
     size_t want = (size_t)nbatches * kDemodGroup * cap * sizeof(uint32_t);
     if ((rc = grow(ctx, &ctx->d_slots, &ctx->slots_bytes, want)) != MODES_OK) return rc;
+    if (ctx->cfg.demod_variant == 2 && (rc = grow(ctx, &ctx->d_surv, &ctx->surv_bytes, want)) != MODES_OK) return rc;
     if (ctx->cfg.keep_candidates && (rc = grow(ctx, &ctx->d_cand_slots, &ctx->cand_slots_bytes, want)) != MODES_OK) return rc;
     if (ctx->counts_elems < nruns) {
         if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -2067,9 +2518,30 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
         HIP_TRY(ctx, hipStreamWaitEvent(st2, ek[1], 0));
     }
     ctx->demod_grid = std::min<uint32_t>(nbatches, ctx->demod_wgs);        // every workgroup's first batch; the rest are dealt dynamically
-    if (ctx->cfg.demod_variant == 2)
-        hipExtLaunchKernelGGL((demod_kernel<4, LutSmall, 6>), dim3(ctx->demod_grid), dim3(256), 0, st2, ev(2), ev(3), 0, dp);
-    else if (ctx->cfg.demod_variant == 1)
+    ctx->split_path = ctx->cfg.demod_variant == 2;
+    if (ctx->split_path) {
+        SelectParams sel{};
+        sel.iq = sp.iq; sel.lo = sp.lo; sel.hi = sp.hi;
+        sel.nruns = nruns; sel.run_chunks = R; sel.slot_cap = cap;
+        sel.slots = ctx->d_slots; sel.counts = d_counts; sel.lut = ctx->d_lut;
+        sel.cand_slots = dp.cand_slots; sel.cand_counts = d_cand_counts;
+        sel.surv = ctx->d_surv; sel.batch_count = d_batch_count; sel.nbatches = nbatches; sel.totals = ctx->d_totals;
+        hipExtLaunchKernelGGL(select_kernel, dim3(ctx->demod_grid), dim3(kSelThreads), 0, st2, ev(2), ev(3), 0, sel);
+        mark(3);
+        RecordParams rp{};
+        rp.d = dp;
+        rp.d.staging = fp.out;                                              // records go straight to their place in the ordered list
+        rp.surv = ctx->d_surv; rp.batch_count = d_batch_count;
+        rp.host_out = ctx->h_records_dev; rp.direct_cap = fp.inline_cap; rp.wg_flags = ctx->d_wg_flags;
+        const uint32_t rec_grid = std::min<uint32_t>(nbatches, 512);
+        hipExtLaunchKernelGGL(record_kernel, dim3(rec_grid), dim3(512), 0, st2, ev(4), ev(5), 0, rp);
+        Finalize2Params f2{};
+        f2.hdr = ctx->d_hdr; f2.totals = ctx->d_totals; f2.ntotals = ctx->demod_grid; f2.wg_flags = ctx->d_wg_flags; f2.nwg = rec_grid;
+        f2.batch_count = d_batch_count; f2.nbatches = nbatches; f2.d_count = ctx->d_user_count; f2.host_hdr = ctx->h_hdr_dev; f2.seq = fp.seq;
+        hipExtLaunchKernelGGL(finalize2_kernel, dim3(1), dim3(512), 0, st2, nullptr, nullptr, 0, f2);
+        mark(4);
+    } else {
+    if (ctx->cfg.demod_variant == 1)
         hipExtLaunchKernelGGL((demod_kernel<4, LutSmall>), dim3(ctx->demod_grid), dim3(256), 0, st2, ev(2), ev(3), 0, dp);
     else
         hipExtLaunchKernelGGL((demod_kernel<8, LutFull>), dim3(ctx->demod_grid), dim3(512), 0, st2, ev(2), ev(3), 0, dp);
@@ -2077,11 +2549,12 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     fp.ntotals = ctx->demod_grid;
     hipExtLaunchKernelGGL(finalize_kernel, dim3(1), dim3(512), 0, st2, nullptr, nullptr, 0, fp);
     mark(4);
+    }
     // Lists of up to direct_records records are put in order by finalize_kernel.  order_kernel only follows in the
     // stream when the caller consumes the list on the device in stream order (MODES_GPU_ORDER_IN_STREAM); otherwise
     // modes_gpu_fetch / modes_gpu_fetch_device launch it when a list turns out to be long.
     const bool tail = ctx->cfg.keep_candidates != 0;                       // prefix_kernel follows
-    ctx->order_launched = ctx->d_user_records != nullptr && (ctx->cfg.flags & MODES_GPU_ORDER_IN_STREAM) != 0;
+    ctx->order_launched = !ctx->split_path && ctx->d_user_records != nullptr && (ctx->cfg.flags & MODES_GPU_ORDER_IN_STREAM) != 0;
     ctx->order_params = op;
     if (ctx->order_launched) {
         if (ctx->cfg.overlap == 2 && st != ctx->own_stream) {              // only the order kernel leaves the caller's stream
@@ -2186,7 +2659,10 @@ static int finish_detect(modes_gpu *ctx, modes_gpu_result *res, bool to_host) {
     }
     const modes_record *d_list = ctx->d_user_records ? ctx->d_user_records : ctx->d_records;
     bool ordered_late = false;
-    if (!hh.ordered) {                                                  // a long list: short ones are complete, on the host too
+    if (ctx->split_path) {                                              // in order already; the first direct_records are on the host too
+        if (to_host && n_records > std::min(ctx->cfg.direct_records, ctx->cfg.max_records))
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_records, d_list, (size_t)n_records * sizeof(modes_record), hipMemcpyDeviceToHost, st));
+    } else if (!hh.ordered) {                                           // a long list: short ones are complete, on the host too
         if (!ctx->order_launched) {
             hipExtLaunchKernelGGL(order_kernel, dim3(512), dim3(256), 0, st, ctx->timed ? ctx->ev_k[4] : nullptr,
                                   ctx->timed ? ctx->ev_k[5] : nullptr, 0, ctx->order_params);
@@ -2225,10 +2701,11 @@ static int finish_detect(modes_gpu *ctx, modes_gpu_result *res, bool to_host) {
     res->n_preambles = n_preambles;
     if (ctx->timed) {
         // the host word is published before the demod kernel has retired: its stop event may still be pending
-        (void)hipEventSynchronize(ctx->ev_k[(ctx->order_launched || ordered_late) ? 5 : 3]);
+        const bool third = ctx->order_launched || ordered_late || ctx->split_path;     // split path: the record kernel's events
+        (void)hipEventSynchronize(ctx->ev_k[third ? 5 : 3]);
         (void)hipEventElapsedTime(&res->scan_ms, ctx->ev_k[0], ctx->ev_k[1]);
         (void)hipEventElapsedTime(&res->demod_ms, ctx->ev_k[2], ctx->ev_k[3]);
-        if (ctx->order_launched || ordered_late) (void)hipEventElapsedTime(&res->order_ms, ctx->ev_k[4], ctx->ev_k[5]);
+        if (third) (void)hipEventElapsedTime(&res->order_ms, ctx->ev_k[4], ctx->ev_k[5]);
     }
     return MODES_OK;
 }

@@ -143,7 +143,7 @@ def test_synth_noise_matches_host_generator(torch_cuda):
     d.close()
 
 
-@pytest.mark.parametrize("demod_variant", [0, 1])
+@pytest.mark.parametrize("demod_variant", [0, 1, 2])
 @pytest.mark.parametrize("case", CASES)
 def test_records_and_candidates_match_oracle(torch_cuda, streams, case, demod_variant):
     """Both demod kernels: the production one (8 waves, the whole table in LDS) and the independent second

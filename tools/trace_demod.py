@@ -32,7 +32,8 @@ for name, v in (("start", start), ("lut done", lut), ("end", end), ("life", end 
     print("%-11s min %8.2f p10 %8.2f p50 %8.2f p90 %8.2f max %8.2f  (us; cands: count)" % (name, v.min(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
 
 # who is slow?  (8 wavefronts per workgroup share their workgroup's numbers; one line per workgroup)
-wg = t[::8] if len(t) % 8 == 0 else t
+wpw = 16 if (len(sys.argv) > 3 and sys.argv[3] == "2") else 8            # select_kernel: 16 wavefronts per workgroup       # wavefronts per workgroup: select_kernel has 16
+wg = t[::wpw] if len(t) % wpw == 0 else t
 life = (wg[:, 2] - wg[:, 0]) / 100.0
 order = np.argsort(-life)
 print("corr(life, cands) = %.2f" % np.corrcoef(life, wg[:, 3])[0, 1])
