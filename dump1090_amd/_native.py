@@ -13,6 +13,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 GPU_LIB = os.environ.get("MODES_GPU_LIB") or os.path.join(PKG_DIR, "libmodes_gfx950.so")      # (MODES_GPU_LIB: another build of the library - tools/ab_scan.py, experiments)
 HOST_LIB = os.path.join(PKG_DIR, "libmodes_host.so")
+GATHER_LIB = os.path.join(PKG_DIR, "libmodes_gather.so")      # the C hosts' record gather over RCCL (include/modes_gather.h)
 
 DATA_LEN = 262144
 CARRY_BYTES = 476
@@ -127,8 +128,52 @@ HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_set_time"
                 "modes_tracker_create", "modes_tracker_destroy", "modes_tracker_receive", "modes_tracker_expire",
                 "modes_tracker_count", "modes_tracker_get", "modes_tracker_reference", "modes_tracker_json", "modes_format_sbs")
 
+GATHER_SYMBOLS = ("modes_gather_unique_id", "modes_gather_create", "modes_gather_destroy", "modes_gather_last_error",
+                  "modes_gather_output", "modes_gather_set_empty", "modes_gather_counts", "modes_gather_records", "modes_gather_wait",
+                  "modes_gather_get_stats", "modes_gather_abi_version")
+
+
+class GatherConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32), ("cap_records", C.c_uint32),
+                ("nslots", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class GatherStats(C.Structure):
+    _fields_ = [("nranks", C.c_int32), ("rank", C.c_int32), ("rccl_version", C.c_int32), ("reserved", C.c_uint32),
+                ("calls", C.c_uint64), ("p2p_ops", C.c_uint64), ("bytes_received", C.c_uint64), ("bytes_sent", C.c_uint64),
+                ("gather_ms", C.c_double)]
+
+
 _gpu = None
 _host = None
+_gather = None
+
+
+def gather_lib():
+    """libmodes_gather.so - what a C host binds for the N-GPU gather (Python hosts use dump1090_amd/distributed.py); loaded
+    here for the tests.  Needs librccl (torch's copy is picked up when torch is already imported)."""
+    global _gather
+    if _gather is None:
+        if not os.path.exists(GATHER_LIB):
+            raise ModesError(-2, "%s is not built" % GATHER_LIB)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(GATHER_LIB)
+        L.modes_gather_unique_id.argtypes = [C.c_void_p]
+        L.modes_gather_create.argtypes = [C.POINTER(GatherConfig), C.c_void_p, C.POINTER(C.c_void_p)]
+        L.modes_gather_destroy.argtypes = [C.c_void_p]
+        L.modes_gather_destroy.restype = None
+        L.modes_gather_last_error.argtypes = [C.c_void_p]
+        L.modes_gather_last_error.restype = C.c_char_p
+        L.modes_gather_output.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
+        for f in (L.modes_gather_set_empty, L.modes_gather_counts, L.modes_gather_records):
+            f.argtypes = [C.c_void_p, C.c_uint32]
+        L.modes_gather_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]
+        L.modes_gather_get_stats.argtypes = [C.c_void_p, C.POINTER(GatherStats)]
+        _gather = L
+    return _gather
 
 
 def gpu_lib():

@@ -19,6 +19,11 @@
 // batches - and therefore GPUs (--gpus N: batch b runs on device b mod N, one context per lane) - share nothing
 // but those 476 input bytes; the record lists come back per batch, already in stream order, and are resolved
 // strictly in batch order by the one thread that owns the ICAO whitelist.
+//
+// --ranks N is the other way to use N GPUs (north_star's): ONE PROCESS PER GPU - this program forks N - 1 copies of
+// itself - and the record lists travel to rank 0 from device memory over RCCL / xGMI (libmodes_gather.so, loaded on demand):
+// rank r demodulates batches r, r + N, r + 2N, ... of the (regular) file, round g of the gather carries batches
+// gN .. gN + N - 1, so rank order is stream order and rank 0 resolves and prints every round as it arrives (run_ranks).
 
 #include <cerrno>
 #include <chrono>
@@ -34,12 +39,15 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
+#include "../../include/modes_gather.h"
 #include "../../include/modes_gfx950.h"
 #include "../../include/modes_host.h"
 
@@ -55,6 +63,8 @@ struct Options {
     int depth = 3;                         // batches in flight per device (lanes = depth x devices)
     bool use_mmap = true;                  // regular files: copy out of a mapping of the file instead of pread()
     int resolve_threads = 8;               // --raw only: pieces of a batch resolved in parallel (modes_host_resolve_raw_mt)
+    int ranks = 0;                         // --ranks N: one process per GPU, record lists gathered to rank 0 over RCCL
+    uint32_t gather_cap = 1u << 18;        // --gather-records: records per rank and round the gather buffers hold
 };
 
 struct Sink {
@@ -79,6 +89,9 @@ void show_help() {
         "--gpu <ordinal>          HIP device to run on (default: 0).\n"
         "--gpus <n>               Split the stream over HIP devices 0..n-1 (batch b runs on device b mod n).\n"
         "--gpu-list <a,b,...>     The same with explicit ordinals; an ordinal may repeat (several contexts on one device).\n"
+        "--ranks <n>              One PROCESS per GPU (this one forks n-1 more): rank r takes batches r, r+n, ... of a regular\n"
+        "                         file on device r (or --gpu-list), the record lists are gathered to rank 0 over RCCL.\n"
+        "--gather-records <n>     With --ranks: records per rank and round the gather buffers hold (default: 262144).\n"
         "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).\n"
         "--depth <n>              Batches in flight per device (default: 3).\n"
         "--read-threads <n>       Threads reading a regular file (default: 16).\n"
@@ -215,6 +228,215 @@ struct Lane {
     int device = 0;
 };
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// --ranks N: one process per GPU, the record lists gathered to rank 0 over RCCL (include/modes_gather.h).
+// ---------------------------------------------------------------------------------------------------------------------
+struct GatherApi {
+    void *dl = nullptr;
+    decltype(&modes_gather_unique_id) unique_id = nullptr;
+    decltype(&modes_gather_create) create = nullptr;
+    decltype(&modes_gather_destroy) destroy = nullptr;
+    decltype(&modes_gather_last_error) last_error = nullptr;
+    decltype(&modes_gather_output) output = nullptr;
+    decltype(&modes_gather_set_empty) set_empty = nullptr;
+    decltype(&modes_gather_counts) counts = nullptr;
+    decltype(&modes_gather_records) records = nullptr;
+    decltype(&modes_gather_wait) wait = nullptr;
+    decltype(&modes_gather_get_stats) get_stats = nullptr;
+    // libmodes_gather.so sits next to libmodes_gfx950.so; it is loaded only here because it pulls in librccl (0.5 GB)
+    bool load() {
+        Dl_info info;
+        std::string dir = ".";
+        if (dladdr(reinterpret_cast<void *>(&modes_gpu_create), &info) && info.dli_fname) {
+            dir = info.dli_fname;
+            const size_t slash = dir.rfind('/');
+            dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+        }
+        dl = dlopen((dir + "/libmodes_gather.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!dl) { fprintf(stderr, "--ranks: %s\n", dlerror()); return false; }
+#define SYM(name) if (!(name = reinterpret_cast<decltype(name)>(dlsym(dl, "modes_gather_" #name)))) { fprintf(stderr, "--ranks: modes_gather_" #name " missing\n"); return false; }
+        SYM(unique_id) SYM(create) SYM(destroy) SYM(last_error) SYM(output) SYM(set_empty) SYM(counts) SYM(records) SYM(wait) SYM(get_stats)
+#undef SYM
+        return true;
+    }
+};
+
+bool write_all(int fd, const void *p, size_t n) {
+    const char *c = static_cast<const char *>(p);
+    while (n) { ssize_t w = write(fd, c, n); if (w < 0) { if (errno == EINTR) continue; return false; } c += w; n -= (size_t)w; }
+    return true;
+}
+bool read_all(int fd, void *p, size_t n) {
+    char *c = static_cast<char *>(p);
+    while (n) { ssize_t r = read(fd, c, n); if (r < 0) { if (errno == EINTR) continue; return false; } if (r == 0) return false; c += r; n -= (size_t)r; }
+    return true;
+}
+
+int run_ranks(const Options &opt, double t_start) {
+    const int N = opt.ranks;
+    if (opt.stats) { fprintf(stderr, "--ranks: --stats needs every rank's preamble positions on rank 0; use --gpus %d for it\n", N); return 1; }
+    if (opt.loop || opt.filename == "-") { fprintf(stderr, "--ranks reads a regular file (every rank maps its own batches)\n"); return 1; }
+    if (!opt.devices.empty() && (int)opt.devices.size() != N) { fprintf(stderr, "--ranks %d with a --gpu-list of %zu devices\n", N, opt.devices.size()); return 1; }
+    // the unique id travels from rank 0 to rank r through a pipe made before the fork; no HIP / RCCL call precedes the fork
+    std::vector<int> rd((size_t)N, -1), wr((size_t)N, -1);
+    for (int r = 1; r < N; r++) {
+        int fds[2];
+        if (pipe(fds) != 0) { perror("pipe"); return 1; }
+        rd[(size_t)r] = fds[0];
+        wr[(size_t)r] = fds[1];
+    }
+    int rank = 0;
+    std::vector<pid_t> kids;
+    for (int r = 1; r < N; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) { perror("fork"); return 1; }
+        if (pid == 0) { rank = r; kids.clear(); break; }
+        kids.push_back(pid);
+    }
+    for (int r = 1; r < N; r++) {                                            // keep only this rank's end(s)
+        if (rank == 0) close(rd[(size_t)r]);
+        else { close(wr[(size_t)r]); if (r != rank) close(rd[(size_t)r]); }
+    }
+    auto finish = [&](int rc) {                                              // rank 0: the job's status is the worst rank's
+        if (rank != 0) { fflush(stdout); fflush(stderr); _exit(rc); }
+        for (pid_t k : kids) {
+            int st = 0;
+            if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : 1;
+        }
+        return rc;
+    };
+    // RCCL prints a version banner on stdout when a communicator is made: stdout is the message sink of this program, so
+    // the library side of the process gets stderr as its stdout and the sink keeps the real one
+    fflush(stdout);
+    FILE *out = fdopen(dup(1), "w");
+    if (!out || dup2(2, 1) < 0) { perror("--ranks: stdout"); return finish(1); }
+    GatherApi G;
+    if (!G.load()) return finish(1);
+    unsigned char id[MODES_GATHER_ID_BYTES];
+    if (rank == 0) {
+        if (G.unique_id(id) != MODES_OK) { fprintf(stderr, "--ranks: %s\n", G.last_error(nullptr)); return finish(1); }
+        for (int r = 1; r < N; r++) { if (!write_all(wr[(size_t)r], id, sizeof id)) { perror("--ranks: id pipe"); return finish(1); } close(wr[(size_t)r]); }
+    } else {
+        if (!read_all(rd[(size_t)rank], id, sizeof id)) { fprintf(stderr, "--ranks: rank %d got no id from rank 0\n", rank); return finish(1); }
+        close(rd[(size_t)rank]);
+    }
+    const int device = opt.devices.empty() ? rank : opt.devices[(size_t)rank];
+    const int fd = open(opt.filename.c_str(), O_RDONLY);
+    struct stat sb;
+    if (fd == -1 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { perror("Opening data file"); return finish(1); }
+    const size_t size = (size_t)sb.st_size;
+    const uint8_t *map = size ? static_cast<const uint8_t *>(mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0)) : nullptr;
+    if (size && map == MAP_FAILED) { perror("mmap"); return finish(1); }
+
+    const int depth = 3;
+    modes_gather_config gc{device, rank, N, opt.gather_cap, (uint32_t)depth, 0};
+    modes_gather *g = nullptr;
+    if (G.create(&gc, id, &g) != MODES_OK) { fprintf(stderr, "--ranks: rank %d: %s\n", rank, G.last_error(nullptr)); return finish(1); }
+    const size_t batch_bytes = (size_t)opt.batch_blocks * MODES_DATA_LEN;
+    std::vector<Lane> lanes((size_t)depth);
+    for (int l = 0; l < depth; l++) {
+        modes_gpu_config cfg{};
+        cfg.device = device;
+        cfg.fix_errors = opt.fix_errors;
+        cfg.aggressive = opt.aggressive ? 1 : 0;
+        void *d_rec = nullptr, *d_cnt = nullptr, *p = nullptr;
+        uint64_t cap = 0;
+        if (modes_gpu_create(&cfg, &lanes[(size_t)l].gpu) != MODES_OK) { fprintf(stderr, "rank %d: GPU init failed: %s\n", rank, modes_gpu_last_error(nullptr)); return finish(1); }
+        modes_gpu_set_timing(lanes[(size_t)l].gpu, 0);
+        if (G.output(g, (uint32_t)l, &d_rec, &cap, &d_cnt) != MODES_OK || modes_gpu_set_output(lanes[(size_t)l].gpu, d_rec, cap, d_cnt) != MODES_OK ||
+            modes_gpu_host_alloc(lanes[(size_t)l].gpu, MODES_CARRY_BYTES + batch_bytes, &p) != MODES_OK) {
+            fprintf(stderr, "rank %d: %s / %s\n", rank, G.last_error(g), modes_gpu_last_error(lanes[(size_t)l].gpu));
+            return finish(1);
+        }
+        lanes[(size_t)l].buf = static_cast<uint8_t *>(p);
+    }
+    modes_host_config hcfg{opt.fix_errors, opt.aggressive ? 1 : 0, opt.check_crc, 0};
+    modes_host *host = rank == 0 ? modes_host_create(&hcfg) : nullptr;
+    Sink sink{&opt, host, {}, (rank == 0 && opt.sbs) ? modes_tracker_create() : nullptr};
+    const bool raw_fast = opt.raw && !opt.sbs && !opt.raw_net && !opt.onlyaddr;
+    std::vector<char> rawbuf;
+    uint64_t n_messages_out = 0;
+    const double t_ready = now_s();
+
+    // Batch b of the stream (the single-process host's geometry: a short - possibly empty - batch ends the stream and
+    // carries the EOF buffer, dump1090.c:484-510); round q of the gather = batches qN .. qN + N - 1, rank r takes batch qN + r.
+    const uint64_t nbatches = size / batch_bytes + 1;
+    const uint64_t nrounds = (nbatches + (uint64_t)N - 1) / (uint64_t)N;
+    Pool pool(std::max(1, opt.read_threads / N));
+    std::vector<char> has((size_t)depth, 0);
+    int rc = 0;
+    auto fail_rank = [&](const char *what, const char *text) { fprintf(stderr, "rank %d: %s: %s\n", rank, what, text); rc = 1; };
+    for (uint64_t q = 0; q < nrounds + 2 && !rc; q++) {
+        if (q < nrounds) {                                                   // submit this rank's batch of round q
+            const int l = (int)(q % (uint64_t)depth);
+            const uint64_t b = q * (uint64_t)N + (uint64_t)rank;
+            has[(size_t)l] = b < nbatches;
+            if (has[(size_t)l]) {
+                const size_t lo = (size_t)b * batch_bytes, got = std::min(batch_bytes, size - std::min(size, lo));
+                const size_t carry = b ? MODES_CARRY_BYTES : 0;
+                const uint8_t *src = map + lo - carry;
+                const size_t n = carry + got, sl = (n / (size_t)pool.size() + 4095) & ~(size_t)4095;
+                uint8_t *dst = lanes[(size_t)l].buf;
+                pool.run(pool.size(), [&](int t) { const size_t o = (size_t)t * sl; if (o < n) memcpy(dst + o, src + o, std::min(sl, n - o)); });
+                uint64_t nblocks = got / MODES_DATA_LEN;
+                if (got < batch_bytes) nblocks += 1;                         // the EOF buffer
+                if (modes_gpu_submit_host(lanes[(size_t)l].gpu, dst, n, (uint64_t)lo - carry, b * opt.batch_blocks, nblocks) != MODES_OK)
+                    fail_rank("GPU demodulation failed", modes_gpu_last_error(lanes[(size_t)l].gpu));
+            }
+        }
+        if (q >= 1 && q - 1 < nrounds && !rc) {                              // round q - 1: kernels done -> lengths -> transfers
+            const int l = (int)((q - 1) % (uint64_t)depth);
+            if (has[(size_t)l]) {
+                modes_gpu_result res{};
+                // (a list that outgrew the buffers still goes through the length exchange: every rank then fails together)
+                const int frc = modes_gpu_fetch_device(lanes[(size_t)l].gpu, &res);
+                if (frc != MODES_OK && frc != MODES_ERR_OVERFLOW) fail_rank("GPU demodulation failed", modes_gpu_last_error(lanes[(size_t)l].gpu));
+            } else if (G.set_empty(g, (uint32_t)l) != MODES_OK) fail_rank("gather", G.last_error(g));
+            if (!rc && (G.counts(g, (uint32_t)l) != MODES_OK || G.records(g, (uint32_t)l) != MODES_OK)) fail_rank("gather", G.last_error(g));
+        }
+        if (q >= 2 && !rc) {                                                 // round q - 2: rank 0 resolves what arrived
+            const int l = (int)((q - 2) % (uint64_t)depth);
+            const modes_record *recs = nullptr;
+            uint64_t nrec = 0;
+            if (G.wait(g, (uint32_t)l, &recs, &nrec, nullptr) != MODES_OK) { fail_rank("gather", G.last_error(g)); break; }
+            if (rank != 0) continue;
+            if (raw_fast) {
+                const uint64_t cap = nrec * 62 + 64;
+                if (rawbuf.size() < cap) rawbuf.resize(cap);
+                uint64_t nb = 0;
+                n_messages_out += modes_host_resolve_raw_mt(host, recs, nrec, rawbuf.data(), rawbuf.size(), &nb, opt.resolve_threads);
+                sink.out.assign(rawbuf.data(), (size_t)nb);
+            } else
+                n_messages_out += modes_host_resolve(host, recs, nrec, nullptr, 0, on_message, &sink);
+            if (!sink.out.empty()) {
+                fwrite(sink.out.data(), 1, sink.out.size(), out);
+                fflush(out);
+                sink.out.clear();
+            }
+        }
+    }
+    const double t_end = now_s();
+    if (rank == 0 && opt.timing && !rc) {
+        modes_gather_stats st{};
+        G.get_stats(g, &st);
+        const double stream_s = t_end - t_ready;
+        fprintf(stderr,
+                "{\"bytes\": %zu, \"ranks\": %d, \"rounds\": %llu, \"init_s\": %.4f, \"stream_s\": %.4f, \"total_s\": %.4f, \"stream_GBps\": %.2f, "
+                "\"sink_calls\": %llu, \"rccl\": {\"version\": %d, \"nranks\": %d, \"p2p_ops\": %llu, \"bytes_received\": %llu, \"gather_ms\": %.3f}}\n",
+                size, N, (unsigned long long)nrounds, t_ready - t_start, stream_s, t_end - t_start, stream_s > 0 ? size / stream_s / 1e9 : 0.0,
+                (unsigned long long)n_messages_out, st.rccl_version, st.nranks, (unsigned long long)st.p2p_ops,
+                (unsigned long long)st.bytes_received, st.gather_ms);
+    }
+    if (host) modes_host_destroy(host);
+    modes_tracker_destroy(sink.tracker);
+    for (auto &ln : lanes) { modes_gpu_host_free(ln.gpu, ln.buf); modes_gpu_destroy(ln.gpu); }
+    G.destroy(g);
+    if (map) munmap(const_cast<uint8_t *>(map), size);
+    close(fd);
+    return finish(rc);
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -246,6 +468,8 @@ int main(int argc, char **argv) {
                 p = *end == ',' ? end + 1 : end;
             }
         }
+        else if (!strcmp(a, "--ranks") && more) opt.ranks = atoi(argv[++j]);
+        else if (!strcmp(a, "--gather-records") && more) opt.gather_cap = (uint32_t)strtoul(argv[++j], nullptr, 10);
         else if (!strcmp(a, "--batch-blocks") && more) opt.batch_blocks = strtoull(argv[++j], nullptr, 10);
         else if (!strcmp(a, "--depth") && more) opt.depth = std::max(1, atoi(argv[++j]));
         else if (!strcmp(a, "--read-threads") && more) opt.read_threads = std::max(1, atoi(argv[++j]));
@@ -263,6 +487,7 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (opt.batch_blocks == 0) opt.batch_blocks = 1;
+    if (opt.ranks > 0) return run_ranks(opt, t_start);
     if (opt.devices.empty()) {
         if (ngpus > 0) for (int d = 0; d < ngpus; d++) opt.devices.push_back(d);
         else opt.devices.push_back(single_device);

@@ -1,0 +1,286 @@
+// modes_gather.cpp - libmodes_gather.so (include/modes_gather.h): the gather of the per-GPU record lists to rank 0 over
+// RCCL, behind a C ABI.  One process per GPU; the only collective of the N-GPU path.
+//
+// Per call in flight (slot): the rank's list and its 8-byte length live in device buffers the demodulation kernels write
+// (modes_gpu_set_output); the exchange is
+//     counts   ncclAllGather of the lengths (8 bytes per rank) + copy to pinned host memory
+//     records  when the lengths are on the host: every rank with records sends exactly n * 64 bytes, rank 0 receives each
+//              list at its final offset of one contiguous device buffer (its own list is already at the front) - grouped
+//              ncclSend / ncclRecv, 7 peers -> root over 7 distinct xGMI links, no padding, no staging copy - then ONE
+//              device-to-host copy of the concatenation on rank 0.
+// Everything is queued on the gather's own stream; the host blocks only in modes_gather_records (for the lengths) and in
+// modes_gather_wait.  A group of one rank sends its list to itself into a second half of its buffer and compares.
+//
+// Line numbers cite /root/reference/dump1090.c where the reference has a counterpart; the exchange itself has none.
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/modes_gather.h"
+
+static_assert(sizeof(ncclUniqueId) == MODES_GATHER_ID_BYTES, "ncclUniqueId size");
+
+namespace {
+
+struct Slot {
+    uint8_t *d_records = nullptr;              // root: room for every rank's list (two lists in a group of one); others: their own
+    unsigned long long *d_count = nullptr;     // this rank's length (written by finalize_kernel)
+    unsigned long long *d_all = nullptr;       // [nranks]
+    unsigned long long *h_all = nullptr;       // pinned
+    uint8_t *h_records = nullptr;              // pinned, root only
+    hipEvent_t ev_c0 = nullptr, ev_counts = nullptr, ev_r0 = nullptr, ev_records = nullptr;
+    std::vector<uint64_t> counts;              // lengths of the call whose records were queued
+    uint64_t total = 0;
+    bool counts_queued = false, records_queued = false, loopback = false;
+};
+
+thread_local char g_error[512] = "";
+
+}  // namespace
+
+struct modes_gather {
+    modes_gather_config cfg{};
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<Slot> slots;
+    modes_gather_stats st{};
+    std::string err;
+};
+
+static int fail(modes_gather *g, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (g) g->err = buf;
+    else { strncpy(g_error, buf, sizeof g_error - 1); g_error[sizeof g_error - 1] = 0; }
+    return code;
+}
+
+#define HIP_TRY(g, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail(g, MODES_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+#define NCCL_TRY(g, call)                                                                                \
+    do {                                                                                                 \
+        ncclResult_t r_ = (call);                                                                        \
+        if (r_ != ncclSuccess) return fail(g, MODES_ERR_HIP, "%s: %s", #call, ncclGetErrorString(r_));  \
+    } while (0)
+
+extern "C" {
+
+int modes_gather_abi_version(void) { return MODES_GATHER_ABI; }
+
+const char *modes_gather_last_error(const modes_gather *g) { return g ? g->err.c_str() : g_error; }
+
+int modes_gather_unique_id(void *id) {
+    if (!id) return fail(nullptr, MODES_ERR_ARG, "unique_id: null");
+    ncclUniqueId u;
+    NCCL_TRY(nullptr, ncclGetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return MODES_OK;
+}
+
+int modes_gather_create(const modes_gather_config *cfg, const void *id, modes_gather **out) {
+    if (!cfg || !id || !out) return fail(nullptr, MODES_ERR_ARG, "modes_gather_create: null argument");
+    *out = nullptr;
+    if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks || cfg->cap_records == 0)
+        return fail(nullptr, MODES_ERR_ARG, "modes_gather_create: rank %d of %d, %u records", cfg->rank, cfg->nranks, cfg->cap_records);
+    modes_gather *g = new (std::nothrow) modes_gather;
+    if (!g) return fail(nullptr, MODES_ERR_NOMEM, "out of memory");
+    g->cfg = *cfg;
+    if (g->cfg.nslots == 0) g->cfg.nslots = 3;
+    auto bail = [&](int rc) { fail(nullptr, rc, "%s", g->err.c_str()); modes_gather_destroy(g); return rc; };
+#define CREATE_HIP(call)                                                                                                  \
+    do {                                                                                                                  \
+        hipError_t e_ = (call);                                                                                           \
+        if (e_ != hipSuccess) { fail(g, MODES_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); return bail(MODES_ERR_HIP); } \
+    } while (0)
+    CREATE_HIP(hipSetDevice(cfg->device));
+    CREATE_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    {
+        ncclResult_t r = ncclCommInitRank(&g->comm, cfg->nranks, u, cfg->rank);
+        if (r != ncclSuccess) { fail(g, MODES_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", cfg->rank, cfg->nranks, ncclGetErrorString(r)); return bail(MODES_ERR_HIP); }
+    }
+    const bool root = cfg->rank == 0;
+    const size_t own = (size_t)cfg->cap_records * sizeof(modes_record);
+    const size_t lists = root ? (size_t)(cfg->nranks > 1 ? cfg->nranks : 2) : 1;
+    g->slots.resize(g->cfg.nslots);
+    for (Slot &s : g->slots) {
+        CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_records), own * lists));
+        CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_count), sizeof(unsigned long long)));
+        CREATE_HIP(hipMemset(s.d_count, 0, sizeof(unsigned long long)));
+        CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_all), sizeof(unsigned long long) * (size_t)cfg->nranks));
+        CREATE_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_all), sizeof(unsigned long long) * (size_t)cfg->nranks, hipHostMallocDefault));
+        if (root) CREATE_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_records), own * lists, hipHostMallocDefault));
+        CREATE_HIP(hipEventCreate(&s.ev_c0));
+        CREATE_HIP(hipEventCreate(&s.ev_counts));
+        CREATE_HIP(hipEventCreate(&s.ev_r0));
+        CREATE_HIP(hipEventCreate(&s.ev_records));
+        s.counts.assign((size_t)cfg->nranks, 0);
+    }
+#undef CREATE_HIP
+    g->st.nranks = cfg->nranks;
+    g->st.rank = cfg->rank;
+    (void)ncclGetVersion(&g->st.rccl_version);
+    *out = g;
+    return MODES_OK;
+}
+
+void modes_gather_destroy(modes_gather *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->cfg.device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    for (Slot &s : g->slots) {
+        if (s.d_records) (void)hipFree(s.d_records);
+        if (s.d_count) (void)hipFree(s.d_count);
+        if (s.d_all) (void)hipFree(s.d_all);
+        if (s.h_all) (void)hipHostFree(s.h_all);
+        if (s.h_records) (void)hipHostFree(s.h_records);
+        for (hipEvent_t e : {s.ev_c0, s.ev_counts, s.ev_r0, s.ev_records})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (g->comm) (void)ncclCommDestroy(g->comm);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+static Slot *slot_of(modes_gather *g, uint32_t slot) { return g && slot < g->slots.size() ? &g->slots[slot] : nullptr; }
+
+int modes_gather_output(modes_gather *g, uint32_t slot, void **d_records, uint64_t *capacity, void **d_count) {
+    Slot *s = slot_of(g, slot);
+    if (!s || !d_records || !capacity || !d_count) return g ? fail(g, MODES_ERR_ARG, "output: bad slot or null argument") : MODES_ERR_ARG;
+    *d_records = s->d_records;
+    *capacity = g->cfg.cap_records;
+    *d_count = s->d_count;
+    return MODES_OK;
+}
+
+int modes_gather_set_empty(modes_gather *g, uint32_t slot) {
+    Slot *s = slot_of(g, slot);
+    if (!s) return g ? fail(g, MODES_ERR_ARG, "set_empty: slot %u of %zu", slot, g->slots.size()) : MODES_ERR_ARG;
+    HIP_TRY(g, hipSetDevice(g->cfg.device));
+    HIP_TRY(g, hipMemsetAsync(s->d_count, 0, sizeof(unsigned long long), g->stream));
+    return MODES_OK;
+}
+
+int modes_gather_counts(modes_gather *g, uint32_t slot) {
+    Slot *s = slot_of(g, slot);
+    if (!s) return g ? fail(g, MODES_ERR_ARG, "counts: slot %u of %zu", slot, g->slots.size()) : MODES_ERR_ARG;
+    if (s->counts_queued) return fail(g, MODES_ERR_STATE, "counts: slot %u already has an exchange in flight (wait for it first)", slot);
+    HIP_TRY(g, hipSetDevice(g->cfg.device));
+    HIP_TRY(g, hipEventRecord(s->ev_c0, g->stream));
+    NCCL_TRY(g, ncclAllGather(s->d_count, s->d_all, 1, ncclUint64, g->comm, g->stream));
+    HIP_TRY(g, hipMemcpyAsync(s->h_all, s->d_all, sizeof(unsigned long long) * (size_t)g->cfg.nranks, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(g, hipEventRecord(s->ev_counts, g->stream));
+    s->counts_queued = true;
+    s->records_queued = false;
+    return MODES_OK;
+}
+
+int modes_gather_records(modes_gather *g, uint32_t slot) {
+    Slot *s = slot_of(g, slot);
+    if (!s) return g ? fail(g, MODES_ERR_ARG, "records: slot %u of %zu", slot, g->slots.size()) : MODES_ERR_ARG;
+    if (!s->counts_queued || s->records_queued) return fail(g, MODES_ERR_STATE, "records: call modes_gather_counts for slot %u first", slot);
+    HIP_TRY(g, hipSetDevice(g->cfg.device));
+    HIP_TRY(g, hipEventSynchronize(s->ev_counts));                           // the step's one synchronisation
+    const int n = g->cfg.nranks, me = g->cfg.rank;
+    s->total = 0;
+    for (int r = 0; r < n; r++) {
+        s->counts[(size_t)r] = s->h_all[r];
+        s->total += s->h_all[r];
+        if (s->h_all[r] > g->cfg.cap_records) {                              // every rank sees the same lengths: all fail together
+            s->counts_queued = false;
+            return fail(g, MODES_ERR_OVERFLOW, "rank %d produced %llu records, the gather buffers hold %u per rank", r,
+                        (unsigned long long)s->h_all[r], g->cfg.cap_records);
+        }
+    }
+    const size_t rec = sizeof(modes_record);
+    HIP_TRY(g, hipEventRecord(s->ev_r0, g->stream));
+    s->loopback = false;
+    uint64_t ops = 0, rx = 0, tx = 0;
+    NCCL_TRY(g, ncclGroupStart());
+    if (me == 0) {
+        // rank order = stream order: the root's own list already sits at the front, every other list lands behind its predecessor's
+        size_t off = (size_t)s->counts[0] * rec;
+        for (int r = 1; r < n; r++) {
+            const size_t nb = (size_t)s->counts[(size_t)r] * rec;
+            if (nb == 0) continue;
+            NCCL_TRY(g, ncclRecv(s->d_records + off, nb, ncclUint8, r, g->comm, g->stream));
+            off += nb;
+            rx += nb;
+            ops++;
+        }
+        if (n == 1 && s->counts[0]) {                                        // loopback: the same calls on the one GPU there is
+            const size_t nb = (size_t)s->counts[0] * rec, half = (size_t)g->cfg.cap_records * rec;
+            NCCL_TRY(g, ncclRecv(s->d_records + half, nb, ncclUint8, 0, g->comm, g->stream));
+            NCCL_TRY(g, ncclSend(s->d_records, nb, ncclUint8, 0, g->comm, g->stream));
+            rx += nb;
+            tx += nb;
+            ops += 2;
+            s->loopback = true;
+        }
+    } else if (s->counts[(size_t)me]) {
+        const size_t nb = (size_t)s->counts[(size_t)me] * rec;
+        NCCL_TRY(g, ncclSend(s->d_records, nb, ncclUint8, 0, g->comm, g->stream));
+        tx += nb;
+        ops++;
+    }
+    NCCL_TRY(g, ncclGroupEnd());
+    if (me == 0 && s->total) {
+        HIP_TRY(g, hipMemcpyAsync(s->h_records, s->d_records, (size_t)s->total * rec, hipMemcpyDeviceToHost, g->stream));
+        if (s->loopback) {
+            const size_t half = (size_t)g->cfg.cap_records * rec;
+            HIP_TRY(g, hipMemcpyAsync(s->h_records + half, s->d_records + half, (size_t)s->counts[0] * rec, hipMemcpyDeviceToHost, g->stream));
+        }
+    }
+    HIP_TRY(g, hipEventRecord(s->ev_records, g->stream));
+    s->records_queued = true;
+    g->st.calls++;
+    g->st.p2p_ops += ops;
+    g->st.bytes_received += rx;
+    g->st.bytes_sent += tx;
+    return MODES_OK;
+}
+
+int modes_gather_wait(modes_gather *g, uint32_t slot, const modes_record **records, uint64_t *n_records, const uint64_t **counts) {
+    Slot *s = slot_of(g, slot);
+    if (!s) return g ? fail(g, MODES_ERR_ARG, "wait: slot %u of %zu", slot, g->slots.size()) : MODES_ERR_ARG;
+    if (!s->records_queued) return fail(g, MODES_ERR_STATE, "wait: no exchange queued for slot %u", slot);
+    HIP_TRY(g, hipSetDevice(g->cfg.device));
+    HIP_TRY(g, hipEventSynchronize(s->ev_records));
+    float a = 0.f, b = 0.f;
+    (void)hipEventElapsedTime(&a, s->ev_c0, s->ev_counts);
+    (void)hipEventElapsedTime(&b, s->ev_r0, s->ev_records);
+    g->st.gather_ms += a + b;
+    s->counts_queued = s->records_queued = false;
+    if (s->loopback) {
+        const size_t half = (size_t)g->cfg.cap_records * sizeof(modes_record);
+        if (memcmp(s->h_records, s->h_records + half, (size_t)s->counts[0] * sizeof(modes_record)) != 0)
+            return fail(g, MODES_ERR_HIP, "loopback: the record list that went through ncclSend / ncclRecv differs from the one sent");
+    }
+    const bool root = g->cfg.rank == 0;
+    if (records) *records = root && s->total ? reinterpret_cast<const modes_record *>(s->h_records) : nullptr;
+    if (n_records) *n_records = root ? s->total : 0;
+    if (counts) *counts = s->counts.data();
+    return MODES_OK;
+}
+
+int modes_gather_get_stats(const modes_gather *g, modes_gather_stats *out) {
+    if (!g || !out) return MODES_ERR_ARG;
+    *out = g->st;
+    return MODES_OK;
+}
+
+}  // extern "C"

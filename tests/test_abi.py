@@ -34,6 +34,27 @@ def test_gpu_library_exports_header():
     assert L.modes_gpu_abi_version() == 4
 
 
+def test_gather_library_exports_header():
+    """libmodes_gather.so (the record gather over RCCL a C host binds): built in-tree, loads (it links librccl, no GPU
+    needed for that) and exports what include/modes_gather.h declares."""
+    names = declared("modes_gather.h")
+    assert sorted(N.GATHER_SYMBOLS) == names
+    assert os.path.exists(N.GATHER_LIB), "libmodes_gather.so must be built in-tree"
+    L = N.gather_lib()
+    for n in names:
+        assert getattr(L, n)
+    assert L.modes_gather_abi_version() == 1
+    assert C.sizeof(N.GatherConfig) == 24 and C.sizeof(N.GatherStats) == 56
+    # without a device the create fails loudly, with a text
+    import torch
+    if not torch.cuda.is_available():
+        ident = (C.c_ubyte * 128)()
+        h = C.c_void_p()
+        cfg = N.GatherConfig(0, 0, 1, 1024, 0, 0)
+        assert L.modes_gather_create(C.byref(cfg), ident, C.byref(h)) < 0 and not h.value
+        assert L.modes_gather_last_error(None)
+
+
 def test_struct_layouts():
     assert C.sizeof(N.Attempt) == 28 and C.sizeof(N.Record) == 64
     assert N.RECORD_DTYPE.itemsize == 64 and N.RECORD_DTYPE.fields["att"][1] == 8

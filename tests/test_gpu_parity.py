@@ -1,5 +1,6 @@
 """-m gpu: the HIP path (through the C ABI) against the oracle, bit for bit."""
 import hashlib
+import json
 import os
 import subprocess
 
@@ -9,6 +10,7 @@ import pytest
 import oracle as orc
 import synth
 from helpers import assert_records_equal, maxfix_of, oracle_records
+from dump1090_amd import _native as N
 
 pytestmark = pytest.mark.gpu
 
@@ -215,6 +217,75 @@ def test_cli_reproduces_reference_stdout(torch_cuda, flags, lines, md5):
     data = open(os.path.join(ROOT, "tests", "golden", "modes1.bin"), "rb").read()
     p2 = subprocess.run([exe, "--ifile", "-"] + flags, input=data, capture_output=True, check=True)
     assert p2.stdout == p.stdout
+
+
+@pytest.mark.parametrize("flags,name", [(["--raw"], "default"), (["--raw", "--aggressive"], "aggressive"), (["--raw", "--no-fix"], "nofix"),
+                                        (["--onlyaddr"], None), ([], None)])
+def test_cli_one_process_per_gpu_gathers_over_rccl(torch_cuda, golden, streams, tmp_path, flags, name):
+    """dump1090_amd --ranks 1: the one-process-per-GPU host - unique id, communicator, device output buffers, length
+    all-gather, the list through ncclSend / ncclRecv (to itself: the group has one rank), rank 0's resolve - on the GPU at
+    hand.  Same stdout as the single-process host and, for --raw, as the reference; several rounds (small batches, three
+    slots in rotation), the EOF batch included."""
+    exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
+    for case, batch in (("modes1", 1), ("frames", 2), ("edges_smear", 4)):
+        path = tmp_path / (case + ".bin")
+        streams[case].tofile(path)
+        one = subprocess.run([exe, "--ifile", str(path), "--batch-blocks", str(batch)] + flags, capture_output=True, check=True)
+        p = subprocess.run([exe, "--ifile", str(path), "--batch-blocks", str(batch), "--ranks", "1", "--timing"] + flags, capture_output=True)
+        assert p.returncode == 0, p.stderr[-600:]
+        assert p.stdout == one.stdout and len(p.stdout) > 0, (case, flags)
+        if name is not None:
+            assert p.stdout.decode() == golden[case]["raw"][name]["text"], (case, name)
+        t = json.loads([ln for ln in p.stderr.decode().splitlines() if ln.startswith("{")][-1])
+        assert t["ranks"] == 1 and t["rounds"] == streams[case].size // (batch * 262144) + 1
+        assert t["rccl"]["p2p_ops"] >= 2 and t["rccl"]["bytes_received"] >= 64 and t["rccl"]["version"] > 20000
+
+
+def test_gather_library_overflow_and_state_errors(torch_cuda, streams):
+    """include/modes_gather.h through ctypes, one rank: a list longer than the gather buffers is MODES_ERR_OVERFLOW from
+    modes_gather_records (where every rank would see it), calls out of order are MODES_ERR_STATE, and after an exchange
+    rank 0 holds the records the detect produced."""
+    import ctypes as C
+    from dump1090_amd import Demodulator
+    L = N.gather_lib()
+    iq = to_dev(torch_cuda, streams["frames"])
+    want = None
+    for cap in (1 << 14, 8):
+        ident = (C.c_ubyte * 128)()
+        assert L.modes_gather_unique_id(ident) == 0                        # one id per communicator
+        cfg = N.GatherConfig(0, 0, 1, cap, 2, 0)
+        h = C.c_void_p()
+        assert L.modes_gather_create(C.byref(cfg), ident, C.byref(h)) == 0, L.modes_gather_last_error(None)
+        d_rec, d_cnt, capacity = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        assert L.modes_gather_output(h, 1, C.byref(d_rec), C.byref(capacity), C.byref(d_cnt)) == 0 and capacity.value == cap
+        assert L.modes_gather_output(h, 2, C.byref(d_rec), C.byref(capacity), C.byref(d_cnt)) == -1            # no such slot
+        assert L.modes_gather_records(h, 1) == -5 and L.modes_gather_wait(h, 1, None, None, None) == -5           # nothing queued
+        d = Demodulator()
+        assert N.gpu_lib().modes_gpu_set_output(d._h, d_rec, cap, d_cnt) == 0
+        d.detect(iq)
+        if cap > 8:
+            n, _ = d.fetch_device()
+            assert L.modes_gather_counts(h, 1) == 0 and L.modes_gather_counts(h, 1) == -5                        # one exchange per slot at a time
+            assert L.modes_gather_records(h, 1) == 0
+            recs, nrec, counts = C.c_void_p(), C.c_uint64(), C.POINTER(C.c_uint64)()
+            assert L.modes_gather_wait(h, 1, C.byref(recs), C.byref(nrec), C.byref(counts)) == 0, L.modes_gather_last_error(h)
+            assert nrec.value == n == counts[0] and n > 100
+            got = np.frombuffer((C.c_uint8 * (n * 64)).from_address(recs.value), dtype=N.RECORD_DTYPE).copy()
+            d2 = Demodulator()
+            d2.detect(iq)
+            want = d2.fetch()[0]
+            d2.close()
+            assert np.array_equal(got, want)
+            st = N.GatherStats()
+            assert L.modes_gather_get_stats(h, C.byref(st)) == 0 and st.p2p_ops == 2 and st.bytes_received == n * 64 and st.gather_ms > 0
+        else:
+            with pytest.raises(N.ModesError, match="OVERFLOW"):
+                d.fetch_device()
+            assert L.modes_gather_counts(h, 1) == 0                       # the true length still travels ...
+            assert L.modes_gather_records(h, 1) == -4                     # ... and fails the exchange on every rank
+            assert b"gather buffers hold 8" in L.modes_gather_last_error(h)
+        d.close()
+        L.modes_gather_destroy(h)
 
 
 @pytest.mark.parametrize("flag,golden_file", [("--sbs", "modes1_sbs.txt"), ("--raw-net", "modes1_rawnet.txt")])
