@@ -1378,7 +1378,7 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
 }
 
 // ------------------------------------------------------------------------------------
-// The demodulation in TWO kernels (demod_variant 0, production from round 3):
+// The demodulation in TWO kernels (demod_variant 2; demod_variant 0 takes it for calls that follow a record-rich call):
 //
 //   select_kernel   stages 1 and 2 for EVERY forwarded position - the exact preamble predicate and the noise-gate
 //                   pre-test - and nothing else: on noise that is all there is to do (~270,000 preambles per GiB, none of
@@ -1391,9 +1391,9 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
 //                   list, no keys, no order kernel).  A workgroup whose batches have no survivor retires before it
 //                   stages a table: on noise the kernel is a few microseconds.
 //
-// demod_kernel (one kernel, stage 3 inline, staging + keys + order) stays as demod_variant 1: the independent second
-// implementation the parity tests cross-check.
+// demod_kernel (one kernel, stage 3 inline, staging + keys + order) is what record-free input runs on (demod_variant 3: always).
 // ------------------------------------------------------------------------------------
+constexpr double kSplitAbove = 4096.0;                     // records per GiB beyond which demod_variant 0 takes the two-kernel path
 constexpr int kSelWaves = 16;
 constexpr int kSelThreads = kSelWaves * 64;
 constexpr int kSelLanes = 8;                               // lanes per preamble in the gate pre-test
@@ -2127,6 +2127,10 @@ struct modes_gpu {
     double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     uint32_t demod_wgs = 1024;        // workgroups of demod_kernel that are resident at once (occupancy x CUs)
+    uint32_t select_wgs = 512;        // ... of select_kernel
+    // demod_variant 0 chooses per call: the one-kernel path on (nearly) record-free input, select + record when the
+    // previous call of this context left more than kSplitAbove records per GiB (+4 % there, -4 % on noise)
+    double records_per_gib = 0.0;
     bool auto_records = false;        // max_records was 0: the record list grows when a call needs more
     bool full_slots = false;          // a run once overflowed the automatic slot_cap: size the lists for the worst case
     modes_gpu_span last_span{};       // what the detect in flight was asked to do (for the overflow retry)
@@ -2225,10 +2229,11 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
         hipDeviceProp_t prop;
         int per_cu = 0;
         CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
-        if (ctx->cfg.demod_variant == 2)      CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, select_kernel, kSelThreads, 0));
-        else if (ctx->cfg.demod_variant == 1) CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<4, LutSmall>, 256, 0));
-        else                                  CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<8, LutFull>, 512, 0));
+        if (ctx->cfg.demod_variant == 1) CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<4, LutSmall>, 256, 0));
+        else                             CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<8, LutFull>, 512, 0));
         ctx->demod_wgs = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, prop.multiProcessorCount);
+        CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, select_kernel, kSelThreads, 0));
+        ctx->select_wgs = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, prop.multiProcessorCount);
     }
     for (auto &e : ctx->ev_k) CREATE_TRY(hipEventCreate(&e));
     CREATE_TRY(hipEventCreate(&ctx->ev_done));
@@ -2247,7 +2252,7 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     CREATE_TRY(hipMemcpy(ctx->d_lut, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(ctx->d_esyn, esyn, sizeof esyn, hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hdr), sizeof(ResultHeader)));
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_totals), sizeof(WgTotals) * ctx->demod_wgs));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_totals), sizeof(WgTotals) * std::max(ctx->demod_wgs, ctx->select_wgs)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_wg_flags), sizeof(uint32_t) * 512));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hdr), sizeof(HostHeader), hipHostMallocMapped));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_hdr_dev), ctx->h_hdr, 0));
@@ -2412,7 +2417,8 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     const uint32_t nbatches = (nruns + kDemodGroup - 1) / kDemodGroup;      // demod_kernel's unit of work, of candidate lists and of record order
     size_t want = (size_t)nbatches * kDemodGroup * cap * sizeof(uint32_t);
     if ((rc = grow(ctx, &ctx->d_slots, &ctx->slots_bytes, want)) != MODES_OK) return rc;
-    if (ctx->cfg.demod_variant == 2 && (rc = grow(ctx, &ctx->d_surv, &ctx->surv_bytes, want)) != MODES_OK) return rc;
+    const bool split = ctx->cfg.demod_variant == 2 || (ctx->cfg.demod_variant == 0 && ctx->records_per_gib > kSplitAbove);
+    if (split && (rc = grow(ctx, &ctx->d_surv, &ctx->surv_bytes, want)) != MODES_OK) return rc;
     if (ctx->cfg.keep_candidates && (rc = grow(ctx, &ctx->d_cand_slots, &ctx->cand_slots_bytes, want)) != MODES_OK) return rc;
     if (ctx->counts_elems < nruns) {
         if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -2517,8 +2523,8 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
         if (!timed) HIP_TRY(ctx, hipEventRecord(ek[1], st));
         HIP_TRY(ctx, hipStreamWaitEvent(st2, ek[1], 0));
     }
-    ctx->demod_grid = std::min<uint32_t>(nbatches, ctx->demod_wgs);        // every workgroup's first batch; the rest are dealt dynamically
-    ctx->split_path = ctx->cfg.demod_variant == 2;
+    ctx->split_path = split;
+    ctx->demod_grid = std::min<uint32_t>(nbatches, split ? ctx->select_wgs : ctx->demod_wgs);   // persistent workgroups: what is resident at once
     if (ctx->split_path) {
         SelectParams sel{};
         sel.iq = sp.iq; sel.lo = sp.lo; sel.hi = sp.hi;
@@ -2693,6 +2699,7 @@ static int finish_detect(modes_gpu *ctx, modes_gpu_result *res, bool to_host) {
     HIP_TRY(ctx, hipStreamSynchronize(st));
     // candidates: the workgroup lists keep no order inside a block of positions
     std::sort(ctx->h_cands.begin(), ctx->h_cands.end());
+    ctx->records_per_gib = (double)n_records * 1073741824.0 / (double)std::max<uint64_t>(ctx->last_span.nbytes, 1);
     res->records = to_host ? ctx->h_records : d_list;
     res->n_records = n_records;
     res->candidates = ctx->h_cands.empty() ? nullptr : ctx->h_cands.data();

@@ -67,13 +67,14 @@ typedef struct {
     uint32_t flags;            /* MODES_GPU_* below                                                       */
     uint32_t direct_records;   /* lists of at most this many records reach the host with the kernels
                                   (zero-copy stores, no copy operation); 0 = 4096                          */
-    uint32_t demod_variant;    /* 0 = one kernel: 8-wave workgroups with the whole 64 KiB magnitude table in LDS, every stage
-                                  inline, records put in order behind it (production); 1 = the same with 4-wave workgroups,
-                                  a 1 KiB table and the exact square root beyond it (cross-check implementation, frozen);
-                                  2 = two kernels: select (preamble test + noise-gate pre-test, 16 wavefronts at 64 VGPRs)
-                                  and record (one wavefront per survivor, written straight to its final place: no staging
-                                  list, no order kernel) - 4-5 % faster where there are records, 3 % slower on pure noise
-                                                                                                         */
+    uint32_t demod_variant;    /* 0 = automatic (production): one kernel - 8-wave workgroups with the whole 64 KiB magnitude
+                                  table in LDS, every stage inline, records put in order behind it - unless the context's
+                                  previous call left more than 4096 records per GiB: then two kernels, select (preamble test +
+                                  noise-gate pre-test, 16 wavefronts at 64 VGPRs) and record (one wavefront per survivor,
+                                  written straight to its final place: no staging list, no order kernel): 4 % faster where
+                                  there are records, 4 % slower on pure noise.  3 = always the one kernel,
+                                  2 = always the two; 1 = the one kernel with 4-wave workgroups, a 1 KiB table and the exact
+                                  square root beyond it (cross-check implementation, frozen)                              */
 } modes_gpu_config;
 
 /* modes_gpu_config.flags */

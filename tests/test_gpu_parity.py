@@ -145,7 +145,7 @@ def test_synth_noise_matches_host_generator(torch_cuda):
     d.close()
 
 
-@pytest.mark.parametrize("demod_variant", [0, 1, 2])
+@pytest.mark.parametrize("demod_variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", CASES)
 def test_records_and_candidates_match_oracle(torch_cuda, streams, case, demod_variant):
     """Both demod kernels: the production one (8 waves, the whole table in LDS) and the independent second
@@ -163,6 +163,27 @@ def test_records_and_candidates_match_oracle(torch_cuda, streams, case, demod_va
         assert info["n_preambles"] == want_cands.size and info["n_forwarded"] >= want_cands.size
         assert_records_equal(recs, want, ctx=(case, mf))
         d.close()
+
+
+def test_automatic_demod_path_follows_the_record_density(torch_cuda, streams):
+    """demod_variant 0: a context's first call and calls behind record-free ones run the one-kernel path; a call that follows
+    a record-rich call (> 4096 records per GiB) runs select + record.  Same records either way; which path ran shows in the
+    third kernel's time (the record kernel is timed on the two-kernel path; a short list needs no order kernel on the other)."""
+    from dump1090_amd import Demodulator
+    rich, quiet = to_dev(torch_cuda, streams["frames"]), to_dev(torch_cuda, streams["noise"])
+    want, _ = oracle_records(streams["frames"], 1)
+    d = Demodulator()
+    seen = []
+    for iq, expect in ((rich, want), (rich, want), (quiet, None), (rich, want), (rich, want)):
+        d.detect(iq)
+        recs, _, info = d.fetch()
+        seen.append(info["order_ms"] > 0)
+        if expect is not None:
+            assert_records_equal(recs, expect, ctx=("auto", len(seen)))
+        else:
+            assert recs.size == 0
+    assert seen == [False, True, True, False, True], seen       # the call AFTER a rich one is the first on the other path
+    d.close()
 
 
 @pytest.mark.parametrize("case", CASES)
