@@ -35,11 +35,23 @@ def reference_stdout(data: np.ndarray, flagset: str, mode: str) -> str:
     return orc.raw_text(msgs) if mode == "--raw" else orc.stats_text(st)
 
 
-def build_on_device(torch, d, st: synth.SparseFrameStream):
-    """synth_noise + scatter of the frames' footprints + 127-tail: the stream `st`, resident in HBM."""
+def build_on_device(torch, d, st: synth.SparseFrameStream, by_deltas=False):
+    """synth_noise + scatter of the frames' footprints + 127-tail: the stream `st`, resident in HBM.  The footprints come
+    finished from the host (st.patches(): numpy's copy of the noise under them) or - by_deltas, what bench.py does: seconds
+    instead of a minute for 524,287 frames - as what the frames ADD to the device's own noise (st.deltas())."""
     iq = torch.empty(st.nbytes, dtype=torch.uint8, device="cuda:0")
     d.synth_noise(iq, 0, seed=st.seed, sigma_q16=st.sigma_q16)
-    first, data = st.patches()
+    if by_deltas:
+        first, delta = st.deltas()
+        cols = torch.arange(delta.shape[1], device="cuda:0")[None, :]
+        for a in range(0, len(first), 65536):
+            idx = torch.from_numpy(first[a:a + 65536]).to("cuda:0")[:, None] + cols
+            keep = idx < st.nbytes
+            at = idx[keep]
+            iq[at] = (iq[at].to(torch.int16) + torch.from_numpy(delta[a:a + 65536]).to("cuda:0")[keep]).clamp_(0, 255).to(torch.uint8)
+        first = first[:0]
+    else:
+        first, data = st.patches()
     if len(first):
         idx = torch.from_numpy(first).to("cuda:0")[:, None] + torch.arange(data.shape[1], device="cuda:0")[None, :]
         iq[idx.reshape(-1)] = torch.from_numpy(data).to("cuda:0").reshape(-1)
@@ -161,15 +173,9 @@ def test_config4_sixty_four_gib_in_eight_shards_matches_reference(torch_cuda):
     free, _ = torch.cuda.mem_get_info()
     if free < nblocks * synth.DATA_LEN * 1.2:
         pytest.skip("not enough free HBM for the 64 GiB stream")
-    avail = 0
-    for line in open("/proc/meminfo"):
-        if line.startswith("MemAvailable:"):
-            avail = int(line.split()[1]) * 1024
-    if avail < nblocks * synth.DATA_LEN * 1.3:
-        pytest.skip("not enough host memory to hand the 64 GiB stream to the reference")
     st = synth.config3_stream(4, nblocks)
     d = Demodulator()
-    iq = build_on_device(torch, d, st)
+    iq = build_on_device(torch, d, st, by_deltas=True)
     total = block_count(st.nbytes)
     recs = []
     for rank in range(8):
@@ -187,8 +193,15 @@ def test_config4_sixty_four_gib_in_eight_shards_matches_reference(torch_cuda):
     res = HostResolver()
     got = raw_text(res.resolve(np.concatenate(recs), None))
     res.close()
-    want = reference_stdout(iq.cpu().numpy(), "default", "--raw")
+    # The reference's verdict on this very stream is committed (tests/golden/config_listings.json: the compiled reference fed
+    # the same bytes by tests/golden/gen_stream.c in the build container); MODES_LIVE_REFERENCE=1 also runs the binary here
+    # (3 more minutes and 64 GiB of host memory).
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_listings.json")) as f:
+        gold = json.load(f)["frames:4:%d" % nblocks]
     assert got.count("\n") > 500000
-    assert hashlib.md5(got.encode()).hexdigest() == hashlib.md5(want.encode()).hexdigest(), \
-        "listing differs from the reference (%d vs %d lines)" % (got.count("\n"), want.count("\n"))
+    assert (got.count("\n"), hashlib.md5(got.encode()).hexdigest()) == (gold["lines"], gold["md5"]), \
+        "listing differs from the reference's (%d vs %d lines)" % (got.count("\n"), gold["lines"])
+    if os.environ.get("MODES_LIVE_REFERENCE") == "1":
+        want = reference_stdout(iq.cpu().numpy(), "default", "--raw")
+        assert hashlib.md5(got.encode()).hexdigest() == hashlib.md5(want.encode()).hexdigest()
     d.close()

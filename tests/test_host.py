@@ -282,3 +282,18 @@ def test_a_listing_that_outgrows_its_buffer_is_cut_at_a_line(streams):
                 # as many whole lines as fit: the next line would not have
                 nxt = text0[len(stored):].split(b"\n")[0] + b"\n"
                 assert len(stored) + len(nxt) + 1 > cap, (cap, pieces)
+
+
+def test_c_host_under_thread_sanitizer():
+    """tools/sanitize_host.sh tsan-host: dump1090_amd/csrc/main.cpp - reader thread, resolver thread, lanes of two and three
+    "devices" handed between them - built under -fsanitize=thread with the GPU library replaced by tests/native/gpu_stub.cpp
+    (the oracle's stateless functions behind the same entry points).  No race, and the reference's md5s for --raw, --stats
+    and --onlyaddr (the script checks both)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "tsan-host"], capture_output=True, timeout=600)
+    assert p.returncode == 0 and b"ThreadSanitizer" not in p.stderr + p.stdout, (p.stdout[-800:], p.stderr[-800:])
+    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 2

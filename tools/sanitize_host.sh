@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs the CPU tests of the host library and of the header-only device arithmetic against sanitizer builds:
 #   tools/sanitize_host.sh                 UBSan, then ASan, then TSan
-#   tools/sanitize_host.sh ubsan|asan|tsan one of them
+#   tools/sanitize_host.sh ubsan|asan|tsan|tsan-host one of them
 # tsan: the multi-threaded resolve (modes_host_resolve_raw_mt: worker pool, speculative pieces) in a C++ harness built
 # together with the host sources under -fsanitize=thread, on the records of the reference's capture.
 # (-fno-sanitize-recover / abort_on_error: any finding kills the test process).  The host library is built with
@@ -55,9 +55,30 @@ PY
         dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp -lpthread -lm
     TSAN_OPTIONS=halt_on_error=1 /tmp/modes_mt_harness /tmp/modes_mt_records.bin
 }
+# tsan-host: the C host itself (dump1090_amd/csrc/main.cpp: reader thread, resolver thread, lanes of two "devices" handed
+# between them) under ThreadSanitizer, the GPU library replaced by tests/native/gpu_stub.cpp (the oracle's stateless
+# functions behind the same entry points) - listing and --stats must be the reference's, and no race may be reported.
+run_tsan_host() {
+    echo "== tsan-host =="
+    gcc -O1 -g -fsanitize=thread -c -o /tmp/modes_oracle_tsan.o oracle/modes_oracle.c
+    g++ -O1 -g -std=c++17 -fsanitize=thread -Iinclude -o /tmp/dump1090_amd_tsan dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+        dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp /tmp/modes_oracle_tsan.o -lpthread -lm -ldl
+    # the reference's md5s of BASELINE.md section 4 (--raw, --stats, --onlyaddr)
+    check() { want=$1; shift
+        TSAN_OPTIONS=halt_on_error=1 /tmp/dump1090_amd_tsan --ifile tests/golden/modes1.bin "$@" > /tmp/tsan_host.out
+        got=$(md5sum < /tmp/tsan_host.out | cut -c1-32)
+        echo "   $*: $(wc -l < /tmp/tsan_host.out) lines, md5 $got"
+        [ "$got" = "$want" ] || { echo "   expected $want"; exit 1; }
+    }
+    check 4a81758c8bec5e45ffa8541c5622938a --raw
+    check 4a81758c8bec5e45ffa8541c5622938a --raw --gpu-list 0,0 --batch-blocks 1 --depth 2
+    check bc3d1c04b24f4989f0fc4a2d1f45abdd --stats --gpu-list 0,0,0 --batch-blocks 2
+    check bab0f055e262e216208a5cbbdf63fe24 --onlyaddr --gpus 2 --batch-blocks 1 --read-threads 3
+}
 case "${1:-all}" in
     ubsan) run_one ubsan ;;
     asan)  run_one asan ;;
     tsan)  run_tsan ;;
-    *)     run_one ubsan; run_one asan; run_tsan ;;
+    tsan-host) run_tsan_host ;;
+    *)     run_one ubsan; run_one asan; run_tsan; run_tsan_host ;;
 esac
