@@ -83,3 +83,26 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
                        capture_output=True, timeout=900)
     assert p.returncode == 0, p.stderr[-1500:]
     check(parse(p.stdout), 2)
+
+
+def test_bench_eight_ranks_at_full_size_reproduce_the_reference_listings():
+    """The command the 8-GPU lease runs - `python bench.py --gpus 8`, BASELINE's sizes: 1 GiB of noise, 8 GiB of frames, 1 GiB
+    low SNR per rank, the 64 GiB stream - with the eight ranks sharing this box's one GPU and the lists travelling over gloo
+    (RCCL refuses two ranks on one device): sharding, carry, the gather's bookkeeping, rank 0's resolve of eight ranks'
+    records and the committed reference listings of the N = 8 streams (64 GiB: 524,155 messages; 8 GiB low SNR: 20,351)
+    are all on the path; only the transport differs from the real thing."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 * 2 ** 30:
+        pytest.skip("needs ~90 GiB of free HBM for eight ranks' shards")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, timeout=1200, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = parse(p.stdout)
+    assert j["n_gpus"] == 8 and len(j["kernel_ms_per_rank"]) == 8
+    for leg, lines in (("frames", 524155), ("lowsnr", 20351), ("frames_strong", 524155)):
+        lc = j[leg]["listing_check"]
+        assert lc["equals_reference_md5"] is True and lc["lines"] == lines, (leg, lc)
+        assert j[leg]["rccl"]["nranks"] == 8 and j[leg]["rccl"]["p2p_ops_per_step"] >= 7      # seven lists travel to rank 0 per call
+    assert j["frames_strong"]["same_run_as"] == "frames" and j["frames_strong"]["scaling"] == "strong"
