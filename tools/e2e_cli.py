@@ -45,7 +45,7 @@ def run(extra, mode="--raw"):
 run([])                                                     # page cache / driver warm-up, not reported
 for extra in ([], ["--read-threads", "8"], ["--read-threads", "32"], ["--no-mmap"], ["--no-mmap", "--read-threads", "8"],
               ["--no-mmap", "--read-threads", "32"], ["--batch-blocks", "256"], ["--batch-blocks", "1024"], ["--depth", "2"],
-              ["--depth", "4"], ["--gpu-list", "0,0"], []):
+              ["--depth", "4"], ["--gpu-list", "0,0"], ["--ranks", "1"], []):
     out["runs"].append(run(extra))
 out["stats_mode"] = run([], mode="--stats")
 best = max(out["runs"], key=lambda r: r["stream_GBps"] or 0)
