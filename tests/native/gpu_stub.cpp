@@ -21,6 +21,9 @@ struct modes_gpu {
     std::vector<modes_record> recs;
     std::vector<uint64_t> cands;
     std::string err;
+    modes_record *out_records = nullptr;         // modes_gpu_set_output: the caller's "device" list and its length
+    uint64_t out_cap = 0;
+    unsigned long long *out_count = nullptr;
 };
 
 extern "C" {
@@ -91,8 +94,21 @@ int modes_gpu_fetch(modes_gpu *g, modes_gpu_result *res) {
     return MODES_OK;
 }
 
-// (--ranks is not part of this run: it needs RCCL and one process per GPU)
-int modes_gpu_set_output(modes_gpu *g, void *, uint64_t, void *) { g->err = "stub: no device output"; return MODES_ERR_ARG; }
-int modes_gpu_fetch_device(modes_gpu *g, modes_gpu_result *) { g->err = "stub: no device output"; return MODES_ERR_ARG; }
+// --ranks: the caller's list and length (with tests/native/gather_stub.cpp: cells of a shared-memory segment)
+int modes_gpu_set_output(modes_gpu *g, void *d_records, uint64_t capacity, void *d_count) {
+    g->out_records = static_cast<modes_record *>(d_records);
+    g->out_cap = capacity;
+    g->out_count = static_cast<unsigned long long *>(d_count);
+    return MODES_OK;
+}
+int modes_gpu_fetch_device(modes_gpu *g, modes_gpu_result *res) {
+    const int rc = modes_gpu_fetch(g, res);
+    if (rc != MODES_OK) return rc;
+    if (g->out_count) *g->out_count = g->recs.size();                      // the true length, whatever fits
+    if (g->recs.size() > g->out_cap) { g->err = "records exceed max_records"; return MODES_ERR_OVERFLOW; }
+    if (g->out_records) memcpy(g->out_records, g->recs.data(), g->recs.size() * sizeof(modes_record));
+    res->records = g->out_records;
+    return MODES_OK;
+}
 
 }  // extern "C"

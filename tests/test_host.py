@@ -297,3 +297,19 @@ def test_c_host_under_thread_sanitizer():
     p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "tsan-host"], capture_output=True, timeout=600)
     assert p.returncode == 0 and b"ThreadSanitizer" not in p.stderr + p.stdout, (p.stdout[-800:], p.stderr[-800:])
     assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 2
+
+
+def test_c_host_one_process_per_gpu_with_two_and_three_processes():
+    """tools/sanitize_host.sh ranks-host: `dump1090_amd --ranks N` with N = 1, 2, 3 real processes on this machine - the GPU
+    library stubbed by the oracle (tests/native/gpu_stub.cpp), include/modes_gather.h implemented over shared memory
+    (tests/native/gather_stub.cpp, the libmodes_gather.so the host dlopens): the fork, the id pipes, round-robin batches,
+    gather rounds in three rotating slots, ranks that have no batch in a round, the EOF batch.  stdout is the reference's
+    for every N and batch size (the script compares the md5s)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "ranks-host"], capture_output=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-800:], p.stderr[-800:])
+    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 9 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout

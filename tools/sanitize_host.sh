@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs the CPU tests of the host library and of the header-only device arithmetic against sanitizer builds:
 #   tools/sanitize_host.sh                 UBSan, then ASan, then TSan
-#   tools/sanitize_host.sh ubsan|asan|tsan|tsan-host one of them
+#   tools/sanitize_host.sh ubsan|asan|tsan|tsan-host|ranks-host one of them
 # tsan: the multi-threaded resolve (modes_host_resolve_raw_mt: worker pool, speculative pieces) in a C++ harness built
 # together with the host sources under -fsanitize=thread, on the records of the reference's capture.
 # (-fno-sanitize-recover / abort_on_error: any finding kills the test process).  The host library is built with
@@ -75,10 +75,32 @@ run_tsan_host() {
     check bc3d1c04b24f4989f0fc4a2d1f45abdd --stats --gpu-list 0,0,0 --batch-blocks 2
     check bab0f055e262e216208a5cbbdf63fe24 --onlyaddr --gpus 2 --batch-blocks 1 --read-threads 3
 }
+# ranks-host: the one-process-per-GPU mode of the C host (dump1090_amd --ranks N) with N = 1, 2, 3 PROCESSES on this machine:
+# the GPU stub above plus tests/native/gather_stub.cpp (include/modes_gather.h over shared memory instead of RCCL, built as
+# the libmodes_gather.so the host dlopens) - fork, id pipes, round-robin batches, gather rounds, ranks without a batch, the EOF
+# batch; stdout must be the reference's for every N and batch size.
+run_ranks_host() {
+    echo "== ranks-host =="
+    D=/tmp/modes_ranks_host
+    mkdir -p $D
+    gcc -O1 -g -c -o $D/modes_oracle.o oracle/modes_oracle.c
+    g++ -O1 -g -std=c++17 -Iinclude -o $D/dump1090_amd_stub dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+        dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp $D/modes_oracle.o -lpthread -lm -ldl -rdynamic
+    g++ -O1 -g -std=c++17 -fPIC -shared -Iinclude -o $D/libmodes_gather.so tests/native/gather_stub.cpp -lpthread -lrt
+    for n in 1 2 3; do for bb in 1 2 5; do
+        got=$($D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw --ranks $n --batch-blocks $bb | md5sum | cut -c1-32)
+        echo "   --ranks $n --batch-blocks $bb: md5 $got"
+        [ "$got" = 4a81758c8bec5e45ffa8541c5622938a ] || { echo "   expected 4a81758c8bec5e45ffa8541c5622938a"; exit 1; }
+    done; done
+    got=$($D/dump1090_amd_stub --ifile tests/golden/modes1.bin --onlyaddr --ranks 3 --batch-blocks 1 | md5sum | cut -c1-32)
+    [ "$got" = bab0f055e262e216208a5cbbdf63fe24 ] || { echo "   --onlyaddr: $got"; exit 1; }
+    echo "   --onlyaddr --ranks 3: md5 $got"
+}
 case "${1:-all}" in
     ubsan) run_one ubsan ;;
     asan)  run_one asan ;;
     tsan)  run_tsan ;;
     tsan-host) run_tsan_host ;;
-    *)     run_one ubsan; run_one asan; run_tsan; run_tsan_host ;;
+    ranks-host) run_ranks_host ;;
+    *)     run_one ubsan; run_one asan; run_tsan; run_tsan_host; run_ranks_host ;;
 esac
