@@ -375,7 +375,6 @@ __device__ unsigned long long g_trace[8192 * 8];      // per demod wavefront: st
 constexpr uint32_t kNoPos = 0xFFFFFFFFu;          // a survivor whose first gate failed after all (edge of the span)
 constexpr uint64_t kNoKey = ~0ull;
 
-// wavefronts per demod workgroup: a template parameter of the kernel (4 with LutSmall, 8 with LutFull)
 constexpr int kDemodGroup = 64;       // runs whose slot lists one demod workgroup walks together (one per lane of a wavefront)
 
 struct DemodParams {
@@ -670,37 +669,15 @@ __device__ __forceinline__ uint32_t load_sample(const uint8_t *iq, int64_t sampl
 __device__ __forceinline__ bool samples_inside(int64_t first, int64_t last, int64_t lo, int64_t hi) {
     return 2 * first >= lo && 2 * last + 2 <= hi;
 }
-// The magnitude table as the demod kernel sees it.  Two forms:
-//   LutFull   the whole table in 64 KiB of LDS, shared by the 8 wavefronts of a workgroup (2 workgroups per CU).  Production.
-//   LutSmall  the first 512 entries (powers below 512: amplitudes below 22 LSB - all of the noise) in 1 KiB of LDS,
-//             modes_mag_exact (a square root and two comparisons, modes_core.h) beyond.  With it a 4-wave demod workgroup
-//             needs < 10 KiB of LDS and fits on a CU NEXT TO the scan kernel's 12 workgroups (153,600 of 163,840 B of LDS,
-//             24 of 32 wave slots).  Built to run the demod kernel of one call under the scan of the next (overlap = 1);
-//             measured (profiles/r02c): 0.079 ms alone against LutFull's 0.050 per GiB of noise, 1.25 against 0.95 ms on
-//             the message-dense capture (strong samples take the square root), and overlapped the step only goes from
-//             0.308 to 0.297 ms: the scan's 6 waves per SIMD leave registers for ONE demod wavefront per SIMD, and one
-//             4-wave workgroup per CU is too little parallelism for a latency-bound kernel - it needs the whole next scan
-//             to finish.  Kept as demod_variant 1: an independent second implementation the parity tests cross-check.
-// fast(idx) is only valid for idx < kEntries (it masks); callers OR their indices together and repeat the few lookups
-// that were out of range through operator[].
-// Also measured and rejected (profiles/r02a): the table left in global memory and read through L1/L2 - 2.5x slower alone
-// and no gain overlapped: 36 M two-byte gathers pull 2 GB of lines through the L2 the scan is streaming 1 GB through.
-struct LutSmall {
-    static constexpr uint32_t kEntries = 512;
-    static constexpr bool kHybrid = true;
-    const uint16_t *p;
-    __device__ __forceinline__ uint32_t fast(uint32_t idx) const { return p[idx & (kEntries - 1)]; }
-    __device__ __forceinline__ uint32_t operator[](uint32_t idx) const { return idx < kEntries ? (uint32_t)p[idx] : modes_mag_exact(idx); }
-};
+// The magnitude table as the demodulation kernels see it: the whole table - the reference's LUT by saturated power - in
+// 64 KiB of LDS, shared by the wavefronts of a workgroup.  (Until round 3 a second form lived here - the first 512 entries
+// in 1 KiB of LDS, modes_mag_exact beyond, for 4-wave workgroups small enough to sit next to the scan kernel's: 0.055-0.079 ms
+// alone against 0.036, and a kernel that runs UNDER the scan slows the scan down by more than it hides - DESIGN.md 3.2.  The
+// table left in global memory and read through L1 / L2: 2.5x slower alone, the scan +28 % - profiles/r02a.)
 struct LutFull {
-    static constexpr uint32_t kEntries = MODES_LUT_ENTRIES;
-    static constexpr bool kHybrid = false;
     const uint16_t *p;
-    __device__ __forceinline__ uint32_t fast(uint32_t idx) const { return p[idx]; }
     __device__ __forceinline__ uint32_t operator[](uint32_t idx) const { return p[idx]; }
 };
-// bits of a packed index pair (idx0 | idx1 << 16) that are set only when one of the two is beyond LutSmall
-constexpr uint32_t kBigPair = ~((LutSmall::kEntries - 1) | ((LutSmall::kEntries - 1) << 16));
 // magnitude of a sample packed as I | Q << 8 (low 16 bits)
 template <class Lut>
 __device__ __forceinline__ int mag_of(const Lut lut, uint32_t iq16) {
@@ -846,41 +823,20 @@ __device__ __forceinline__ bool preamble_at_guarded(const uint8_t *iq, int64_t l
     return modes_preamble_exact(Win{m});
 }
 // Fast form: the 15 samples are two 16-byte loads at a 2-byte aligned address (unaligned-access mode, raw buffer
-// descriptor); voff = byte offset of sample p from the descriptor's base.
-template <bool EXACT, class Lut>
-__device__ __forceinline__ bool preamble_eval(const uint32_t (&idx)[8], const Lut lut) {
-    int m[16];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        m[2 * i] = (int)(EXACT ? lut[idx[i] & 0xffffu] : lut.fast(idx[i] & 0xffffu));
-        m[2 * i + 1] = (int)(EXACT ? lut[idx[i] >> 16] : lut.fast(idx[i] >> 16));
-    }
-    struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
-    return modes_preamble_exact(Win{m});
-}
+// descriptor); voff = byte offset of sample p from the descriptor's base.  Indexed and looked up dword by dword.
 template <class Lut>
 __device__ __forceinline__ bool preamble_at_fast(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, const Lut lut) {
     const u32x4 wa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, kDemodAux), wb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16u, 0, kDemodAux);
     const uint32_t w[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
-    if constexpr (!Lut::kHybrid) {                                           // index and look up dword by dword
-        int m[16];
+    int m[16];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t ix = pk_lut_index(w[i]);
-            m[2 * i] = (int)lut.p[ix & 0xffffu];
-            m[2 * i + 1] = (int)lut.p[ix >> 16];
-        }
-        struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
-        return modes_preamble_exact(Win{m});
+    for (int i = 0; i < 8; i++) {
+        const uint32_t ix = pk_lut_index(w[i]);
+        m[2 * i] = (int)lut.p[ix & 0xffffu];
+        m[2 * i + 1] = (int)lut.p[ix >> 16];
     }
-    uint32_t idx[8], big = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { idx[i] = pk_lut_index(w[i]); big |= idx[i]; }
-    bool ok = preamble_eval<false>(idx, lut);
-    if (Lut::kHybrid && __any((big & kBigPair) != 0)) {                       // a strong sample somewhere in the wavefront
-        if (big & kBigPair) ok = preamble_eval<true>(idx, lut);
-    }
-    return ok;
+    struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
+    return modes_preamble_exact(Win{m});
 }
 
 // Noise-gate pre-test (dump1090.c:1713-1723): the sum of |lo - hi| over 56 consecutive bit pairs
@@ -901,16 +857,17 @@ __device__ __forceinline__ void half_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
     if (t < 2) w[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 192u, 0, kDemodAux);
 }
 // Returns this lane's part of the sum.  *first: flags of the lane's first four pairs (pairs 4t .. 4t+3 of
-// the 56), bit k = |lo - hi| < 256, bit 4 + k = lo > hi, bit 8 = (lo == hi) of its first pair.
-template <bool EXACT, class Lut>
-__device__ __forceinline__ uint32_t half_sum(const uint32_t (&idx)[16], const Lut lut, uint32_t *first) {
+// the 56), bit k = |lo - hi| < 256, bit 4 + k = lo > hi, bit 8 = (lo == hi) of its first pair.  Indexed and looked up
+// dword by dword: the gathers spread over the VALU work.
+template <class Lut>
+__device__ __forceinline__ uint32_t half_eval(const u32x4 (&w)[4], const Lut lut, uint32_t *first) {
     uint32_t acc = 0, f = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t ix = idx[4 * i + k];                              // both LUT indices
-            const uint32_t a = EXACT ? lut[ix & 0xffffu] : lut.fast(ix & 0xffffu), b = EXACT ? lut[ix >> 16] : lut.fast(ix >> 16);
+            const uint32_t ix = pk_lut_index(w[i][k]);                       // both LUT indices
+            const uint32_t a = lut.p[ix & 0xffffu], b = lut.p[ix >> 16];
             if (i == 0 && first) {
                 const uint32_t d = __builtin_amdgcn_sad_u16(a, b, 0u);
                 f |= (d < 256u ? 1u : 0u) << k | (a > b ? 1u : 0u) << (4 + k);
@@ -922,40 +879,6 @@ __device__ __forceinline__ uint32_t half_sum(const uint32_t (&idx)[16], const Lu
         }
     }
     if (first) *first = f;
-    return acc;
-}
-template <class Lut>
-__device__ __forceinline__ uint32_t half_eval(const u32x4 (&w)[4], const Lut lut, uint32_t *first) {
-    if constexpr (!Lut::kHybrid) {                                           // index and look up dword by dword: the gathers spread over the VALU work
-        uint32_t acc = 0, f = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t ix = pk_lut_index(w[i][k]);                   // both LUT indices
-                const uint32_t a = lut.p[ix & 0xffffu], b = lut.p[ix >> 16];
-                if (i == 0 && first) {
-                    const uint32_t d = __builtin_amdgcn_sad_u16(a, b, 0u);
-                    f |= (d < 256u ? 1u : 0u) << k | (a > b ? 1u : 0u) << (4 + k);
-                    if (k == 0) f |= (a == b ? 1u : 0u) << 8;
-                    acc += d;
-                } else {
-                    acc = __builtin_amdgcn_sad_u16(a, b, acc);               // += |a - b| (high halves are zero)
-                }
-            }
-        }
-        if (first) *first = f;
-        return acc;
-    }
-    uint32_t idx[16], big = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) { idx[4 * i + k] = pk_lut_index(w[i][k]); big |= idx[4 * i + k]; }
-    uint32_t acc = half_sum<false>(idx, lut, first);
-    if (Lut::kHybrid && __any((big & kBigPair) != 0)) {                       // a strong sample somewhere in the wavefront
-        if (big & kBigPair) acc = half_sum<true>(idx, lut, first);
-    }
     return acc;
 }
 __device__ __forceinline__ void surv_push(uint32_t *list, uint32_t k, uint32_t p, uint32_t sum56, uint32_t sum112) {
@@ -1093,7 +1016,7 @@ template <int kDemodWaves, class Lut>
 __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80))) void demod_kernel(DemodParams P) {
     constexpr int kDemodThreads = kDemodWaves * 64;
     constexpr int kGatePerRound = kDemodThreads / kGateLanes;   // preambles a workgroup tests per round
-    __shared__ __attribute__((aligned(16))) uint16_t s_lut[Lut::kEntries];
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[MODES_LUT_ENTRIES];
     __shared__ uint32_t s_pre[kDemodGroup + 1];        // exclusive prefix of the batch's (clamped) run counts
     __shared__ uint32_t s_list[kDemodThreads];         // preambles awaiting the gate pre-test
     __shared__ uint32_t s_long[2 * kDemodThreads];     // (position, sum over the first 56 pairs) of those that decode as long
@@ -1106,13 +1029,7 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
 #ifdef MODES_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
-    if constexpr (Lut::kEntries == MODES_LUT_ENTRIES) {
-        stage_lut<kDemodThreads>(s_lut, P.tab.lut);
-    } else {                                                                 // the first entries: 16 bytes per thread and turn
-        const uint4 *src = reinterpret_cast<const uint4 *>(P.tab.lut);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
-        for (uint32_t i = threadIdx.x; i < Lut::kEntries / 8; i += kDemodThreads) dst[i] = src[i];
-    }
+    stage_lut<kDemodThreads>(s_lut, P.tab.lut);
     if (threadIdx.x < 112) s_esyn[threadIdx.x] = P.tab.esyn[threadIdx.x];
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_flags[threadIdx.x] = 0;
@@ -2213,6 +2130,11 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     ctx->cfg = *cfg;
     if (const char *v = getenv("MODES_GPU_DEMOD_VARIANT"))           // measurement / test knob: run a whole suite on another demod path
         ctx->cfg.demod_variant = (uint32_t)atoi(v);
+    if (ctx->cfg.demod_variant == 1 || ctx->cfg.demod_variant > 3) {
+        const uint32_t v = ctx->cfg.demod_variant;
+        delete ctx;
+        return fail(nullptr, MODES_ERR_ARG, "demod_variant %u: 0 (automatic), 2 (two kernels) or 3 (one kernel)", v);
+    }
     ctx->auto_records = ctx->cfg.max_records == 0;
     if (ctx->auto_records) ctx->cfg.max_records = 1u << 18;          // 16 MiB of records; grows on demand
     if (ctx->cfg.direct_records == 0) ctx->cfg.direct_records = 4096;
@@ -2229,8 +2151,7 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
         hipDeviceProp_t prop;
         int per_cu = 0;
         CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
-        if (ctx->cfg.demod_variant == 1) CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<4, LutSmall>, 256, 0));
-        else                             CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<8, LutFull>, 512, 0));
+        CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, demod_kernel<8, LutFull>, 512, 0));
         ctx->demod_wgs = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, prop.multiProcessorCount);
         CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, select_kernel, kSelThreads, 0));
         ctx->select_wgs = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, prop.multiProcessorCount);
@@ -2547,10 +2468,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
         hipExtLaunchKernelGGL(finalize2_kernel, dim3(1), dim3(512), 0, st2, nullptr, nullptr, 0, f2);
         mark(4);
     } else {
-    if (ctx->cfg.demod_variant == 1)
-        hipExtLaunchKernelGGL((demod_kernel<4, LutSmall>), dim3(ctx->demod_grid), dim3(256), 0, st2, ev(2), ev(3), 0, dp);
-    else
-        hipExtLaunchKernelGGL((demod_kernel<8, LutFull>), dim3(ctx->demod_grid), dim3(512), 0, st2, ev(2), ev(3), 0, dp);
+    hipExtLaunchKernelGGL((demod_kernel<8, LutFull>), dim3(ctx->demod_grid), dim3(512), 0, st2, ev(2), ev(3), 0, dp);
     mark(3);
     fp.ntotals = ctx->demod_grid;
     hipExtLaunchKernelGGL(finalize_kernel, dim3(1), dim3(512), 0, st2, nullptr, nullptr, 0, fp);

@@ -73,8 +73,8 @@ typedef struct {
                                   noise-gate pre-test, 16 wavefronts at 64 VGPRs) and record (one wavefront per survivor,
                                   written straight to its final place: no staging list, no order kernel): 4 % faster where
                                   there are records, 4 % slower on pure noise.  3 = always the one kernel,
-                                  2 = always the two; 1 = the one kernel with 4-wave workgroups, a 1 KiB table and the exact
-                                  square root beyond it (cross-check implementation, frozen)                              */
+                                  2 = always the two (each is the other's cross-check in the parity tests); 1 was a
+                                  small-table form of the one kernel, removed in round 3: MODES_ERR_ARG                    */
 } modes_gpu_config;
 
 /* modes_gpu_config.flags */

@@ -145,11 +145,11 @@ def test_synth_noise_matches_host_generator(torch_cuda):
     d.close()
 
 
-@pytest.mark.parametrize("demod_variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("demod_variant", [0, 2, 3])
 @pytest.mark.parametrize("case", CASES)
 def test_records_and_candidates_match_oracle(torch_cuda, streams, case, demod_variant):
-    """Both demod kernels: the production one (8 waves, the whole table in LDS) and the independent second
-    implementation (4-wave workgroups, 512-entry table + exact square root beyond it)."""
+    """Both demodulation paths - one kernel (3), select + record (2) - and the automatic choice between them (0): two
+    independent implementations of stages 1-3 against the oracle."""
     from dump1090_amd import Demodulator
     data = streams[case]
     iq = to_dev(torch_cuda, data)
@@ -165,11 +165,21 @@ def test_records_and_candidates_match_oracle(torch_cuda, streams, case, demod_va
         d.close()
 
 
+def test_removed_demod_variant_is_refused(torch_cuda):
+    from dump1090_amd import Demodulator, ModesError
+    if os.environ.get("MODES_GPU_DEMOD_VARIANT"):
+        pytest.skip("the environment overrides the variant")
+    with pytest.raises(ModesError, match="demod_variant 1"):
+        Demodulator(demod_variant=1)
+
+
 def test_automatic_demod_path_follows_the_record_density(torch_cuda, streams):
     """demod_variant 0: a context's first call and calls behind record-free ones run the one-kernel path; a call that follows
     a record-rich call (> 4096 records per GiB) runs select + record.  Same records either way; which path ran shows in the
     third kernel's time (the record kernel is timed on the two-kernel path; a short list needs no order kernel on the other)."""
     from dump1090_amd import Demodulator
+    if os.environ.get("MODES_GPU_DEMOD_VARIANT"):
+        pytest.skip("the environment overrides the variant")
     rich, quiet = to_dev(torch_cuda, streams["frames"]), to_dev(torch_cuda, streams["noise"])
     want, _ = oracle_records(streams["frames"], 1)
     d = Demodulator()

@@ -17,8 +17,8 @@ for s in "$@"; do
     full8)     run full8 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --maxfail=3 -p no:cacheprovider -k "not sixty_four" ;;
     full)      run full 1500 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --maxfail=3 -p no:cacheprovider ;;
     bench)     run bench 900 python bench.py ;;
-    variants)  for v in 0 1 2; do run noise_v$v 200 $NOISE --demod-variant $v; done
-               for v in 0 2; do run noise_v${v}_s1 200 $NOISE --demod-variant $v --streams 1; done ;;
+    variants)  for v in 0 2 3; do run noise_v$v 200 $NOISE --demod-variant $v; done
+               for v in 3 2; do run noise_v${v}_s1 200 $NOISE --demod-variant $v --streams 1; done ;;
     frames_v)  for v in 0 2; do run frames_v$v 300 python bench.py --workload frames --steps 40 --demod-variant $v; done
                for v in 0 2; do run lowsnr_v$v 300 python bench.py --workload lowsnr --steps 40 --demod-variant $v; done ;;
     parity3)   MODES_GPU_DEMOD_VARIANT=2 run parity3 900 python -m pytest tests/test_gpu_parity.py tests/test_dropin.py -m gpu -q --maxfail=6 -p no:cacheprovider ;;
