@@ -11,9 +11,14 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 cd "$R"
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 RT=$(ls -d /opt/rocm/lib/llvm/lib/clang/*/lib/linux | head -1)
-cp dump1090_amd/libmodes_host.so /tmp/libmodes_host_orig.so
+# ubsan / asan replace dump1090_amd/libmodes_host.so and the core shim by sanitizer builds: the normal ones are put back
+# whatever happens - through a rename, never by writing into the file (a process that has the library mapped, e.g. the pytest
+# run that started this script, would see its pages change)
+SAVED=0
+save() { cp dump1090_amd/libmodes_host.so /tmp/libmodes_host_orig.so; SAVED=1; }
 restore() {
-    cp /tmp/libmodes_host_orig.so "$R/dump1090_amd/libmodes_host.so"
+    [ "$SAVED" = 1 ] || return 0
+    cp /tmp/libmodes_host_orig.so "$R/dump1090_amd/libmodes_host.so.tmp" && mv "$R/dump1090_amd/libmodes_host.so.tmp" "$R/dump1090_amd/libmodes_host.so"
     (cd "$R" && python -c "import sys; sys.path.insert(0, 'tests'); from native.build import build; build(force=True)")
 }
 trap restore EXIT
@@ -21,6 +26,7 @@ set -e
 TESTS="tests/test_host.py tests/test_track.py tests/test_core.py"
 run_one() {
     local kind=$1 san
+    [ "$SAVED" = 1 ] || save
     if [ "$kind" = ubsan ]; then
         san="-fsanitize=undefined -fno-sanitize-recover=undefined"
     else
