@@ -715,6 +715,22 @@ struct AttemptFix {
     uint32_t syndrome;
     uint8_t nfix, pos0, pos1;
 };
+// The 112 single-bit syndromes by value: a 512-entry open-addressing table (key << 8 | position, 0xFFFFFFFF = empty) the host
+// builds next to them (modes_gpu_create: multiplicative hash, linear probing; the longest run of occupied cells is 3, so four
+// probes decide).  -> the position whose single-bit syndrome is `key`, 255 if there is none.
+constexpr int kSynHashBits = 9, kSynProbes = 4;
+constexpr uint32_t kSynHashMul = 0x85EBCA6Bu, kSynEmpty = 0xFFFFFFFFu;
+constexpr int kSynWords = 112 + (1 << kSynHashBits);                         // esyn[112] | table[512]
+__device__ __forceinline__ uint32_t syn_lookup(const uint32_t *table, uint32_t key) {
+    const uint32_t h = (key * kSynHashMul) >> (32 - kSynHashBits);
+    uint32_t q = 255u;
+#pragma unroll
+    for (int t = 0; t < kSynProbes; t++) {
+        const uint32_t v = table[(h + (uint32_t)t) & ((1u << kSynHashBits) - 1)];
+        if ((v >> 8) == key && v != kSynEmpty) q = v & 0xffu;
+    }
+    return q;
+}
 __device__ __forceinline__ int df_of_bits(modes_m128 bits) {                 // msg[0] >> 3
     const uint32_t v = (uint32_t)bits.lo;
     return (int)(((v & 1u) << 4) | ((v & 2u) << 2) | (v & 4u) | ((v & 8u) >> 2) | ((v & 16u) >> 4));
@@ -749,16 +765,21 @@ __device__ __forceinline__ AttemptFix wave_finish_attempt(modes_m128 bits, bool 
         }
     }
     if (maxfix < 2) return r;
-    // two flipped bits p < q: syn == esyn[p] ^ esyn[q]; lanes hold p, the loop walks q
-    for (int q = first + 1; q < 112; q++) {
-        const uint32_t want = syn ^ s_esyn[q];
-        const uint64_t bA = __ballot(okA && pA < q && eA == want), bB = __ballot(okB && pB < q && eB == want);
+    // Two flipped bits p < q: syn == esyn[p] ^ esyn[q].  Lanes hold p; the q that goes with it - if any - is the position whose
+    // single-bit syndrome is syn ^ esyn[p]: one hash lookup per candidate p instead of a walk over all q (107 wave-wide
+    // rounds of two ballots each - it made the record stage of the low-SNR --aggressive workload 0.08 ms per GiB).  All one- and
+    // two-bit syndromes over the repairable positions are distinct (dump1090.c:795-841 relies on it), so at most one pair
+    // answers and the order of the search cannot matter.  s_esyn[112 ..]: the table (syn_lookup).
+    {
+        const uint32_t qA = okA ? syn_lookup(s_esyn + 112, syn ^ eA) : 255u, qB = okB ? syn_lookup(s_esyn + 112, syn ^ eB) : 255u;
+        const uint64_t bA = __ballot(qA < 112u && (int)qA > pA), bB = __ballot(qB < 112u && (int)qB > pB);
         if (bA | bB) {
-            const int p = bA ? __builtin_ctzll(bA) : 64 + __builtin_ctzll(bB);
+            const int src = bA ? __builtin_ctzll(bA) : __builtin_ctzll(bB);                 // the lane that holds p
+            const int p = bA ? src : 64 + src;
+            const int q = (int)(bA ? __builtin_amdgcn_readlane((int)qA, src) : __builtin_amdgcn_readlane((int)qB, src));
             r.nfix = 2;
             r.pos0 = (uint8_t)(p - shift);
             r.pos1 = (uint8_t)(q - shift);
-            return r;
         }
     }
     return r;
@@ -1023,14 +1044,14 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
     __shared__ uint32_t s_surv[3 * kDemodThreads];     // (position, the two delta sums or kUnknown) of those that go to stage 3
     __shared__ uint32_t s_n[2][4];                     // list counters of the current / the next block (see stage 1)
     __shared__ uint32_t s_blk[4];                      // [0] survivors dropped by the edge gate, [1] staging base, [2] records of the block
-    __shared__ uint32_t s_esyn[112];
+    __shared__ uint32_t s_esyn[kSynWords];             // the 112 single-bit syndromes, then their hash table (syn_lookup)
     __shared__ unsigned long long s_tot[2];
     __shared__ uint32_t s_flags[2];                    // [1]: WgTotals.flags bits this workgroup raises
 #ifdef MODES_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
     stage_lut<kDemodThreads>(s_lut, P.tab.lut);
-    if (threadIdx.x < 112) s_esyn[threadIdx.x] = P.tab.esyn[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kSynWords; i += kDemodThreads) s_esyn[i] = P.tab.esyn[i];
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_flags[threadIdx.x] = 0;
     if (threadIdx.x < 4) s_blk[threadIdx.x] = 0;
@@ -1639,7 +1660,7 @@ struct RecordParams {
 };
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(80))) void record_kernel(RecordParams R) {
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[MODES_LUT_ENTRIES];
-    __shared__ uint32_t s_esyn[112];
+    __shared__ uint32_t s_esyn[kSynWords];
     __shared__ uint32_t s_red[8];
     __shared__ uint32_t s_bad;
     const DemodParams &P = R.d;
@@ -1667,7 +1688,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(80))) void reco
         if (nb == 0) continue;                                               // workgroup-uniform: noise ends here, before any table is staged
         if (!staged) {
             stage_lut<512>(s_lut, P.tab.lut);
-            if (tid < 112) s_esyn[tid] = P.tab.esyn[tid];
+            for (int i = tid; i < kSynWords; i += 512) s_esyn[i] = P.tab.esyn[i];
             __syncthreads();
             staged = true;
         }
@@ -2166,8 +2187,24 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     for (int i = 0; i <= 128; i++)
         for (int q = 0; q <= 128; q++)
             lut[std::min(i * i + q * q, 32767)] = (uint16_t)std::round(std::sqrt((double)(i * i + q * q)) * 360.0);
-    uint32_t esyn[112];
+    uint32_t esyn[kSynWords];
     for (int p = 0; p < 112; p++) esyn[p] = modes_bit_syndrome(p);
+    {   // ... and the same by value (syn_lookup): open addressing, linear probing
+        const uint32_t mask = (1u << kSynHashBits) - 1;
+        uint32_t *table = esyn + 112;
+        for (uint32_t i = 0; i <= mask; i++) table[i] = kSynEmpty;
+        for (uint32_t p = 0; p < 112; p++) {
+            uint32_t i = (esyn[p] * kSynHashMul) >> (32 - kSynHashBits);
+            while (table[i] != kSynEmpty) i = (i + 1) & mask;
+            table[i] = esyn[p] << 8 | p;
+        }
+        uint32_t run = 0, longest = 0;
+        for (uint32_t i = 0; i < 2 * (mask + 1); i++) {
+            run = table[i & mask] != kSynEmpty ? run + 1 : 0;
+            longest = std::max(longest, run);
+        }
+        if (longest >= (uint32_t)kSynProbes) { fail(ctx, MODES_ERR_ARG, "syndrome table: a run of %u cells, %d probes", longest, kSynProbes); return bail(MODES_ERR_ARG); }
+    }
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_lut), lut.size() * 2));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_esyn), sizeof esyn));
     CREATE_TRY(hipMemcpy(ctx->d_lut, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));

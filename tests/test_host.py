@@ -294,7 +294,8 @@ def test_c_host_under_thread_sanitizer():
     if not shutil.which("g++"):
         pytest.skip("no g++")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "tsan-host"], capture_output=True, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS")}       # (this test may itself run under ASan)
+    p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "tsan-host"], capture_output=True, timeout=600, env=env)
     assert p.returncode == 0 and b"ThreadSanitizer" not in p.stderr + p.stdout, (p.stdout[-800:], p.stderr[-800:])
     assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 2
 
@@ -310,6 +311,7 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     if not shutil.which("g++"):
         pytest.skip("no g++")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "ranks-host"], capture_output=True, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS")}
+    p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "ranks-host"], capture_output=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout[-800:], p.stderr[-800:])
     assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 9 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
