@@ -92,6 +92,50 @@ def measured_traffic(mib):
         return None, "unreadable"
 
 
+def live_traffic(mib, timeout_s=240):
+    """(HBM bytes per scan launch, note) measured NOW: a child `rocprofv3 --kernel-trace --pmc FETCH_SIZE` run (a counter pass of
+    its own, no other trace domain) of three steps of the headline workload on this GPU, FETCH_SIZE (KB) averaged over the
+    scan kernel's dispatches and doubled (the guide's gfx950 correction for 16 B-per-lane streaming reads).  None when
+    rocprofv3 is not there, when this process already runs under it, or when the pass fails - the caller then falls back on
+    the committed pass of the same sources."""
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    out = tempfile.mkdtemp(prefix="modes_fetch_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", out, "-o", "fetch", "-f", "csv", "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--workload", "noise", "--mib", str(mib), "--no-end-to-end", "--no-cpu-baseline", "--no-ceiling",
+           "--no-live-traffic", "--settle", "4", "--steps", "3", "--warmup", "1", "--depth", "1", "--streams", "1", "--time-every", "100000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    try:
+        t0 = time.perf_counter()
+        child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            if child.wait(timeout=timeout_s) != 0:
+                return None
+        except subprocess.TimeoutExpired:
+            os.killpg(child.pid, 9)                      # the profiler AND the bench under it: its own process group
+            child.wait()
+            return None
+        vals = []
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if "scan_kernel" in row["Kernel_Name"] and row["Counter_Name"] == "FETCH_SIZE":
+                        vals.append(float(row["Counter_Value"]))
+        if not vals:
+            return None
+        return int(sum(vals) / len(vals) * 1024 * 2), "rocprofv3 --kernel-trace --pmc FETCH_SIZE pass run by this bench.py (%d scan launches, %.0f s; KB x 1024 x 2)" % (
+            len(vals), time.perf_counter() - t0)
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 TRACE_AVG_MS = None      # the committed kernel trace's average scan launch (same sources, same workload), for comparison
 
 
@@ -286,6 +330,8 @@ def parse_args(argv=None):
                          "all_gather, the list sent to itself through isend / irecv) - exercises the RCCL calls on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC pass only: no child "
+                    "rocprofv3 --pmc FETCH_SIZE run (N = 1, ~40 s)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip roofline.measured_ceiling (the read-only streaming kernel)")
     return ap.parse_args(argv)
 
@@ -523,6 +569,11 @@ def main():
     assert kern["timed_calls"] > 0 and kern["scan_ms"] > 0, "no call of the timed region carried timing events"
     achieved = kern["call_bytes"] / (kern["scan_ms"] * 1e-3) / 1e9             # this rank's launches: 2 B per sample
     traffic, traffic_note = measured_traffic(args.mib) if noise is not None else (None, "no PMC pass for this workload")
+    committed_traffic = traffic
+    if rank == 0 and world == 1 and noise is not None and not args.no_live_traffic:
+        live = live_traffic(args.mib)
+        if live is not None:
+            traffic, traffic_note = live
     per_rank_kernels = gathered({"scan": round(kern["scan_ms"], 4), "demod": round(kern["demod_ms"], 4)})
     line = {
         "metric": "IQ Msamples/s demodulated", "value": round(value, 1), "unit": "Msamples/s",
@@ -560,7 +611,7 @@ def main():
                      "frac_of_measured_ceiling": round(achieved / ceiling["GB_per_s"], 4) if ceiling else None,
                      # `achieved` is from the HIP events of THIS run; the committed rocprofv3 trace of the same sources
                      # (profiles/): its events read ~3 % above its own kernel durations (the dispatch's ~5 us lead-in)
-                     "committed_trace_avg_ms": TRACE_AVG_MS},
+                     "committed_trace_avg_ms": TRACE_AVG_MS, "committed_traffic": committed_traffic},
     }
     if rank == 0 and world > 1:
         line["kernel_ms_per_rank"] = per_rank_kernels

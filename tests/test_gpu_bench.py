@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--mib", "128", "--frames-mib", "256", "--steps", "3", "--warmup", "1", "--settle", "4", "--frames-steps", "3",
          "--lowsnr-mib", "128", "--lowsnr-steps", "3", "--frames-total-mib", "512", "--strong-steps", "2",
-         "--no-cpu-baseline", "--no-end-to-end"]
+         "--no-cpu-baseline", "--no-end-to-end", "--no-live-traffic"]
 
 
 def parse(out: bytes):
@@ -106,3 +106,17 @@ def test_bench_eight_ranks_at_full_size_reproduce_the_reference_listings():
         assert lc["equals_reference_md5"] is True and lc["lines"] == lines, (leg, lc)
         assert j[leg]["rccl"]["nranks"] == 8 and j[leg]["rccl"]["p2p_ops_per_step"] >= 7      # seven lists travel to rank 0 per call
     assert j["frames_strong"]["same_run_as"] == "frames" and j["frames_strong"]["scaling"] == "strong"
+
+
+def test_bench_measures_the_scan_kernels_hbm_traffic_itself():
+    """roofline.traffic of a plain run comes from a rocprofv3 FETCH_SIZE pass bench.py runs itself (a child process, counters
+    only): within a few per cent of the algorithmic bytes of the launch - the scan kernel reads every sample once."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3 on this box")
+    args = [a for a in SMALL if a != "--no-live-traffic"] + ["--workload", "noise", "--mib", "1024"]     # the headline's launch
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-1500:]
+    r = parse(p.stdout)["roofline"]
+    assert r["traffic_source"].startswith("rocprofv3 --kernel-trace --pmc FETCH_SIZE pass run by this bench.py"), r["traffic_source"]
+    assert 0.98 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.08, r

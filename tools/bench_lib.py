@@ -3,6 +3,6 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 from dump1090_amd import _native as N
 N.GPU_LIB = os.path.abspath(sys.argv[1])
-sys.argv = ["bench.py", "--no-cpu-baseline"] + sys.argv[2:]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-live-traffic"] + sys.argv[2:]
 import runpy
 runpy.run_path("bench.py", run_name="__main__")

@@ -8,7 +8,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 export TMPDIR=/tmp
 run() { name=$1; shift; echo "== $name"; ( time timeout "$@" ) > "$O/$name.log" 2>&1; echo "   rc=$? $(tail -n 4 "$O/$name.log" | tr '\n' ' ' | cut -c1-400)"; }
-NOISE="python bench.py --workload noise --no-end-to-end --no-cpu-baseline --no-ceiling"
+NOISE="python bench.py --workload noise --no-end-to-end --no-cpu-baseline --no-ceiling --no-live-traffic"
 for s in "$@"; do
   case $s in
     smoke)     run smoke 400 python __graft_entry__.py smoke ;;

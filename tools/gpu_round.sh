@@ -17,7 +17,7 @@ for s in $STEPS; do
     full)   run full 1500 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --maxfail=3 -p no:cacheprovider ;;
     full8)  run full8 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --maxfail=3 -p no:cacheprovider -k "not sixty_four" ;;
     bench)  run bench 600 python bench.py ;;
-    ab)     B="python bench.py --workload noise --no-end-to-end --no-cpu-baseline --steps 60"
+    ab)     B="python bench.py --workload noise --no-end-to-end --no-live-traffic --no-cpu-baseline --steps 60"
             run ab_s2 200 $B
             MODES_DEMOD_PER_CU=1 run ab_s2_cu1 200 $B
             MODES_DEMOD_PER_CU=1 run ab_s2_cu1_R16 200 $B --run-chunks 16
@@ -31,7 +31,7 @@ for s in $STEPS; do
             cp gpurun_out/prof_$TAG/kt/*kernel_stats.csv "$O/prof/" 2>/dev/null; find gpurun_out/prof_$TAG -name "*kernel_stats.csv" -exec cp {} "$O/prof/kt_kernel_stats.csv" \; ;;
     e2e)    run e2e 600 python tools/e2e_cli.py 8 ;;
     dense)  run dense 300 python tools/bench_dense.py ;;
-    gaps)   B="$R/bench.py --workload noise --no-end-to-end --no-cpu-baseline --settle 40 --steps 100"
+    gaps)   B="$R/bench.py --workload noise --no-end-to-end --no-live-traffic --no-cpu-baseline --settle 40 --steps 100"
             ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$O/overlap_kt" -o kt -f csv -- python $B --time-every 100000 > "$O/overlap_kt.log" 2>&1 )
             ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$O/serial_kt" -o kt -f csv -- python $B --time-every 100000 --streams 1 > "$O/serial_kt.log" 2>&1 )
             python tools/kernel_gaps.py "$O/overlap_kt" > "$O/overlap_kt_summary.txt" 2>&1

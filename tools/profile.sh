@@ -11,8 +11,8 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --workload noise --no-end-to-end --steps 300 --warmup 2 --no-cpu-baseline --depth 4 --streams 1 --time-every 8 $EXTRA"   # the headline leg of the default `python bench.py`   # the timed region dominates the --stats average
-SHORT="python $R/bench.py --workload noise --no-end-to-end --settle 20 --steps 3 --warmup 1 --no-cpu-baseline --depth 1 --streams 1 --time-every 100000 $EXTRA"
+BENCH="python $R/bench.py --workload noise --no-end-to-end --no-live-traffic --steps 300 --warmup 2 --no-cpu-baseline --depth 4 --streams 1 --time-every 8 $EXTRA"   # the headline leg of the default `python bench.py`   # the timed region dominates the --stats average
+SHORT="python $R/bench.py --workload noise --no-end-to-end --no-live-traffic --settle 20 --steps 3 --warmup 1 --no-cpu-baseline --depth 1 --streams 1 --time-every 100000 $EXTRA"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -f csv -- $BENCH > "$OUT/kt.log" 2>&1
 echo "kt rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY \
