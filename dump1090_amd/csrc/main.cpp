@@ -25,7 +25,9 @@
 // rank r demodulates batches r, r + N, r + 2N, ... of the (regular) file, round g of the gather carries batches
 // gN .. gN + N - 1, so rank order is stream order and rank 0 resolves and prints every round as it arrives (run_ranks).
 
+#include <atomic>
 #include <cerrno>
+#include <csignal>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -42,6 +44,7 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <sys/wait.h>
@@ -288,21 +291,61 @@ int run_ranks(const Options &opt, double t_start) {
     }
     int rank = 0;
     std::vector<pid_t> kids;
+    const pid_t parent = getpid();
     for (int r = 1; r < N; r++) {
         const pid_t pid = fork();
-        if (pid < 0) { perror("fork"); return 1; }
-        if (pid == 0) { rank = r; kids.clear(); break; }
+        if (pid < 0) { perror("fork"); for (pid_t k : kids) kill(k, SIGKILL); return 1; }
+        if (pid == 0) {
+            rank = r; kids.clear();
+            // a rank never outlives rank 0 (which may die inside a collective the others would wait in for ever)
+            prctl(PR_SET_PDEATHSIG, SIGKILL);
+            if (getppid() != parent) _exit(1);
+            break;
+        }
         kids.push_back(pid);
     }
+    // Rank 0 watches the others: a rank that exits with an error (or is killed) leaves its peers inside an RCCL call that
+    // never returns, so the job ends there and then - the other ranks are killed, the status is 1.  Clean exits are recorded
+    // for finish().
+    std::vector<int> kid_status(kids.size(), -1);                           // -1: running; else the wait status
+    std::mutex kid_mu;
+    std::atomic<bool> watch_stop{false};
+    std::thread watchdog;
+    if (rank == 0 && !kids.empty())
+        watchdog = std::thread([&] {
+            while (!watch_stop.load()) {
+                {
+                    std::lock_guard<std::mutex> lk(kid_mu);
+                    for (size_t i = 0; i < kids.size(); i++) {
+                        int st = 0;
+                        if (kid_status[i] != -1 || waitpid(kids[i], &st, WNOHANG) != kids[i]) continue;
+                        kid_status[i] = st;
+                        if (WIFEXITED(st) && WEXITSTATUS(st) == 0) continue;
+                        fprintf(stderr, "--ranks: rank %zu ended with status %d%s; stopping the other ranks\n", i + 1,
+                                WIFEXITED(st) ? WEXITSTATUS(st) : WTERMSIG(st), WIFEXITED(st) ? "" : " (signal)");
+                        for (size_t j = 0; j < kids.size(); j++) if (kid_status[j] == -1) kill(kids[j], SIGKILL);
+                        fflush(stderr);
+                        _exit(1);
+                    }
+                }
+                usleep(50 * 1000);
+            }
+        });
     for (int r = 1; r < N; r++) {                                            // keep only this rank's end(s)
         if (rank == 0) close(rd[(size_t)r]);
         else { close(wr[(size_t)r]); if (r != rank) close(rd[(size_t)r]); }
     }
     auto finish = [&](int rc) {                                              // rank 0: the job's status is the worst rank's
         if (rank != 0) { fflush(stdout); fflush(stderr); _exit(rc); }
-        for (pid_t k : kids) {
-            int st = 0;
-            if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : 1;
+        watch_stop.store(true);
+        if (watchdog.joinable()) watchdog.join();
+        for (size_t i = 0; i < kids.size(); i++) {
+            int st = kid_status[i];
+            if (st == -1) {
+                if (rc) kill(kids[i], SIGKILL);                              // rank 0 failed: its peers may be waiting for it
+                if (waitpid(kids[i], &st, 0) < 0) st = 1;
+            }
+            if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : 1;
         }
         return rc;
     };

@@ -6,6 +6,7 @@
 // "Asynchronous" like the real thing: modes_gpu_submit_host only remembers the host buffer; the records are computed in
 // modes_gpu_fetch - on the resolver thread, while the reader thread is already filling and submitting the next lanes.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -31,6 +32,9 @@ extern "C" {
 int modes_gpu_abi_version(void) { return MODES_GFX950_ABI; }
 const char *modes_gpu_last_error(const modes_gpu *g) { return g ? g->err.c_str() : "stub"; }
 int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
+    // MODES_STUB_FAIL_DEVICE=<d>: the "GPU" d does not come up (how the host treats a rank that fails while its peers wait)
+    if (const char *f = getenv("MODES_STUB_FAIL_DEVICE"))
+        if (atoi(f) == cfg->device) return MODES_ERR_HIP;
     *out = new modes_gpu;
     (*out)->cfg = *cfg;
     return MODES_OK;

@@ -305,7 +305,8 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     library stubbed by the oracle (tests/native/gpu_stub.cpp), include/modes_gather.h implemented over shared memory
     (tests/native/gather_stub.cpp, the libmodes_gather.so the host dlopens): the fork, the id pipes, round-robin batches,
     gather rounds in three rotating slots, ranks that have no batch in a round, the EOF batch.  stdout is the reference's
-    for every N and batch size (the script compares the md5s)."""
+    for every N and batch size (the script compares the md5s).  And the failure path: one rank's "GPU" does not come up
+    (MODES_STUB_FAIL_DEVICE) - the job must end with status 1 instead of leaving the other ranks in the gather for ever."""
     import shutil
     import subprocess
     if not shutil.which("g++"):
@@ -315,3 +316,5 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "ranks-host"], capture_output=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout[-800:], p.stderr[-800:])
     assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 9 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
+    # a rank that fails to start while its peers wait in the gather ends the job (status 1), whichever rank it is
+    assert p.stdout.count(b"fails to start: exit status 1") == 3

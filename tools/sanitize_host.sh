@@ -101,6 +101,16 @@ run_ranks_host() {
     got=$($D/dump1090_amd_stub --ifile tests/golden/modes1.bin --onlyaddr --ranks 3 --batch-blocks 1 | md5sum | cut -c1-32)
     [ "$got" = bab0f055e262e216208a5cbbdf63fe24 ] || { echo "   --onlyaddr: $got"; exit 1; }
     echo "   --onlyaddr --ranks 3: md5 $got"
+    # a rank whose GPU does not come up while its peers already wait in the gather: the job ends with status 1, it does not hang
+    # (rank 0's watchdog kills the other ranks; a rank never outlives rank 0)
+    for bad in 0 1 2; do
+        set +e
+        MODES_STUB_FAIL_DEVICE=$bad timeout 20 $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw --ranks 3 --batch-blocks 1 > /dev/null 2> $D/fail.err
+        rc=$?
+        set -e
+        echo "   rank $bad fails to start: exit status $rc"
+        [ "$rc" = 1 ] || { cat $D/fail.err; exit 1; }
+    done
 }
 case "${1:-all}" in
     ubsan) run_one ubsan ;;
