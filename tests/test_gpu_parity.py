@@ -529,3 +529,49 @@ def test_no_retry_reports_overflow_and_the_resubmitted_call_succeeds(torch_cuda)
     assert np.array_equal(tile5, tile9) and abs(int(tile5.size) - int(per_tile.size)) < 8
     assert np.all(np.diff(recs["block"].astype(np.int64) * 131072 + recs["j"]) > 0)      # strictly ascending: device order
     d.close()
+
+
+def random_stream(i):
+    """Stream i of the randomized differential test: sigma, frame density, amplitude range (down to the noise, up to
+    saturation), inter-sample leak, one- and two-bit errors, seam frames all drawn from a seeded generator; one stream
+    in four gets a stretch of uniform random bytes (preambles everywhere), one in four a stretch of full-scale square wave."""
+    rng = np.random.RandomState(1000 + i)
+    kw = dict(per=int(rng.choice([2048, 4096, 16384])), sigma_q16=int(rng.choice([300, 941, 2000])),
+              amp=[(6, 12), (10, 30), (40, 100), (110, 127)][rng.randint(4)], smear=[(0,), (3, 4, 5, 6), (0, 8)][rng.randint(3)],
+              flip1=int(rng.choice([0, 3, 10])), flip2=int(rng.choice([0, 4])), edge_every=int(rng.choice([0, 7, 61])))
+    st = synth.config3_stream(5000 + i, int(rng.randint(3, 9)), **kw)
+    data = st.window(0, st.nbytes).copy()
+    if rng.randint(4) == 0:
+        lo = 2 * int(rng.randint(0, data.size // 2 - 40000))
+        data[lo:lo + 65536] = rng.randint(0, 256, 65536).astype(np.uint8)
+    if rng.randint(4) == 0:
+        lo = 2 * int(rng.randint(0, data.size // 2 - 40000))
+        period = int(rng.choice([2, 4, 6]))
+        data[lo:lo + 32768] = np.where((np.arange(32768) // period) % 2 == 0, 255, 0).astype(np.uint8)
+    data[-480:] = 127
+    return data, kw
+
+
+@pytest.mark.parametrize("group", range(8))
+def test_randomized_streams_match_oracle(torch_cuda, group):
+    """64 seeded random streams (8 per group) x 3 flag sets x both demodulation paths: every record, every preamble
+    position, bit for bit - whatever mix of density, SNR, leak, bit errors and hostile stretches the generator draws."""
+    from dump1090_amd import Demodulator
+    demods = {(v, name): Demodulator(keep_candidates=True, demod_variant=v, **orc.FLAGSETS[name])
+              for v in (2, 3) for name in ("default", "aggressive", "nofix")}
+    total = 0
+    for i in range(group * 8, group * 8 + 8):
+        data, kw = random_stream(i)
+        iq = to_dev(torch_cuda, data)
+        for name in ("default", "aggressive", "nofix"):
+            want, want_cands = oracle_records(data, maxfix_of(orc.FLAGSETS[name]))
+            total += want.size
+            for v in (2, 3):
+                d = demods[(v, name)]
+                d.detect(iq)
+                recs, cands, info = d.fetch()
+                assert np.array_equal(cands, want_cands), (i, kw, name, v, "preamble positions")
+                assert_records_equal(recs, want, ctx=(i, kw, name, v))
+    for d in demods.values():
+        d.close()
+    assert total > 500                                        # the group did exercise the demodulator
