@@ -272,6 +272,19 @@ def test_cli_one_process_per_gpu_gathers_over_rccl(torch_cuda, golden, streams, 
         assert t["rccl"]["p2p_ops"] >= 2 and t["rccl"]["bytes_received"] >= 64 and t["rccl"]["version"] > 20000
 
 
+def test_cli_more_ranks_than_gpus_fails_instead_of_hanging(torch_cuda, streams, tmp_path):
+    """dump1090_amd --ranks 2 on a box with one GPU: rank 1 has no device, rank 0 already waits in the communicator's
+    rendezvous.  Rank 0's watchdog ends the job: status 1 and a message, not a hang."""
+    if torch_cuda.cuda.device_count() >= 2:
+        pytest.skip("needs a box with a single GPU")
+    exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
+    path = tmp_path / "modes1.bin"
+    streams["modes1"].tofile(path)
+    p = subprocess.run([exe, "--ifile", str(path), "--raw", "--ranks", "2"], capture_output=True, timeout=120)
+    assert p.returncode == 1 and p.stdout == b"", (p.returncode, p.stderr[-600:])
+    assert b"rank 1" in p.stderr, p.stderr[-600:]
+
+
 def test_gather_library_overflow_and_state_errors(torch_cuda, streams):
     """include/modes_gather.h through ctypes, one rank: a list longer than the gather buffers is MODES_ERR_OVERFLOW from
     modes_gather_records (where every rank would see it), calls out of order are MODES_ERR_STATE, and after an exchange
