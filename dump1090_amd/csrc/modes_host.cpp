@@ -645,7 +645,9 @@ uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *se
     memcpy(h->icao_seen, truth.icao_seen, sizeof h->icao_seen);
     uint64_t total = 0, msgs = 0, stored = 0;
     bool full = false;
-    for (Piece &p : pieces) {
+    std::vector<uint64_t> at(P, 0), take(P, 0);                                  // where a piece's text goes, how much of it
+    for (size_t t = 0; t < P; t++) {
+        Piece &p = pieces[t];
         h->st.valid_preamble += p.host.st.valid_preamble;
         h->st.out_of_phase += p.host.st.out_of_phase;
         h->st.demodulated += p.host.st.demodulated;
@@ -657,18 +659,21 @@ uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *se
         // what the header promises when the listing outgrows `cap`: whole lines, as many as fit, nothing behind them -
         // the first piece that does not fit contributes the whole lines of its beginning, every later piece nothing
         if (out && !full) {
-            size_t take = p.text.size();
-            if (total + take + 1 > cap) {
+            size_t n = p.text.size();
+            if (total + n + 1 > cap) {
                 full = true;
-                take = cap > total + 1 ? (size_t)(cap - total - 1) : 0;
-                while (take > 0 && p.text[take - 1] != '\n') take--;
+                n = cap > total + 1 ? (size_t)(cap - total - 1) : 0;
+                while (n > 0 && p.text[n - 1] != '\n') n--;
             }
-            memcpy(out + total, p.text.data(), take);
-            stored = total + take;
+            at[t] = total;
+            take[t] = n;
+            stored = total + n;
         }
         total += p.text.size();
         msgs += p.msgs;
     }
+    // the copies themselves on the workers: 12 MB for the 524,000 lines of a --gpus 8 step is 0.4 ms on one thread
+    if (out) WorkerPool::instance().run(P, [&](size_t t) { if (take[t]) memcpy(out + at[t], pieces[t].text.data(), (size_t)take[t]); });
     if (out && stored < cap) out[stored] = 0;
     if (nbytes) *nbytes = total;
     if (dbg)
