@@ -595,7 +595,12 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
                 const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, qn));
                 uint32_t *e = queue + __umul24(slot, (uint32_t)kQStride);            // v_mad_u32_u24, not a 32-bit multiply
 #pragma unroll
-                for (int t = 0; t < 11; t++) e[t] = E[t];
+                for (int t = 0; t < 11; t++) {
+#if defined(SCAN_ABL_PUSH)
+                    if (t >= 11 - SCAN_ABL_PUSH) continue;                   // ablation build (timing only): fewer LDS writes per push
+#endif
+                    e[t] = E[t];
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++) e[11 + q] = r[q];
                 e[15] = (uint32_t)(c * kChunkSamples - kLookback + 8 * lane);
