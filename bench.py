@@ -342,6 +342,12 @@ def main():
         # no launcher around us: become one (one process per GPU; rank 0 of the children prints the line)
         sys.exit(subprocess.call(launcher_command(sys.argv[1:], args.gpus)))
 
+    # stdout carries ONE line: the JSON.  Libraries write there too (RCCL prints a five-line version banner with printf when a
+    # communicator is made, flushed at exit): keep the real stdout for the line and give everything else stderr as fd 1.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from dump1090_amd import Demodulator, block_count, shard_blocks, shard_byte_range
@@ -636,7 +642,7 @@ def main():
     if rank == 0 and world == 1 and noise is not None and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(iq_noise, min(args.cpu_mib << 20, noise["span"] // 262144 * 262144))
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=line_out, flush=True)
     if dist_on:
         dist.destroy_process_group()
 

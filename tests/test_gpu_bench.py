@@ -17,8 +17,8 @@ SMALL = ["--mib", "128", "--frames-mib", "256", "--steps", "3", "--warmup", "1",
 
 
 def parse(out: bytes):
-    lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out[-600:]
+    lines = out.decode().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out[-600:]      # the JSON line and nothing else (no library banner)
     return json.loads(lines[0])
 
 
