@@ -344,6 +344,7 @@ def main():
 
     # stdout carries ONE line: the JSON.  Libraries write there too (RCCL prints a five-line version banner with printf when a
     # communicator is made, flushed at exit): keep the real stdout for the line and give everything else stderr as fd 1.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool's hosts (RCCL across processes)
     sys.stdout.flush()
     line_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)

@@ -281,6 +281,9 @@ int run_ranks(const Options &opt, double t_start) {
     if (opt.stats) { fprintf(stderr, "--ranks: --stats needs every rank's preamble positions on rank 0; use --gpus %d for it\n", N); return 1; }
     if (opt.loop || opt.filename == "-") { fprintf(stderr, "--ranks reads a regular file (every rank maps its own batches)\n"); return 1; }
     if (!opt.devices.empty() && (int)opt.devices.size() != N) { fprintf(stderr, "--ranks %d with a --gpu-list of %zu devices\n", N, opt.devices.size()); return 1; }
+    // this pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffers fail (hipIpcGetMemHandle:
+    // invalid argument).  Kept if the caller has set it.
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     // the unique id travels from rank 0 to rank r through a pipe made before the fork; no HIP / RCCL call precedes the fork
     std::vector<int> rd((size_t)N, -1), wr((size_t)N, -1);
     for (int r = 1; r < N; r++) {
