@@ -38,10 +38,14 @@ Before the W warmup steps the headline leg runs `--settle` (80) more untimed ste
 needs ~40 back-to-back steps to reach its sustained clocks (tools/scan_steps.py); the K timed steps are
 therefore the sustained rate, which is what a stream of many batches sees.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the scan kernel (the only stage that reads every sample):
-algorithmic bytes = 2 per sample, duration = HIP events recorded around the kernel on its launch stream inside
-libmodes_gfx950.so.  `cpu_baseline` (N == 1 only) times the compiled reference (oracle/_ref) - or the C
-restatement if that binary is absent - on the host.
+Prints ONE JSON line on rank 0 - and nothing else on stdout: whatever libraries print there (RCCL's version banner) is
+sent to stderr.  `roofline` is for the scan kernel (the only stage that reads every sample): algorithmic bytes = 2 per
+sample, duration = HIP events recorded around the kernel on its launch stream inside libmodes_gfx950.so;
+`roofline.traffic` = the kernel's HBM read bytes per launch from a `rocprofv3 --kernel-trace --pmc FETCH_SIZE` pass that
+bench.py runs itself at N = 1 (a child process, three steps of the headline workload, counters only; the committed pass
+of the same kernel sources - `roofline.committed_traffic` - where rocprofv3 is missing); `roofline.measured_ceiling` =
+the same loads with no arithmetic behind them (stream_read_kernel), measured in this run.  `cpu_baseline` (N == 1 only)
+times the compiled reference (oracle/_ref) - or the C restatement if that binary is absent - on the host.
 """
 import argparse
 import hashlib
