@@ -85,15 +85,23 @@ def _to_message(e: N.Emitted, check_crc: bool = True) -> Message:
 class HostResolver:
     """The sequential half: records -> messages (libmodes_host.so).  No GPU needed."""
 
-    def __init__(self, fix: bool = True, aggressive: bool = False, check_crc: bool = True):
+    def __init__(self, fix: bool = True, aggressive: bool = False, check_crc: bool = True, text_buffer=None):
+        """text_buffer: the grow-only listing buffer of a resolver that is being replaced (take_text_buffer()) - a step loop
+        that starts every step with a fresh whitelist must not also pay for a fresh buffer (34 MB, zero-filled and
+        faulted in under the GIL, for the 524,000 lines of an 8-GPU step: 7 ms)."""
         self._lib = N.host_lib()
         self.check_crc = check_crc
         cfg = N.HostConfig(int(fix), int(aggressive), int(check_crc), 0)
         self._h = self._lib.modes_host_create(C.byref(cfg))
         if not self._h:
             raise N.ModesError(-3, "modes_host_create failed")
-        self._rawbuf = None          # grow-only text buffer of raw_listing*: per resolver (ctypes drops the GIL inside the C call,
+        self._rawbuf = text_buffer   # grow-only text buffer of raw_listing*: per resolver (ctypes drops the GIL inside the C call,
                                      # two resolvers on two threads must not format into one buffer)
+
+    def take_text_buffer(self):
+        """Hand the listing buffer to a successor (HostResolver(text_buffer=...)); this resolver allocates anew if used again."""
+        buf, self._rawbuf = self._rawbuf, None
+        return buf
 
     def _text_buffer(self, cap):
         if self._rawbuf is None or len(self._rawbuf) < cap:
@@ -134,9 +142,11 @@ class HostResolver:
         return int(self._lib.modes_host_resolve_to_array(self._h, records.ctypes.data, records.size, cptr, ncand,
                                                          None, 0))
 
-    def raw_listing(self, records: np.ndarray, candidates: np.ndarray | None = None, threads: int = 1) -> tuple[int, bytes]:
+    def raw_listing(self, records: np.ndarray, candidates: np.ndarray | None = None, threads: int = 1, text: bool = True):
         """(number of lines, the --raw listing) of a batch, formatted in C (modes_host_resolve_raw; with threads > 1 and
-        no candidates: modes_host_resolve_raw_mt, the same listing from several threads)."""
+        no candidates: modes_host_resolve_raw_mt, the same listing from several threads).  text=False: the listing is
+        formatted all the same but stays in the resolver's buffer - (number of lines, None); a step loop that only checks
+        its last listing saves the copy into a Python object (made under the GIL) on all the others."""
         records = np.ascontiguousarray(records, dtype=N.RECORD_DTYPE)
         cptr, ncand = None, 0
         if candidates is not None:
@@ -150,21 +160,21 @@ class HostResolver:
         else:
             n = self._lib.modes_host_resolve_raw(self._h, records.ctypes.data, records.size, cptr, ncand, buf, len(buf),
                                                  C.byref(nbytes))
-        return int(n), C.string_at(buf, nbytes.value)     # copies the listing only, not the whole buffer
+        return int(n), (C.string_at(buf, nbytes.value) if text else None)     # copies the listing only, not the whole buffer
 
-    def raw_listing_segments(self, segments, threads: int = 1) -> tuple[int, bytes]:
+    def raw_listing_segments(self, segments, threads: int = 1, text: bool = True):
         """raw_listing of a batch that lies in several record arrays (in stream order, whole buffers each), resolved as ONE
         batch by up to `threads` threads without concatenating them (modes_host_resolve_raw_mtv)."""
         segs = [np.ascontiguousarray(a, dtype=N.RECORD_DTYPE) for a in segments if len(a)]
         if not segs:
-            return 0, b""
+            return 0, (b"" if text else None)
         total = sum(a.size for a in segs)
         buf = self._text_buffer(62 * total + 64)
         ptrs = (C.c_void_p * len(segs))(*[a.ctypes.data for a in segs])
         lens = (C.c_uint64 * len(segs))(*[a.size for a in segs])
         nbytes = C.c_uint64()
         n = self._lib.modes_host_resolve_raw_mtv(self._h, ptrs, lens, len(segs), buf, len(buf), C.byref(nbytes), max(1, threads))
-        return int(n), C.string_at(buf, nbytes.value)
+        return int(n), (C.string_at(buf, nbytes.value) if text else None)
 
     def stats(self) -> dict:
         st = N.HostStats()

@@ -23,21 +23,25 @@ class Resolver(threading.Thread):
         self.threads = threads          # modes_host_resolve_raw_mt: pieces of a long list resolved in parallel (exact)
         self.q = queue.Queue()
         self.msgs = 0                   # messages of the timed steps
-        self.step_text = []             # listing of the step in progress, one piece per call
+        self.step_text = []             # listing of the step in progress, one piece per call (steps whose text is kept)
+        self.step_lines = 0
         self.last_text = b""            # listing of the last complete step
         self.last_lines = 0
         self.error = None
         self._res = None
         self.start()
 
-    def submit(self, recs, counts, first_call, last_call, timed, done_event):
+    def submit(self, recs, counts, first_call, last_call, timed, done_event, keep_text=True):
         """recs: the records of one call - this rank's (counts None) or the gathered lists of all ranks, rank after
-        rank (counts = records per rank)."""
-        self.q.put((recs, counts, first_call, last_call, timed, done_event))
+        rank (counts = records per rank).  keep_text: the step's listing is wanted as a Python object (last_text);
+        otherwise it is formatted all the same, and only counted."""
+        self.q.put((recs, counts, first_call, last_call, timed, done_event, keep_text))
 
-    def _resolve(self, recs, timed):
-        n, text = self._res.raw_listing(recs, None, threads=self.threads)
-        self.step_text.append(text)
+    def _resolve(self, recs, timed, keep):
+        n, text = self._res.raw_listing(recs, None, threads=self.threads, text=keep)
+        if keep:
+            self.step_text.append(text)
+        self.step_lines += n
         if timed:
             self.msgs += n
 
@@ -50,16 +54,21 @@ class Resolver(threading.Thread):
             if isinstance(item, threading.Event):               # drain(): everything submitted before it is resolved
                 item.set()
                 continue
-            recs, counts, first_call, last_call, timed, done = item
+            recs, counts, first_call, last_call, timed, done, keep = item
             try:
                 if first_call:
+                    # a fresh whitelist, the old listing buffer (a new one per step would be zero-filled and faulted in
+                    # under the GIL: 7 ms for the 34 MB of an 8-GPU step - the launching thread stalls, the GPU runs dry)
+                    buf = None
                     if self._res is not None:
+                        buf = self._res.take_text_buffer()
                         self._res.close()
-                    self._res = HostResolver(**self.flags)
+                    self._res = HostResolver(text_buffer=buf, **self.flags)
                     self.step_text = []
+                    self.step_lines = 0
                     self._parts = []
                 if counts is None or (first_call and last_call):
-                    self._resolve(recs, timed)                  # one rank, or one call per step: already in stream order
+                    self._resolve(recs, timed, keep)            # one rank, or one call per step: already in stream order
                     done.set()
                 else:
                     # several calls per step and several ranks: stream order is rank-major (rank 0's calls, then
@@ -76,8 +85,10 @@ class Resolver(threading.Thread):
                         # (modes_host_resolve_raw_mtv): with a call per (rank, call) piece rank 0 of an 8-GPU run spent
                         # 16 x 0.5 ms per step here against 2.2 ms of kernels
                         segs = [call[r] for r in range(len(counts)) for call, _ in self._parts]
-                        n, text = self._res.raw_listing_segments(segs, threads=self.threads)
-                        self.step_text.append(text)
+                        n, text = self._res.raw_listing_segments(segs, threads=self.threads, text=keep)
+                        if keep:
+                            self.step_text.append(text)
+                        self.step_lines += n
                         if timed:
                             self.msgs += n
                         for _, ev in self._parts:
@@ -85,8 +96,9 @@ class Resolver(threading.Thread):
                                 ev.set()
                         self._parts = []
                 if last_call:
-                    self.last_text = b"".join(self.step_text)
-                    self.last_lines = self.last_text.count(b"\n")
+                    self.last_lines = self.step_lines
+                    if keep:                                    # (joining and counting 12 MB under the GIL stalls the launches)
+                        self.last_text = b"".join(self.step_text)
             except Exception as e:          # noqa: BLE001 - reported by the main thread
                 self.error = e
                 done.set()
@@ -265,7 +277,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             note(info, timed)
         if rank == 0:
             free[k].clear()
-            resolver.submit(recs, counts, tag[0], tag[1], timed, free[k])
+            resolver.submit(recs, counts, tag[0], tag[1], timed, free[k], keep_text=tag[2])
 
     stage = {}                                                  # context -> [phase, timed, (first call, last call of its step), call number]
     order = []                                                  # contexts with a call in flight, oldest first
@@ -288,6 +300,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             order.remove(k)
 
     t0 = None
+    prof0 = []
     ncall = 0
     first_timed_call = warm * len(calls)
     timed_phase = (min(time_every, steps * len(calls)) - 1) % time_every
@@ -300,6 +313,9 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             if resolver is not None:
                 resolver.drain()
             sync_all()
+            prof0 = [d.host_profile() for d in demods if hasattr(d, "host_profile")]
+            for key in host:                                    # host time by phase: of the timed calls only (the warm-up
+                host[key] = 0.0                                 # holds one-off costs: list growth, RCCL's connection set-up)
             t0 = time.perf_counter()
         timed = step >= warm
         for ci, (b0, nb, clo, chi) in enumerate(calls):
@@ -344,7 +360,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                 for w in works:
                     if w is not stream:
                         demods[k].stream_wait(w)
-            stage[k] = [0, timed, (ci == 0, ci == len(calls) - 1), ncall]
+            # (first call, last call of its step, the step's listing is wanted: the last step's - it is what the caller checks)
+            stage[k] = [0, timed, (ci == 0, ci == len(calls) - 1, step == warm + steps - 1), ncall]
             order.append(k)
             ncall += 1
             # keep the older calls moving - the same communication calls at the same point on every rank
@@ -373,10 +390,12 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     out = {"elapsed": elapsed, "scan_ms": mean(scan_ms), "demod_ms": mean(demod_ms), "order_ms": mean(order_ms),
            "scan_ms_median": float(np.median(scan_ms)) if scan_ms else 0.0,
            "timed_calls": len(scan_ms), "last": dict(last), "depth": depth, "calls_per_step": len(calls),
-           "host_ms_per_call": {k: round(v / max(1, ncall) * 1e3, 4) for k, v in host.items()},
+           "host_ms_per_call": {k: round(v / max(1, steps * len(calls)) * 1e3, 4) for k, v in host.items()},
            "call_bytes": float(np.mean([chi - clo for _, _, clo, chi in calls])), "steps": steps, "comm": comm}
     prof = [d.host_profile() for d in demods if hasattr(d, "host_profile")]
-    if prof:                                                     # inside modes_gpu_detect, by section, microseconds per call
+    if prof:                                                     # inside modes_gpu_detect, by section, microseconds per timed call
+        if len(prof0) == len(prof):
+            prof = [{k: p[k] - q[k] for k in p} for p, q in zip(prof, prof0)]
         ncalls_p = max(1, sum(p["calls"] for p in prof))
         out["detect_us_per_call"] = {k: round(sum(p[k] for p in prof) / ncalls_p * 1e6, 2) for k in prof[0] if k != "calls"}
     if rank == 0:

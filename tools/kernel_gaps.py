@@ -6,14 +6,14 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 
 
 def short(n):
-    for k in ("scan_kernel", "demod_kernel", "finalize_kernel", "order_kernel", "prefix_kernel"):
+    for k in ("scan_kernel", "demod_kernel", "select_kernel", "record_kernel", "finalize2_kernel", "finalize_kernel", "order_kernel", "prefix_kernel"):
         if k in n:
             return k
     return n[:24]
 
 
 ev = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
-ev = [e for e in ev if e[0] in ("scan_kernel", "demod_kernel", "finalize_kernel", "order_kernel")]
+ev = [e for e in ev if e[0] in ("scan_kernel", "demod_kernel", "select_kernel", "record_kernel", "finalize2_kernel", "finalize_kernel", "order_kernel")]
 ev = ev[len(ev) * 4 // 10:]
 gaps, dur = {}, {}
 for a, b in zip(ev, ev[1:]):
