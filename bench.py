@@ -334,6 +334,8 @@ def parse_args(argv=None):
                          "all_gather, the list sent to itself through isend / irecv) - exercises the RCCL calls on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--leg-streams", type=int, default=1, help="launch streams of the frames / lowsnr / strong legs (their calls that "
+                    "carry timing events run alone either way)")
     ap.add_argument("--call-blocks", type=int, default=32767, help="buffers per GPU call of the frames / strong legs (at most 32767 = "
                     "8 GiB - 256 KiB; the same number of calls on every rank)")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC pass only: no child "
@@ -453,7 +455,7 @@ def main():
         # collectives pair up)
         max_blocks = total_blocks // world + 1
         calls = split_calls(first_block, nblocks, (max_blocks + args.call_blocks - 1) // args.call_blocks, lo, total_bytes)
-        res = leg(iq_f, lo, calls, flags, steps, 6, cap_records, 1, True)
+        res = leg(iq_f, lo, calls, flags, steps, 6, cap_records, max(1, args.leg_streams), True)
         res.update(total=total_bytes, span=hi - lo, per_gpu=total_bytes // world)
         del iq_f
         torch.cuda.empty_cache()
