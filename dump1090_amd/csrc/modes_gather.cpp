@@ -211,6 +211,10 @@ int modes_gather_records(modes_gather *g, uint32_t slot) {
     s->loopback = false;
     uint64_t ops = 0, rx = 0, tx = 0;
     NCCL_TRY(g, ncclGroupStart());
+    struct GroupGuard {                                                      // an error return between start and end must not leave the group open
+        bool open = true;
+        ~GroupGuard() { if (open) (void)ncclGroupEnd(); }
+    } group;
     if (me == 0) {
         // rank order = stream order: the root's own list already sits at the front, every other list lands behind its predecessor's
         size_t off = (size_t)s->counts[0] * rec;
@@ -237,6 +241,7 @@ int modes_gather_records(modes_gather *g, uint32_t slot) {
         tx += nb;
         ops++;
     }
+    group.open = false;
     NCCL_TRY(g, ncclGroupEnd());
     if (me == 0 && s->total) {
         HIP_TRY(g, hipMemcpyAsync(s->h_records, s->d_records, (size_t)s->total * rec, hipMemcpyDeviceToHost, g->stream));
