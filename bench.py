@@ -610,6 +610,7 @@ def main():
         "msgs_per_s": round(head.get("msgs", 0) / head["elapsed"], 2) if rank == 0 else None,
         "host_ms_per_call": head.get("host_ms_per_call"),          # rank 0's host thread, by phase of the step loop
         "detect_us_per_call": head.get("detect_us_per_call"),      # inside modes_gpu_detect, by section (modes_gpu_host_profile)
+        "region_tail_ms": head.get("region_tail_ms"),              # the end of the timed region: calls in flight, resolver, final sync
         "preambles_per_step_rank0": int(head["last"].get("n_preambles", 0)),
         "forwarded_per_step_rank0": int(head["last"].get("n_forwarded", 0)),
         "kernel_ms": {"scan": round(kern["scan_ms"], 4), "demod": round(kern["demod_ms"], 4), "order": round(kern["order_ms"], 4),
