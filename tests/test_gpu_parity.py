@@ -544,25 +544,7 @@ def test_no_retry_reports_overflow_and_the_resubmitted_call_succeeds(torch_cuda)
     d.close()
 
 
-def random_stream(i):
-    """Stream i of the randomized differential test: sigma, frame density, amplitude range (down to the noise, up to
-    saturation), inter-sample leak, one- and two-bit errors, seam frames all drawn from a seeded generator; one stream
-    in four gets a stretch of uniform random bytes (preambles everywhere), one in four a stretch of full-scale square wave."""
-    rng = np.random.RandomState(1000 + i)
-    kw = dict(per=int(rng.choice([2048, 4096, 16384])), sigma_q16=int(rng.choice([300, 941, 2000])),
-              amp=[(6, 12), (10, 30), (40, 100), (110, 127)][rng.randint(4)], smear=[(0,), (3, 4, 5, 6), (0, 8)][rng.randint(3)],
-              flip1=int(rng.choice([0, 3, 10])), flip2=int(rng.choice([0, 4])), edge_every=int(rng.choice([0, 7, 61])))
-    st = synth.config3_stream(5000 + i, int(rng.randint(3, 9)), **kw)
-    data = st.window(0, st.nbytes).copy()
-    if rng.randint(4) == 0:
-        lo = 2 * int(rng.randint(0, data.size // 2 - 40000))
-        data[lo:lo + 65536] = rng.randint(0, 256, 65536).astype(np.uint8)
-    if rng.randint(4) == 0:
-        lo = 2 * int(rng.randint(0, data.size // 2 - 40000))
-        period = int(rng.choice([2, 4, 6]))
-        data[lo:lo + 32768] = np.where((np.arange(32768) // period) % 2 == 0, 255, 0).astype(np.uint8)
-    data[-480:] = 127
-    return data, kw
+random_stream = synth.random_stream          # the generator of the randomized differential tests (tests/synth.py)
 
 
 @pytest.mark.parametrize("group", range(8))

@@ -87,6 +87,24 @@ def test_live_reference_agrees(tmp_path, streams):
             assert orc.stats_text(st) == orc.run_ref(str(path), ["--stats"] + cli)
 
 
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("group", range(4))
+def test_restatement_equals_compiled_reference_on_random_streams(group):
+    """The streams of the GPU suite's randomized differential test (synth.random_stream: density, SNR, leak, bit errors, seam
+    frames, hostile stretches - all drawn from a seeded generator), through the compiled reference and through the
+    restatement: the same --raw listing and the same --stats counters.  Reference = restatement here, restatement = HIP
+    path there (tests/test_gpu_parity.py::test_randomized_streams_match_oracle), on the very same bytes."""
+    total = 0
+    for i in range(group * 16, group * 16 + 16):
+        data, kw = synth.random_stream(i)
+        for fs, cli in (("default", []), ("aggressive", ["--aggressive"]), ("nofix", ["--no-fix"])):
+            msgs, st = orc.run_stream(data, **orc.FLAGSETS[fs])
+            assert orc.raw_text(msgs) == orc.run_ref_bytes(data, ["--raw"] + cli).decode(), (i, kw, fs)
+            assert orc.stats_text(st) == orc.run_ref_bytes(data, ["--stats"] + cli).decode(), (i, kw, fs)
+            total += len(msgs)
+    assert total > 200
+
+
 def test_maglut_matches_formula_and_is_monotone_in_s():
     lut = orc.maglut().reshape(129, 129)
     i, q = np.meshgrid(np.arange(129), np.arange(129), indexing="ij")
