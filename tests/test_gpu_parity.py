@@ -551,7 +551,7 @@ random_stream = synth.random_stream          # the generator of the randomized d
 def test_randomized_streams_match_oracle(torch_cuda, group):
     """64 seeded random streams (8 per group) x 3 flag sets x both demodulation paths: every record, every preamble
     position, bit for bit - whatever mix of density, SNR, leak, bit errors and hostile stretches the generator draws."""
-    from dump1090_amd import Demodulator
+    from dump1090_amd import Demodulator, raw_text
     demods = {(v, name): Demodulator(keep_candidates=True, demod_variant=v, **orc.FLAGSETS[name])
               for v in (2, 3) for name in ("default", "aggressive", "nofix")}
     total = 0
@@ -567,6 +567,10 @@ def test_randomized_streams_match_oracle(torch_cuda, group):
                 recs, cands, info = d.fetch()
                 assert np.array_equal(cands, want_cands), (i, kw, name, v, "preamble positions")
                 assert_records_equal(recs, want, ctx=(i, kw, name, v))
+            if orc.have_ref():                                # and end to end: the listing the compiled reference prints
+                cli = {"default": [], "aggressive": ["--aggressive"], "nofix": ["--no-fix"]}[name]
+                msgs = demods[(3 - (i & 1), name)].demodulate(iq)      # the two paths in turn
+                assert raw_text(msgs) == orc.run_ref_bytes(data, ["--raw"] + cli).decode(), (i, kw, name, "listing")
     for d in demods.values():
         d.close()
     assert total > 500                                        # the group did exercise the demodulator
