@@ -172,9 +172,15 @@ def cpu_baseline(iq, nbytes_sample):
         dt = time.perf_counter() - t0
         kind, lines = "port", len(msgs)
         what = "oracle/liboracle.so orc_run_stream on the first %d MiB of the workload, --no-fix" % (nbytes_sample >> 20)
+    model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "?")
+    except OSError:
+        pass
     return {"value": round(nsamp / dt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
-            "sample": "%s; %.2f s wall, %d messages; 1 decode thread (host has %d cores)" % (
-                what, dt, lines, os.cpu_count() or 0)}
+            "sample": "%s; %.2f s wall, %d messages; 1 decode thread (host: %d x %s)" % (
+                what, dt, lines, os.cpu_count() or 0, model)}
 
 
 LOWSNR = dict(per=16384, amp=(8, 15), smear=(3, 4, 5, 6), flip1=10, flip2=20, edge_every=61)      # configs[4]'s stream (tests/synth.py)
