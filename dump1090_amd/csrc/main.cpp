@@ -545,6 +545,14 @@ int main(int argc, char **argv) {
         return 1;
     }
 
+    {   // a regular file shorter than a batch: pinned buffers of its size, not of the default 128 MiB each (they are most of
+        // the start-up time of a run on a small file); the whole file is then one batch with its EOF buffer
+        struct stat sb;
+        if (fd != 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
+            const uint64_t in_file = (uint64_t)sb.st_size / MODES_DATA_LEN + 1;
+            if (in_file < opt.batch_blocks) opt.batch_blocks = in_file;
+        }
+    }
     // One lane = one GPU context + one pinned buffer; lane l lives on device l mod N, so that batch b (lane
     // b mod L, L a multiple of N) runs on device b mod N.  The contexts of different devices are created
     // concurrently (HIP initialises each device on first use).
