@@ -96,14 +96,29 @@ def measured_traffic(mib):
         return None, "unreadable"
 
 
+def fetch_bytes_per_launch(directory, kernel="scan_kernel"):
+    """(HBM read bytes per launch, launches) from the counter_collection CSVs rocprofv3 left under `directory`: FETCH_SIZE is in
+    KB and counts the 128-byte requests of 16 B-per-lane streaming reads as 64 bytes on gfx950 (the guide's correction: x 2).
+    None when the kernel has no FETCH_SIZE row."""
+    import csv
+    import glob
+    vals = []
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if kernel in row["Kernel_Name"] and row["Counter_Name"] == "FETCH_SIZE":
+                    vals.append(float(row["Counter_Value"]))
+    if not vals:
+        return None
+    return int(sum(vals) / len(vals) * 1024 * 2), len(vals)
+
+
 def live_traffic(mib, timeout_s=240):
     """(HBM bytes per scan launch, note) measured NOW: a child `rocprofv3 --kernel-trace --pmc FETCH_SIZE` run (a counter pass of
     its own, no other trace domain) of three steps of the headline workload on this GPU, FETCH_SIZE (KB) averaged over the
     scan kernel's dispatches and doubled (the guide's gfx950 correction for 16 B-per-lane streaming reads).  None when
     rocprofv3 is not there, when this process already runs under it, or when the pass fails - the caller then falls back on
     the committed pass of the same sources."""
-    import csv
-    import glob
     import shutil
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
@@ -124,16 +139,11 @@ def live_traffic(mib, timeout_s=240):
             os.killpg(child.pid, 9)                      # the profiler AND the bench under it: its own process group
             child.wait()
             return None
-        vals = []
-        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-            with open(f, newline="") as fh:
-                for row in csv.DictReader(fh):
-                    if "scan_kernel" in row["Kernel_Name"] and row["Counter_Name"] == "FETCH_SIZE":
-                        vals.append(float(row["Counter_Value"]))
-        if not vals:
+        got = fetch_bytes_per_launch(out)
+        if got is None:
             return None
-        return int(sum(vals) / len(vals) * 1024 * 2), "rocprofv3 --kernel-trace --pmc FETCH_SIZE pass run by this bench.py (%d scan launches, %.0f s; KB x 1024 x 2)" % (
-            len(vals), time.perf_counter() - t0)
+        return got[0], "rocprofv3 --kernel-trace --pmc FETCH_SIZE pass run by this bench.py (%d scan launches, %.0f s; KB x 1024 x 2)" % (
+            got[1], time.perf_counter() - t0)
     except (OSError, subprocess.SubprocessError, KeyError, ValueError):
         return None
     finally:

@@ -112,3 +112,23 @@ def test_committed_reference_listings_cover_the_default_runs():
         assert low and low["lines"] > 2000 * n and "--aggressive" in low["flags"]
     assert bench.golden_listing("frames", 4, 262144)["lines"] > 520000          # the strong-scaling leg's stream at every N
     assert bench.golden_listing("frames", 3, 32768)["md5"] == "71d130a9532b26ccef50568cc9966b53"   # = tests/golden/config2_listing.json
+
+
+def test_fetch_size_rows_become_bytes_per_launch(tmp_path):
+    """bench.py's own PMC pass: the scan kernel's FETCH_SIZE rows (KB) of rocprofv3's counter_collection CSV, averaged over
+    the launches and doubled (gfx950: 128-byte requests of 16 B-per-lane reads count as 64 bytes); other kernels and other
+    counters do not enter; no row, no number."""
+    import bench
+    d = tmp_path / "pass" / "box"
+    d.mkdir(parents=True)
+    rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,"
+            "Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+    def row(kernel, counter, value):
+        return '1,1,4,1,10,10,4194304,7,"%s",128,12800,0,56,0,112,%s,%s,100,200' % (kernel, counter, value)
+    rows += [row("(anonymous namespace)::scan_kernel((anonymous namespace)::ScanParams)", "FETCH_SIZE", v) for v in (536000.0, 537000.0)]
+    rows += [row("void (anonymous namespace)::demod_kernel<8, LutFull>(DemodParams)", "FETCH_SIZE", 147000.0),
+             row("(anonymous namespace)::scan_kernel((anonymous namespace)::ScanParams)", "WRITE_SIZE", 2400.0)]
+    (d / "fetch_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    assert bench.fetch_bytes_per_launch(str(tmp_path)) == (int(536500.0 * 1024 * 2), 2)
+    assert bench.fetch_bytes_per_launch(str(tmp_path), kernel="demod_kernel") == (int(147000.0 * 2048), 1)
+    assert bench.fetch_bytes_per_launch(str(tmp_path), kernel="order_kernel") is None
