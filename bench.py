@@ -45,7 +45,10 @@ sample, duration = HIP events recorded around the kernel on its launch stream in
 bench.py runs itself at N = 1 (a child process, three steps of the headline workload, counters only; the committed pass
 of the same kernel sources - `roofline.committed_traffic` - where rocprofv3 is missing); `roofline.measured_ceiling` =
 the same loads with no arithmetic behind them (stream_read_kernel), measured in this run.  `cpu_baseline` (N == 1 only)
-times the compiled reference (oracle/_ref) - or the C restatement if that binary is absent - on the host.
+times the compiled reference (oracle/_ref) - or the C restatement if that binary is absent - on the host: on the whole
+headline workload (--raw --no-fix, four passes), and inside the `frames` and `lowsnr` objects on the first GiB of THEIR
+streams with THEIR flags (--raw / --raw --aggressive; Msamples/s and msgs/s), SURVEY.md 8d.  Every leg settles before
+its timed steps (--settle counts 1 GiB steps; a leg reports its own `settle_steps`).
 """
 import argparse
 import hashlib
@@ -153,15 +156,25 @@ def live_traffic(mib, timeout_s=240):
 TRACE_AVG_MS = None      # the committed kernel trace's average scan launch (same sources, same workload), for comparison
 
 
-def cpu_baseline(iq, nbytes_sample):
-    """Reference single-threaded C path on the host cores, on the first nbytes_sample bytes of the
-    same workload.  Checker code (oracle/) is used here only as the thing being timed."""
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            return next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "?")
+    except OSError:
+        return "?"
+
+
+def cpu_baseline(iq, nbytes_sample, flagset="nofix", passes=4, what="the workload"):
+    """Reference single-threaded C path on the host cores, on the first nbytes_sample bytes of the same workload (SURVEY.md 8d:
+    `./dump1090 --ifile <file> --raw [flags] > /dev/null`, wall clock, one decode thread).  flagset: oracle.FLAGSETS name -
+    "nofix" (configs[1]), "default" (configs[2]/[3], --fix), "aggressive" (configs[4]).  Checker code (oracle/) is used here
+    only as the thing being timed.  -> the object of the JSON line (Msamples/s and msgs/s)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     sample = iq[:nbytes_sample].cpu().numpy()
     sample[-480:] = 127
     nsamp = nbytes_sample // 2
-    passes = 4                                           # ~10 s of single-threaded CPU work on the 1 GiB workload
+    cli = {"nofix": ["--no-fix"], "default": [], "aggressive": ["--aggressive"]}[flagset]
     if orc.have_ref():
         with tempfile.NamedTemporaryFile(suffix=".bin", dir="/tmp") as f:
             sample.tofile(f.name)
@@ -169,28 +182,23 @@ def cpu_baseline(iq, nbytes_sample):
             dt, out = 0.0, b""
             for _ in range(passes):
                 t0 = time.perf_counter()
-                out = subprocess.run([orc.REF_BIN, "--ifile", f.name, "--raw", "--no-fix"], stdout=subprocess.PIPE,
+                out = subprocess.run([orc.REF_BIN, "--ifile", f.name, "--raw"] + cli, stdout=subprocess.PIPE,
                                      env=env, check=True).stdout
                 dt += time.perf_counter() - t0
         kind, lines = "reference", out.count(b"\n")
-        what = "oracle/_ref/dump1090_ref --ifile <first %d MiB of the workload> --raw --no-fix, %d passes" % (
-            nbytes_sample >> 20, passes)
+        desc = "oracle/_ref/dump1090_ref --ifile <first %d MiB of %s> --raw%s, %d pass%s" % (
+            nbytes_sample >> 20, what, "".join(" " + c for c in cli), passes, "es" if passes > 1 else "")
         nsamp *= passes
     else:
+        passes = 1
         t0 = time.perf_counter()
-        msgs, _ = orc.run_stream(sample, **orc.FLAGSETS["nofix"])
+        msgs, _ = orc.run_stream(sample, **orc.FLAGSETS[flagset])
         dt = time.perf_counter() - t0
         kind, lines = "port", len(msgs)
-        what = "oracle/liboracle.so orc_run_stream on the first %d MiB of the workload, --no-fix" % (nbytes_sample >> 20)
-    model = "?"
-    try:
-        with open("/proc/cpuinfo") as f:
-            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "?")
-    except OSError:
-        pass
-    return {"value": round(nsamp / dt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
-            "sample": "%s; %.2f s wall, %d messages; 1 decode thread (host: %d x %s)" % (
-                what, dt, lines, os.cpu_count() or 0, model)}
+        desc = "oracle/liboracle.so orc_run_stream on the first %d MiB of %s, flag set %s" % (nbytes_sample >> 20, what, flagset)
+    return {"value": round(nsamp / dt / 1e6, 2), "unit": "Msamples/s", "msgs_per_s": round(lines * passes / dt, 1), "cores": 1, "kind": kind,
+            "sample": "%s; %.2f s wall, %d messages per pass; 1 decode thread (host: %d x %s)" % (
+                desc, dt, lines, os.cpu_count() or 0, host_cpu_model())}
 
 
 LOWSNR = dict(per=16384, amp=(8, 15), smear=(3, 4, 5, 6), flip1=10, flip2=20, edge_every=61)      # configs[4]'s stream (tests/synth.py)
@@ -250,15 +258,18 @@ def check_listing(listing: bytes, expected: list[str], weak: bool = False):
     Strong frames (default): every injected frame comes out (<= 0.5 % may be lost to a neighbour's skip window or a
     noise hit), in stream order, and next to NOTHING else does - a line that is not an expected frame is a noise-born or
     mis-repaired message, a handful per stream (<= 0.05 % + 2).  weak (the low-SNR stream, --aggressive): most frames are
-    below the demodulator's reach and the two-bit repair invents a few valid-looking ones, so only the order of what is
-    found and rough proportions can be asserted (the exact check is the reference's md5: golden_listing)."""
+    below the demodulator's reach, so what is MISSING cannot be bounded - but what is found must still be frames of the
+    stream (<= 1 % + 2 lines that are not: the two-bit repair invents a valid-looking message now and then) in stream order
+    (the exact check is the reference's md5 where a listing is committed: golden_listing)."""
     lines = listing.decode().split()
     listed = set(lines)
     want = set(expected)
     missing = sum(1 for e in expected if e not in listed)
     spurious = sum(1 for ln in lines if ln not in want)
     if weak:
-        assert len(lines) > 0 and spurious <= len(lines) // 2, "%d lines, %d of them no frame of the stream" % (len(lines), spurious)
+        # (measured: 0-1 invented lines per 2,500 - tests/test_bench_helpers.py; the bound leaves room for a noise-born message
+        # or a mis-repair per hundred, not for a second listing mixed into the first)
+        assert len(lines) > 0 and spurious <= len(lines) // 100 + 2, "%d lines, %d of them no frame of the stream" % (len(lines), spurious)
     else:
         assert missing <= len(expected) // 200, "%d of %d injected frames are not in the listing" % (missing, len(expected))
         assert 0.99 * len(expected) <= len(lines) <= 1.02 * len(expected) + 64, "%d lines for %d frames" % (len(lines), len(expected))
@@ -471,8 +482,20 @@ def main():
         # collectives pair up)
         max_blocks = total_blocks // world + 1
         calls = split_calls(first_block, nblocks, (max_blocks + args.call_blocks - 1) // args.call_blocks, lo, total_bytes)
-        res = leg(iq_f, lo, calls, flags, steps, 6, cap_records, max(1, args.leg_streams), True)
-        res.update(total=total_bytes, span=hi - lo, per_gpu=total_bytes // world)
+        # settle like the headline leg: the chip needs ~13 ms of back-to-back kernels to reach its sustained clocks, and the
+        # seconds of host-side stream building in front of this leg restart that transient.  --settle counts
+        # steps of the 1 GiB workload; a leg with G GiB per step and GPU gets ceil(settle / G) of its own steps, at least 6.
+        gib_per_step = max((hi - lo) / 2 ** 30, 1e-3)
+        settle_steps = max(6, int(-(-args.settle // gib_per_step)))
+        res = leg(iq_f, lo, calls, flags, steps, settle_steps, cap_records, max(1, args.leg_streams), True)
+        res.update(total=total_bytes, span=hi - lo, per_gpu=total_bytes // world, settle_steps=settle_steps)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "strong":     # (strong: the frames leg's stream at another seed)
+            # the compiled reference on the first GiB of THIS leg's stream, with this leg's flags ("for >= 8 GiB
+            # configs ... on the first 1 GiB with the extrapolation stated": the stream is statistically uniform - one frame
+            # per `per` samples throughout - so the rate of the first GiB is the rate of the whole)
+            nb = min(args.cpu_mib << 20, (hi - lo) // 262144 * 262144)
+            res["cpu_baseline"] = cpu_baseline(iq_f, nb, "aggressive" if flags.get("aggressive") else "default", passes=1,
+                                               what="this leg's stream (the whole stream has the same frame density)")
         del iq_f
         torch.cuda.empty_cache()
         parts = gathered(mine)
@@ -556,7 +579,10 @@ def main():
              "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "calls_per_step": leg["calls_per_step"],
              "bytes_per_gpu": leg["per_gpu"],
              "kernel_ms": {"scan": round(leg["scan_ms"], 4), "demod": round(leg["demod_ms"], 4), "order": round(leg["order_ms"], 4)},
-             "records_per_step_rank0": int(leg["last"].get("n_records", 0)), "host_ms_per_call": leg.get("host_ms_per_call")}
+             "records_per_step_rank0": int(leg["last"].get("n_records", 0)), "host_ms_per_call": leg.get("host_ms_per_call"),
+             "settle_steps": leg.get("settle_steps")}
+        if leg.get("cpu_baseline") is not None:
+            d["cpu_baseline"] = leg["cpu_baseline"]
         ksum = leg["calls_per_step"] * (leg["scan_ms"] + leg["demod_ms"] + leg["order_ms"])
         d["wall_over_kernels"] = round(d["ms_per_step"] / ksum, 3) if ksum > 0 else None
         per_rank = gathered({"scan": round(leg["scan_ms"], 4), "demod": round(leg["demod_ms"], 4)})
@@ -614,7 +640,7 @@ def main():
         "vs_baseline": None, "dtype": "u16", "data": "synthetic",
         "config": {"workload": head_name, "bytes_per_gpu": head["per_gpu"],
                    "flags": {"noise": "--raw --no-fix", "lowsnr": "--raw --aggressive"}.get(head_kind, "--raw"),
-                   "sharding": "buffers over %d rank(s)" % world, "settle_steps": args.settle if noise is not None else 6,
+                   "sharding": "buffers over %d rank(s)" % world, "settle_steps": args.settle if noise is not None else head.get("settle_steps"),
                    "demod_variant": args.demod_variant,
                    "step": "scan + demod + order kernels, record fetch%s, host resolve + --raw formatting on a second thread; "
                            "%d detect(s) in flight; overlap=%d; completion by a host-visible word (no event in the stream), kernel timing events on "
@@ -666,7 +692,7 @@ def main():
     if rank == 0 and world == 1 and noise is not None and not args.no_end_to_end:
         line["end_to_end"] = end_to_end(torch, dev, iq_noise, args)
     if rank == 0 and world == 1 and noise is not None and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(iq_noise, min(args.cpu_mib << 20, noise["span"] // 262144 * 262144))
+        line["cpu_baseline"] = cpu_baseline(iq_noise, min(args.cpu_mib << 20, noise["span"] // 262144 * 262144), "nofix", passes=4)
     if rank == 0:
         print(json.dumps(line), file=line_out, flush=True)
     if dist_on:

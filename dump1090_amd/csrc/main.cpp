@@ -375,7 +375,8 @@ int run_ranks(const Options &opt, double t_start) {
     const uint8_t *map = size ? static_cast<const uint8_t *>(mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0)) : nullptr;
     if (size && map == MAP_FAILED) { perror("mmap"); return finish(1); }
 
-    const int depth = 3;
+    // three stages are in flight per rank (round q submits, q - 1 exchanges, q - 2 is resolved): at least three sets of buffers
+    const int depth = std::max(3, opt.depth);
     modes_gather_config gc{device, rank, N, opt.gather_cap, (uint32_t)depth, 0};
     modes_gather *g = nullptr;
     if (G.create(&gc, id, &g) != MODES_OK) { fprintf(stderr, "--ranks: rank %d: %s\n", rank, G.last_error(nullptr)); return finish(1); }
@@ -463,7 +464,17 @@ int run_ranks(const Options &opt, double t_start) {
         }
     }
     const double t_end = now_s();
-    if (rank == 0 && opt.timing && !rc) {
+    if (rc) {
+        // A rank that leaves the round loop with an error has peers that wait inside a collective it will never issue; they never
+        // reach their own teardown, and RCCL's communicator destroy may wait for them (it synchronises the ranks of a node).  So
+        // nothing is torn down on this path: a peer reports and exits at once (rank 0's watchdog then ends the job), rank 0 ends
+        // the other ranks first and leaves the rest to the process exit.
+        fflush(out);
+        fflush(stderr);
+        if (rank != 0) _exit(rc);
+        _exit(finish(rc));
+    }
+    if (rank == 0 && opt.timing) {
         modes_gather_stats st{};
         G.get_stats(g, &st);
         const double stream_s = t_end - t_ready;
@@ -533,7 +544,17 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (opt.batch_blocks == 0) opt.batch_blocks = 1;
-    if (opt.ranks > 0) return run_ranks(opt, t_start);
+    if (opt.ranks > 0) {
+        // a regular file shorter than a batch: buffers of its size (see below) - every rank pins depth x batch, rank 0 also
+        // depth x ranks x the gather capacity
+        struct stat sb;
+        if (opt.filename != "-" && stat(opt.filename.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) {
+            const uint64_t in_file = (uint64_t)sb.st_size / MODES_DATA_LEN + 1;
+            if (in_file < opt.batch_blocks) opt.batch_blocks = in_file;
+        }
+        if (ngpus > 0) { fprintf(stderr, "--ranks and --gpus are two ways to use N GPUs: give one of them\n"); return 1; }
+        return run_ranks(opt, t_start);
+    }
     if (opt.devices.empty()) {
         if (ngpus > 0) for (int d = 0; d < ngpus; d++) opt.devices.push_back(d);
         else opt.devices.push_back(single_device);

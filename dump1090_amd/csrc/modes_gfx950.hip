@@ -695,6 +695,11 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// bits of `mask` below this lane (v_mbcnt: no per-lane mask register to keep alive)
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 // Ballot of a per-pair flag: lane L contributes pair L (f1) and pair L+64 (f2, lanes < 48).
 __device__ __forceinline__ modes_m128 pair_ballot(bool f1, bool f2) {
     return m128_make(__ballot(f1), __ballot(f2) & 0x0000FFFFFFFFFFFFull);
@@ -1341,7 +1346,12 @@ constexpr int kSelWaves = 16;
 constexpr int kSelThreads = kSelWaves * 64;
 constexpr int kSelLanes = 8;                               // lanes per preamble in the gate pre-test
 constexpr int kSelPerRound = kSelThreads / kSelLanes;      // 128 preambles per round
-constexpr int kSelAhead = 2;                               // rounds whose loads are in flight together (640 preambles: a noise batch has ~530)
+#ifndef SEL_AHEAD
+#define SEL_AHEAD 1
+#endif
+constexpr int kSelAhead = SEL_AHEAD;                       // rounds whose loads are in flight together.  1: the kernel fits its 64 VGPRs (two 16-wave
+                                                           // workgroups per CU) without a private segment; 2 spills 24 bytes per lane for no measured gain
+                                                           // (1, 2, 3, 5 or 9 rounds in flight: the stage waits for HBM lines either way - DESIGN.md 3.2)
 // s_flag values (per preamble of the block); LONG carries the first half's delta sum in its low 22 bits (<= 56 * 65167)
 constexpr uint32_t kSelFail = 0u, kSelPass = 1u << 30, kSelEdge = 2u << 30, kSelLong = 3u << 30, kSelKind = 3u << 30;
 
@@ -1426,7 +1436,7 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
     __shared__ uint32_t s_wcnt[kSelWaves + 1];         // per-wavefront counts -> exclusive prefix
     __shared__ uint32_t s_n[2];                        // [0] long ones, [1] edge ones of the block
     __shared__ uint32_t s_flags;                       // WgTotals.flags bits
-    __shared__ unsigned long long s_fwd;
+    __shared__ uint32_t s_fwd;                         // forwarded positions of the workgroup's batches (a call has < 2^32 positions)
 #ifdef MODES_TRACE
     const unsigned long long t_start = wall_clock64();
     unsigned long long tr_t[4] = {0, 0, 0, 0};          // batch set-up, stage 1 (+ compaction), stage 2a, stage 2b + edge + write-out
@@ -1442,9 +1452,8 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
 #endif
     const uint8_t *iq = P.iq;
     const int64_t lo = P.lo, hi = P.hi;
-    const uint64_t below = (1ull << lane) - 1;
     const uint32_t lut_adj = (uint32_t)reinterpret_cast<uintptr_t>(s_lut) + 0x10000u;     // sel_pair: LDS byte address of the table, adjusted
-    unsigned long long tot_fwd = 0, tot_cand = 0;      // tot_fwd: per lane of wavefront 0; tot_cand: workgroup-uniform
+    uint32_t tot_cand = 0;                             // workgroup-uniform
 
     for (uint32_t batch = blockIdx.x; batch < P.nbatches; batch += gridDim.x) {
         const uint32_t run0 = batch * kDemodGroup;
@@ -1457,7 +1466,8 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
                 const uint32_t true_count = P.counts[run0 + lane];
                 if (true_count > P.slot_cap) atomicOr(&s_flags, 1u);           // the scan dropped positions: the call fails
                 cnt = min(true_count, P.slot_cap);
-                tot_fwd += true_count;
+                atomicAdd(&s_fwd, true_count);                                 // (one LDS instruction per batch: a running per-lane sum would
+                                                                               //  be one more register alive across everything below)
             }
             uint32_t incl = cnt;
 #pragma unroll
@@ -1469,7 +1479,7 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
             if (lane == 63) s_pre[64] = incl;
         }
         __syncthreads();
-        const uint32_t n = s_pre[kDemodGroup];
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pre[kDemodGroup]);     // workgroup-uniform values live in SGPRs:
         const uint64_t list_base = (uint64_t)batch * kDemodGroup * P.slot_cap;   // of the batch's candidate and survivor lists
         uint32_t ncand = 0, prior = 0;
         auto slot_of = [&](uint32_t e) -> uint32_t {
@@ -1491,7 +1501,7 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
                 all += c;
             }
             __syncthreads();
-            *total = all;
+            *total = (uint32_t)__builtin_amdgcn_readfirstlane((int)all);
             return before;
         };
         uint32_t p_next = (uint32_t)tid < n ? slot_of((uint32_t)tid) : 0u;
@@ -1514,7 +1524,7 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
             uint32_t nlist;
             const uint32_t wbase = wave_prefix((uint32_t)__builtin_popcountll(okb), &nlist);
             if (ok) {
-                const uint32_t c = wbase + (uint32_t)__builtin_popcountll(okb & below);
+                const uint32_t c = wbase + lanes_below(okb);
                 s_list[c] = p;
                 s_flag[c] = whole ? kSelFail : kSelEdge;
                 if (P.cand_slots) P.cand_slots[list_base + ncand + c] = p;
@@ -1525,8 +1535,8 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
                 uint32_t eb = 0;
                 if (lane == 0) eb = atomicAdd(&s_n[1], (uint32_t)__builtin_popcountll(edgeb));
                 eb = (uint32_t)__builtin_amdgcn_readfirstlane((int)eb);
-                if (ok && !whole) s_work[kSelThreads - 1 - (eb + (uint32_t)__builtin_popcountll(edgeb & below))] =
-                    (uint16_t)(wbase + (uint32_t)__builtin_popcountll(okb & below));
+                if (ok && !whole) s_work[kSelThreads - 1 - (eb + lanes_below(edgeb))] =
+                    (uint16_t)(wbase + lanes_below(okb));
             }
             __syncthreads();
             ncand += nlist;
@@ -1573,7 +1583,7 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
                         if (lane == 0) qb = atomicAdd(&s_n[0], (uint32_t)__builtin_popcountll(mb));
                         qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
                         if (more) {
-                            s_work[qb + (uint32_t)__builtin_popcountll(mb & below)] = (uint16_t)c;
+                            s_work[qb + lanes_below(mb)] = (uint16_t)c;
                             s_flag[c] = kSelLong | d56;
                         }
                     }
@@ -1583,7 +1593,7 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
             TRACE_ADD(2, ts2);
             TRACE_T(ts3);
             // ---------------- stage 2b: the other 56 pairs of the long ones ----------------
-            const uint32_t nlong = s_n[0], nedge = s_n[1];
+            const uint32_t nlong = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_n[0]), nedge = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_n[1]);
             for (uint32_t c0 = 0; c0 < nlong; c0 += kSelPerRound) {
                 const uint32_t k = c0 + (uint32_t)grp;
                 const bool gact = k < nlong;
@@ -1623,7 +1633,7 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
                 const uint64_t pb = __ballot(pass);
                 uint32_t nsurv;
                 const uint32_t sb = wave_prefix((uint32_t)__builtin_popcountll(pb), &nsurv);
-                if (pass) P.surv[list_base + prior + sb + (uint32_t)__builtin_popcountll(pb & below)] = s_list[tid];
+                if (pass) P.surv[list_base + prior + sb + lanes_below(pb)] = s_list[tid];
                 prior += nsurv;
                 if (tid == 0) { s_n[0] = 0; s_n[1] = 0; }                      // (wave_prefix ended with a barrier: nobody reads them now)
             }
@@ -1647,10 +1657,6 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
         }
     }
 #endif
-    if (wave == 0) {
-        tot_fwd = (unsigned long long)wave_sum((int)tot_fwd);
-        if (lane == 0) s_fwd = tot_fwd;
-    }
     __syncthreads();
     if (tid == 0) P.totals[blockIdx.x] = WgTotals{s_fwd, tot_cand, s_flags, 0};
 }
@@ -2154,8 +2160,18 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     modes_gpu *ctx = new (std::nothrow) modes_gpu;
     if (!ctx) return fail(nullptr, MODES_ERR_NOMEM, "out of memory");
     ctx->cfg = *cfg;
-    if (const char *v = getenv("MODES_GPU_DEMOD_VARIANT"))           // measurement / test knob: run a whole suite on another demod path
-        ctx->cfg.demod_variant = (uint32_t)atoi(v);
+    // Measurement / test knob: run a whole suite on one demodulation path.  It only fills in the AUTOMATIC choice - a caller that
+    // asks for a path by number gets that path (the parity tests that cross-check the two paths against each other must not
+    // collapse into one) - and it must be a number the library knows.
+    if (const char *v = getenv("MODES_GPU_DEMOD_VARIANT")) {
+        char *end = nullptr;
+        const unsigned long n = strtoul(v, &end, 10);
+        if (end == v || *end != 0 || !(n == 0 || n == 2 || n == 3)) {
+            delete ctx;
+            return fail(nullptr, MODES_ERR_ARG, "MODES_GPU_DEMOD_VARIANT='%s': 0 (automatic), 2 (two kernels) or 3 (one kernel)", v);
+        }
+        if (ctx->cfg.demod_variant == 0) ctx->cfg.demod_variant = (uint32_t)n;
+    }
     if (ctx->cfg.demod_variant == 1 || ctx->cfg.demod_variant > 3) {
         const uint32_t v = ctx->cfg.demod_variant;
         delete ctx;
@@ -2700,7 +2716,12 @@ int modes_gpu_stream_ceiling(modes_gpu *ctx, const void *d_iq, uint64_t nbytes, 
     // the launches are queued back to back without a host round trip (an idle chip boosts its clocks: DESIGN.md 3.1); one
     // in time_every carries start / stop events attached to its dispatch - the scan kernel's own timing method
     const uint32_t ntimed = (launches + time_every - 1) / time_every;
-    std::vector<hipEvent_t> evs(2 * (size_t)ntimed, nullptr);
+    struct Events {                                                          // destroyed on every way out of this function
+        std::vector<hipEvent_t> v;
+        ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
+    } guard;
+    std::vector<hipEvent_t> &evs = guard.v;
+    evs.assign(2 * (size_t)ntimed, nullptr);
     for (auto &e : evs) HIP_TRY(ctx, hipEventCreate(&e));
     uint32_t t = 0;
     for (uint32_t i = 0; i < launches; i++) {
@@ -2720,7 +2741,6 @@ int modes_gpu_stream_ceiling(modes_gpu *ctx, const void *d_iq, uint64_t nbytes, 
         sum += ms;
         best = std::min(best, ms);
     }
-    for (auto &e : evs) (void)hipEventDestroy(e);
     *avg_ms = t ? (float)(sum / t) : 0.f;
     if (min_ms) *min_ms = t ? best : 0.f;
     return MODES_OK;

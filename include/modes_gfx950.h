@@ -127,7 +127,9 @@ typedef struct {
     uint64_t            n_preambles;   /* positions where dump1090.c:1602-1650 holds  */
     float               scan_ms;       /* HIP-event time of the scan kernel           */
     float               demod_ms;      /* of the demod kernel                         */
-    float               order_ms;      /* of the order kernel (records into stream order) */
+    float               order_ms;      /* of the third kernel of the call: the order kernel (records into stream order) on the
+                                          one-kernel path, the RECORD kernel on the two-kernel path (demod_ms is then the select
+                                          kernel's) - "the kernels behind the scan" add up to demod_ms + order_ms on either path */
     float               reserved;
 } modes_gpu_result;
 

@@ -46,6 +46,13 @@ void modes_gpu_host_free(modes_gpu *, void *p) { delete[] static_cast<uint8_t *>
 
 int modes_gpu_submit_host(modes_gpu *g, const uint8_t *iq, uint64_t nbytes, uint64_t byte0, uint64_t first_block, uint64_t nblocks) {
     if (g->in_flight) { g->err = "submit_host: a detect is already in flight"; return MODES_ERR_STATE; }
+    // MODES_STUB_FAIL_SUBMIT=<d>:<k>: the k-th submit (from 0) of this process on "GPU" d fails - a rank that fails MID-STREAM,
+    // with its peers already inside the next round's collective
+    if (const char *f = getenv("MODES_STUB_FAIL_SUBMIT")) {
+        static int submits = 0;
+        int d = -1, k = -1;
+        if (sscanf(f, "%d:%d", &d, &k) == 2 && d == g->cfg.device && submits++ == k) { g->err = "stub: submit fails on request"; return MODES_ERR_HIP; }
+    }
     g->iq = iq; g->nbytes = nbytes; g->byte0 = byte0; g->first_block = first_block; g->nblocks = nblocks;
     g->in_flight = true;
     return MODES_OK;

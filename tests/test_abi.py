@@ -68,3 +68,21 @@ def test_create_without_gpu_fails_loudly():
     from dump1090_amd import Demodulator, ModesError
     with pytest.raises(ModesError, match="no HIP device"):
         Demodulator()
+
+
+def test_no_kernel_of_the_shipped_library_spills():
+    """Every kernel of dump1090_amd/libmodes_gfx950.so has private_segment_fixed_size == 0 in its gfx950 code object's
+    metadata (tools/kernel_resources.py reads the AMDGPU notes of the very file that ships): select_kernel is held to
+    64 VGPRs for two 16-wave workgroups per CU and used to pay for it with 52 bytes of scratch per lane."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    if not os.path.exists(kr.READELF):
+        pytest.skip("no llvm-readelf")
+    rows = kr.kernel_resources(N.GPU_LIB)
+    names = {r["name"] for r in rows}
+    assert {"scan_kernel", "demod_kernel", "select_kernel", "record_kernel", "finalize_kernel", "finalize2_kernel"} <= names, names
+    spills = {r["name"]: r["scratch"] for r in rows if r["scratch"]}
+    assert not spills, "kernels with a private segment (bytes per lane): %s" % spills
+    by = {r["name"]: r for r in rows}
+    assert by["select_kernel"]["vgpr"] <= 64 and by["scan_kernel"]["vgpr"] <= 64      # the occupancy the launch geometry counts on

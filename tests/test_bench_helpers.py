@@ -132,3 +132,22 @@ def test_fetch_size_rows_become_bytes_per_launch(tmp_path):
     assert bench.fetch_bytes_per_launch(str(tmp_path)) == (int(536500.0 * 1024 * 2), 2)
     assert bench.fetch_bytes_per_launch(str(tmp_path), kernel="demod_kernel") == (int(147000.0 * 2048), 1)
     assert bench.fetch_bytes_per_launch(str(tmp_path), kernel="order_kernel") is None
+
+
+def test_weak_listing_check_still_rejects_foreign_lines():
+    """The low-SNR leg's check (most injected frames are undecodable: `missing` is unbounded) keeps the other two bounds: what is
+    listed must be frames of the stream (1 % + 2 may not be) and in stream order."""
+    import oracle as orc
+    st = synth.config3_stream(5, 96, **bench.LOWSNR)
+    msgs, _ = orc.run_stream(st.window(0, st.nbytes), **orc.FLAGSETS["aggressive"])
+    lines = orc.raw_text(msgs).split()
+    expected = bench.frames_expectation(st, 0, 97)
+    join = lambda ls: ("\n".join(ls) + "\n").encode()
+    ok = bench.check_listing(join(lines), expected, weak=True)
+    assert ok["lines"] > 40 and ok["spurious"] <= 1 and ok["missing"] > ok["lines"]
+    junk = ["*5d%06x%06x;" % (k, k * 7919) for k in range(3)]
+    with pytest.raises(AssertionError, match="no frame of the stream"):
+        bench.check_listing(join(lines[:20] + junk + lines[20:]), expected, weak=True)
+    with pytest.raises(AssertionError, match="stream order"):
+        half = len(lines) // 2
+        bench.check_listing(join(lines[half:] + lines[:half]), expected, weak=True)

@@ -167,10 +167,28 @@ def test_records_and_candidates_match_oracle(torch_cuda, streams, case, demod_va
 
 def test_removed_demod_variant_is_refused(torch_cuda):
     from dump1090_amd import Demodulator, ModesError
-    if os.environ.get("MODES_GPU_DEMOD_VARIANT"):
-        pytest.skip("the environment overrides the variant")
-    with pytest.raises(ModesError, match="demod_variant 1"):
+    with pytest.raises(ModesError, match="demod_variant 1"):      # (an explicit variant is never overridden by the environment)
         Demodulator(demod_variant=1)
+
+
+def test_environment_knob_only_fills_in_the_automatic_choice(torch_cuda, streams, monkeypatch):
+    """MODES_GPU_DEMOD_VARIANT (tools/gpu_round.sh: a whole suite on one path) applies to contexts created with demod_variant 0
+    only, and must be 0, 2 or 3: garbage or the removed variant 1 fails the create instead of silently meaning `automatic`."""
+    from dump1090_amd import Demodulator, ModesError
+    iq = to_dev(torch_cuda, streams["frames"])
+    want, _ = oracle_records(streams["frames"], 1)
+    for value in ("banana", "1", "2x", ""):
+        monkeypatch.setenv("MODES_GPU_DEMOD_VARIANT", value)
+        with pytest.raises(ModesError, match="MODES_GPU_DEMOD_VARIANT"):
+            Demodulator()
+    monkeypatch.setenv("MODES_GPU_DEMOD_VARIANT", "2")
+    for explicit, third_kernel in ((3, False), (0, True), (2, True)):          # 3 stays the one-kernel path: no record kernel time
+        d = Demodulator(demod_variant=explicit)
+        d.detect(iq)
+        recs, _, info = d.fetch()
+        assert_records_equal(recs, want, ctx=("env", explicit))
+        assert (info["order_ms"] > 0) == third_kernel, (explicit, info["order_ms"])
+        d.close()
 
 
 def test_automatic_demod_path_follows_the_record_density(torch_cuda, streams):

@@ -318,3 +318,6 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 9 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
     # a rank that fails to start while its peers wait in the gather ends the job (status 1), whichever rank it is
     assert p.stdout.count(b"fails to start: exit status 1") == 3
+    # ... and so does a rank whose GPU call fails mid-stream, with its peer already inside that round's exchange (no teardown of
+    # the communicator on that path: ADVICE round 3)
+    assert p.stdout.count(b"fails in GPU call") == 2 and p.stdout.count(b": exit status 1") == 5

@@ -111,6 +111,16 @@ run_ranks_host() {
         echo "   rank $bad fails to start: exit status $rc"
         [ "$rc" = 1 ] || { cat $D/fail.err; exit 1; }
     done
+    # a rank that fails MID-STREAM (two ranks, three batches: rank 0's second GPU call / rank 1's only one): the peer is already
+    # in that round's exchange, nobody tears an RCCL communicator down on that path (main.cpp run_ranks) - status 1, promptly
+    for bad in 0:1 1:0; do
+        set +e
+        MODES_STUB_FAIL_SUBMIT=$bad timeout 20 $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw --ranks 2 --batch-blocks 1 --depth 4 > /dev/null 2> $D/fail.err
+        rc=$?
+        set -e
+        echo "   rank ${bad%%:*} fails in GPU call ${bad##*:}: exit status $rc"
+        [ "$rc" = 1 ] || { cat $D/fail.err; exit 1; }
+    done
 }
 case "${1:-all}" in
     ubsan) run_one ubsan ;;
