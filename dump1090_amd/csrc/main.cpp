@@ -581,6 +581,7 @@ int main(int argc, char **argv) {
     const int nlanes = ndev * opt.depth;
     const size_t batch_bytes = (size_t)opt.batch_blocks * MODES_DATA_LEN;
     std::vector<Lane> lanes((size_t)nlanes);
+    std::vector<double> t_created((size_t)nlanes, 0.0), t_pinned((size_t)nlanes, 0.0);      // --timing: when each lane had its context / buffer
     {
         std::vector<std::string> errs((size_t)nlanes);
         auto make = [&](int l) {
@@ -595,12 +596,14 @@ int main(int argc, char **argv) {
                 return;
             }
             modes_gpu_set_timing(lanes[(size_t)l].gpu, 0);            // no timing events between the kernels: batches run back to back
+            t_created[(size_t)l] = now_s();
             void *p = nullptr;
             if (modes_gpu_host_alloc(lanes[(size_t)l].gpu, MODES_CARRY_BYTES + batch_bytes, &p) != MODES_OK) {
                 errs[(size_t)l] = std::string("pinned buffer: ") + modes_gpu_last_error(lanes[(size_t)l].gpu);
                 return;
             }
             lanes[(size_t)l].buf = static_cast<uint8_t *>(p);
+            t_pinned[(size_t)l] = now_s();
         };
         std::vector<std::thread> th;
         for (int d = 0; d < ndev; d++)
@@ -747,22 +750,30 @@ int main(int argc, char **argv) {
         modes_format_stats(&st, text);
         fputs(text, stdout);
     }
-    if (opt.timing) {
-        const double stream_s = t_end - t_ready;
-        fprintf(stderr,
-                "{\"bytes\": %llu, \"devices\": %d, \"lanes\": %d, \"init_s\": %.4f, \"stream_s\": %.4f, \"total_s\": %.4f, "
-                "\"stream_GBps\": %.2f, \"stream_Msamples_per_s\": %.1f, \"sink_calls\": %llu}\n",
-                (unsigned long long)total_bytes, ndev, nlanes, t_ready - t_start, stream_s, t_end - t_start,
-                stream_s > 0 ? total_bytes / stream_s / 1e9 : 0.0, stream_s > 0 ? total_bytes / 2 / stream_s / 1e6 : 0.0,
-                (unsigned long long)n_messages_out);
-    }
+    fflush(stdout);
+    const double t_flushed = now_s();
     modes_host_destroy(host);
     modes_tracker_destroy(sink.tracker);
+    const double t_host = now_s();
     for (auto &ln : lanes) {
         modes_gpu_host_free(ln.gpu, ln.buf);
         modes_gpu_destroy(ln.gpu);
     }
+    const double t_lanes = now_s();
     if (map) munmap(const_cast<uint8_t *>(map), map_len);
     if (fd > 0) close(fd);
+    const double t_unmapped = now_s();
+    if (opt.timing) {
+        const double stream_s = t_end - t_ready;
+        fprintf(stderr,
+                "{\"bytes\": %llu, \"devices\": %d, \"lanes\": %d, \"init_s\": %.4f, \"stream_s\": %.4f, \"total_s\": %.4f, "
+                "\"stream_GBps\": %.2f, \"stream_Msamples_per_s\": %.1f, \"sink_calls\": %llu, "
+                "\"init\": {\"first_context_s\": %.4f, \"first_buffer_s\": %.4f, \"all_lanes_s\": %.4f}, "
+                "\"teardown\": {\"flush_s\": %.4f, \"host_s\": %.4f, \"lanes_s\": %.4f, \"unmap_s\": %.4f}}\n",
+                (unsigned long long)total_bytes, ndev, nlanes, t_ready - t_start, stream_s, t_unmapped - t_start,
+                stream_s > 0 ? total_bytes / stream_s / 1e9 : 0.0, stream_s > 0 ? total_bytes / 2 / stream_s / 1e6 : 0.0,
+                (unsigned long long)n_messages_out, t_created[0] - t_start, t_pinned[0] - t_start, t_ready - t_start,
+                t_flushed - t_end, t_host - t_flushed, t_lanes - t_host, t_unmapped - t_lanes);
+    }
     return rc;
 }

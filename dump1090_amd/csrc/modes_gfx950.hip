@@ -2153,6 +2153,12 @@ const char *modes_gpu_last_error(const modes_gpu *ctx) { return ctx ? ctx->err.c
 int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     if (!cfg || !out) return fail(nullptr, MODES_ERR_ARG, "modes_gpu_create: null argument");
     *out = nullptr;
+    // MODES_GPU_CREATE_TRACE=1: where the time of a create goes, to stderr (the C host's start-up is most of a short file's wall clock)
+    using clk = std::chrono::steady_clock;
+    const bool trace = getenv("MODES_GPU_CREATE_TRACE") != nullptr;
+    clk::time_point t_prev = clk::now();
+    double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto phase = [&](int k) { const clk::time_point now = clk::now(); t_phase[k] += std::chrono::duration<double>(now - t_prev).count(); t_prev = now; };
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, MODES_ERR_HIP, "no HIP device: libmodes_gfx950 has no CPU fallback");
@@ -2187,8 +2193,10 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
         hipError_t e_ = (call);                                                                       \
         if (e_ != hipSuccess) { fail(ctx, MODES_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); return bail(MODES_ERR_HIP); } \
     } while (0)
+    phase(0);                                                               // runtime start-up (first call of the process)
     CREATE_TRY(hipSetDevice(cfg->device));
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    phase(1);                                                               // device context, stream
     {   // demod_kernel is persistent: launch exactly as many workgroups as fit on the chip at once
         hipDeviceProp_t prop;
         int per_cu = 0;
@@ -2198,6 +2206,7 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
         CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, select_kernel, kSelThreads, 0));
         ctx->select_wgs = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, prop.multiProcessorCount);
     }
+    phase(2);                                                               // code object load (first occupancy query)
     for (auto &e : ctx->ev_k) CREATE_TRY(hipEventCreate(&e));
     CREATE_TRY(hipEventCreate(&ctx->ev_done));
     if (const char *m = getenv("MODES_GPU_TIMING"))              // measurement knob (tools/gpu_round.sh): 0 = no kernel events
@@ -2237,7 +2246,12 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_hdr_dev), ctx->h_hdr, 0));
     memset(ctx->h_hdr, 0, sizeof(HostHeader));
 #undef CREATE_TRY
+    phase(3);                                                               // tables, small buffers
     if (alloc_lists(ctx, ctx->cfg.max_records) != MODES_OK) return bail(MODES_ERR_NOMEM);
+    phase(4);                                                               // record lists (device + pinned host)
+    if (trace)
+        fprintf(stderr, "modes_gpu_create: runtime %.4f s, context %.4f, code object %.4f, tables %.4f, lists %.4f\n", t_phase[0], t_phase[1],
+                t_phase[2], t_phase[3], t_phase[4]);
     *out = ctx;
     return MODES_OK;
 }

@@ -10,8 +10,18 @@
  *                                                          Modes.data belongs to the reader again afterwards)
  *     detectModeS(Modes.magnitude, Modes.data_len/2);  ->  modesGpuResolve();
  *
- * One 256 KiB buffer per GPU call keeps the reference's structure (and its latency); it is the wrong
- * granularity for throughput - dump1090_amd/csrc/main.cpp is the host for that.
+ * That is integration/dump1090_gfx950.patch: one 256 KiB buffer per GPU call keeps the reference's structure (and its
+ * latency); it is the wrong granularity for throughput - 4,096 synchronous GPU calls per GiB.
+ *
+ * integration/dump1090_gfx950_batched.patch adds ONE more edit: the file reader (dump1090.c:460-512, called at :524) becomes
+ * modesGpuReadFile() below, which hands over K x 262,144 bytes per round trip through data_mutex / data_cond instead of one
+ * buffer (K = $MODES_DROPIN_BLOCKS, default 512 = 128 MiB; 1 with --interactive, which replays at the radio's pace).  The
+ * library does the framing of a multi-buffer call itself (modes_gpu_submit_host(..., nblocks)), so modesGpuDemod() only passes
+ * the count on; two pinned buffers and two GPU contexts alternate, so that the reader fills one buffer while the GPU works on
+ * the other and the main thread resolves the batch before; the resolve runs once per hand-off.  Live RTL-SDR input
+ * (rtlsdrCallback, dump1090.c:442-456) is untouched and keeps one buffer per call.  The main loop (:2969-2990) is the same
+ * four edits; the reference's EOF race (its loop usually drops the last buffer) does not exist on this path -
+ * the reader raises Modes.exit only after the last hand-off has been consumed.
  */
 #define MODES_HOST_NO_MESSAGE_STRUCT        /* dump1090.c:211-260 is the definition in this translation unit */
 #include "modes_gfx950.h"
@@ -26,6 +36,22 @@ static modes_gpu  *dropin_gpu;
 static modes_host *dropin_host;
 static modes_gpu_result dropin_res;
 static uint64_t dropin_nbuf;                 /* buffers handed over so far */
+
+/* ---- batched file input (integration/dump1090_gfx950_batched.patch) ---- */
+static int            dropin_batched;        /* modesGpuReadFile() is the reader of this run                              */
+static uint64_t       dropin_k = 512;        /* buffers per hand-off                                                      */
+static modes_gpu     *dropin_ctx[2];         /* [0] = dropin_gpu                                                          */
+static unsigned char *dropin_buf[2];         /* pinned: 476-byte carry + K x 262144 bytes                                 */
+static struct {                              /* the hand-off, written by the reader under data_mutex before data_ready = 1 */
+    int      which;                          /* buffer / context of this batch                                            */
+    size_t   carry, fresh;                   /* valid carry bytes in front (0 for the first batch), new bytes behind them  */
+    uint64_t first_block;
+    int      last;                           /* the stream ends with this batch (it carries the EOF buffer)               */
+    int      empty;                          /* nothing to do: the wake-up call that follows the last batch               */
+} dropin_hand;
+static int dropin_inflight = -1;             /* context whose batch has been submitted but not fetched                    */
+static modes_gpu_result dropin_res_last;     /* the last batch's records, fetched together with its predecessor's         */
+static int dropin_have[2];                   /* dropin_res / dropin_res_last hold a batch to resolve                      */
 
 /* once, after modesInit() (dump1090.c:2943) */
 static void modesInitGpu(void) {
@@ -48,12 +74,173 @@ static void modesInitGpu(void) {
         fprintf(stderr, "GPU path: out of memory\n");
         exit(1);
     }
+    dropin_ctx[0] = dropin_gpu;
+}
+
+static void dropin_die(const char *what, modes_gpu *g) {
+    fprintf(stderr, "GPU path: %s: %s\n", what, modes_gpu_last_error(g));
+    exit(1);                                                              /* like dump1090.c:339-343 */
+}
+
+/* K, the second context, the two pinned buffers - by the reader thread, before its first read */
+static void dropin_setup_batched(void) {
+    modes_gpu_config gc;
+    const char *k = getenv("MODES_DROPIN_BLOCKS");
+    int i;
+    if (k && atoll(k) > 0) dropin_k = (uint64_t)atoll(k);
+    if (Modes.interactive) dropin_k = 1;                                  /* replayed at the radio's pace, dump1090.c:470-476 */
+    if (dropin_k > 16384) dropin_k = 16384;                               /* 4 GiB per call */
+    memset(&gc, 0, sizeof(gc));
+    gc.device = 0;
+    gc.fix_errors = Modes.fix_errors;
+    gc.aggressive = Modes.aggressive;
+    gc.keep_candidates = Modes.stats;
+    if (modes_gpu_create(&gc, &dropin_ctx[1]) != MODES_OK) dropin_die("second context", NULL);
+    for (i = 0; i < 2; i++) {
+        void *p = NULL;
+        if (modes_gpu_host_alloc(dropin_ctx[i], MODES_CARRY_BYTES + dropin_k * (size_t)MODES_DATA_LEN, &p) != MODES_OK)
+            dropin_die("pinned buffer", dropin_ctx[i]);
+        dropin_buf[i] = p;
+        modes_gpu_set_timing(dropin_ctx[i], 0);                           /* no timing events between the kernels */
+    }
+    dropin_batched = 1;
+}
+
+/* A regular file is read by several threads at once (pread on disjoint slices): one thread copying out of the page
+ * cache is an order of magnitude slower than the PCIe link behind it. */
+#define DROPIN_READERS 16
+struct dropin_slice { int fd; unsigned char *dst; size_t want, got; off_t at; };
+static void *dropin_read_slice(void *arg) {
+    struct dropin_slice *s = arg;
+    while (s->got < s->want) {
+        ssize_t n = pread(s->fd, s->dst + s->got, s->want - s->got, s->at + (off_t)s->got);
+        if (n < 0 && errno == EINTR) continue;
+        if (n <= 0) break;
+        s->got += (size_t)n;
+    }
+    return NULL;
+}
+/* -> bytes read (short only at end of file) */
+static size_t dropin_read_parallel(int fd, off_t at, unsigned char *dst, size_t want) {
+    struct dropin_slice sl[DROPIN_READERS];
+    pthread_t th[DROPIN_READERS];
+    size_t per = (want / DROPIN_READERS + 4095) & ~(size_t)4095, got = 0;
+    int i, n = 0;
+    for (i = 0; i < DROPIN_READERS && (size_t)i * per < want; i++, n++) {
+        sl[i].fd = fd; sl[i].dst = dst + (size_t)i * per; sl[i].at = at + (off_t)((size_t)i * per); sl[i].got = 0;
+        sl[i].want = want - (size_t)i * per < per ? want - (size_t)i * per : per;
+        if (i > 0 && pthread_create(&th[i], NULL, dropin_read_slice, &sl[i]) != 0) { perror("pthread_create"); exit(1); }
+    }
+    dropin_read_slice(&sl[0]);
+    for (i = 1; i < n; i++) pthread_join(th[i], NULL);
+    for (i = 0; i < n; i++) {
+        got += sl[i].got;
+        if (sl[i].got < sl[i].want) break;                                /* end of file inside this slice */
+    }
+    return got;
+}
+
+/* In place of readDataFromFile() (dump1090.c:460-512; batched patch): the same protocol - fill under data_mutex, publish with
+ * data_ready = 1, wait until the main thread has taken the hand-off - with K buffers per round trip.  At the end of the
+ * file the stream gets its EOF buffer (dump1090.c:499-504 pads the short read with 127: the library reads bytes outside the
+ * span as 127) and Modes.exit is raised only once that hand-off has been consumed. */
+#if defined(__GNUC__)
+__attribute__((unused))                                                   /* only the batched patch calls it */
+#endif
+static void modesGpuReadFile(void) {
+    unsigned char tail[MODES_CARRY_BYTES];
+    size_t carry = 0;
+    uint64_t first_block = 0;
+    off_t pos = 0;
+    int w = 0, last = 0, seekable;
+    dropin_setup_batched();
+    seekable = Modes.fd != STDIN_FILENO && !Modes.loop && lseek(Modes.fd, 0, SEEK_CUR) != (off_t)-1;
+    pthread_mutex_lock(&Modes.data_mutex);
+    while (!last) {
+        const size_t batch = dropin_k * (size_t)MODES_DATA_LEN;
+        unsigned char *p;
+        size_t got = 0;
+        if (Modes.data_ready) {
+            pthread_cond_wait(&Modes.data_cond, &Modes.data_mutex);
+            continue;
+        }
+        if (Modes.interactive) {                                          /* dump1090.c:470-476 */
+            pthread_mutex_unlock(&Modes.data_mutex);
+            usleep(5000);
+            pthread_mutex_lock(&Modes.data_mutex);
+        }
+        p = dropin_buf[w];
+        if (carry) memcpy(p, tail, MODES_CARRY_BYTES);                    /* dump1090.c:481 */
+        if (seekable) {
+            got = dropin_read_parallel(Modes.fd, pos, p + carry, batch);
+            pos += (off_t)got;
+        } else {
+            while (got < batch) {
+                ssize_t n = read(Modes.fd, p + carry + got, batch - got);
+                if (n == 0 && Modes.filename != NULL && Modes.fd != STDIN_FILENO && Modes.loop) {   /* dump1090.c:488-494 */
+                    if (lseek(Modes.fd, 0, SEEK_SET) != -1) continue;
+                }
+                if (n < 0 && errno == EINTR) continue;
+                if (n <= 0) break;
+                got += (size_t)n;
+            }
+        }
+        last = got < batch;
+        dropin_hand.which = w;
+        dropin_hand.carry = carry;
+        dropin_hand.fresh = got;
+        dropin_hand.first_block = first_block;
+        dropin_hand.last = last;
+        dropin_hand.empty = 0;
+        if (!last) {
+            memcpy(tail, p + carry + got - MODES_CARRY_BYTES, MODES_CARRY_BYTES);
+            carry = MODES_CARRY_BYTES;
+            first_block += dropin_k;
+            w ^= 1;
+        }
+        Modes.data_ready = 1;
+        pthread_cond_signal(&Modes.data_cond);
+    }
+    /* the last hand-off is out; when the main thread has taken it, end the main loop (dump1090.c:2989) - with one more,
+     * empty hand-off in case it already waits for data again */
+    while (Modes.data_ready) pthread_cond_wait(&Modes.data_cond, &Modes.data_mutex);
+    Modes.exit = 1;
+    dropin_hand.empty = 1;
+    Modes.data_ready = 1;
+    pthread_cond_signal(&Modes.data_cond);
+    pthread_mutex_unlock(&Modes.data_mutex);
 }
 
 /* In place of computeMagnitudeVector(): Modes.data holds [476-byte carry | 262144 new bytes]
  * (dump1090.c:449-451, 481-483).  The carry of the very first buffer is the 127-fill of modesInit() -
  * "before the stream", which the library supplies itself. */
 static void modesGpuDemod(void) {
+    if (dropin_batched) {
+        /* The hand-off names a pinned buffer with K buffers' worth of stream: queue it (H2D + kernels, asynchronous) on its
+         * own context, then wait for the batch BEFORE it - its buffer is the one the reader fills next, and its records are
+         * what modesGpuResolve() works on while the GPU runs this one.  The last batch is fetched right away too. */
+        const int w = dropin_hand.which;
+        dropin_have[0] = dropin_have[1] = 0;
+        if (dropin_hand.empty) return;
+        {
+            const uint64_t nblocks = dropin_hand.fresh / MODES_DATA_LEN + (dropin_hand.last ? 1 : 0);
+            const uint64_t stream0 = dropin_hand.first_block * (uint64_t)MODES_DATA_LEN - dropin_hand.carry;
+            if (modes_gpu_submit_host(dropin_ctx[w], dropin_buf[w], dropin_hand.carry + dropin_hand.fresh, stream0,
+                                      dropin_hand.first_block, nblocks) != MODES_OK)
+                dropin_die("submit", dropin_ctx[w]);
+        }
+        if (dropin_inflight >= 0) {
+            if (modes_gpu_fetch(dropin_ctx[dropin_inflight], &dropin_res) != MODES_OK) dropin_die("fetch", dropin_ctx[dropin_inflight]);
+            dropin_have[0] = 1;
+        }
+        dropin_inflight = w;
+        if (dropin_hand.last) {
+            if (modes_gpu_fetch(dropin_ctx[w], &dropin_res_last) != MODES_OK) dropin_die("fetch", dropin_ctx[w]);
+            dropin_have[1] = 1;
+            dropin_inflight = -1;
+        }
+        return;
+    }
     const unsigned char *p = dropin_nbuf ? Modes.data : Modes.data + (MODES_FULL_LEN - 1) * 4;
     const uint64_t carry = dropin_nbuf ? MODES_CARRY_BYTES : 0;
     const uint64_t stream0 = dropin_nbuf * (uint64_t)MODES_DATA_LEN - carry;
@@ -79,6 +266,14 @@ static void modesGpuResolve(void) {
      * (Frames that arrive over the raw TCP input port go through the reference's own decodeModesMessage and its own
      * Modes.icao_cache - a second whitelist; INTEGRATION.md says what that means.) */
     modes_host_set_time(dropin_host, (int64_t)time(NULL));
+    if (dropin_batched) {                                                /* the batch before the one the GPU works on, then - at the end - that one */
+        if (dropin_have[0])
+            modes_host_resolve(dropin_host, dropin_res.records, dropin_res.n_records, dropin_res.candidates, dropin_res.n_candidates,
+                               dropin_sink, NULL);
+        if (dropin_have[1])
+            modes_host_resolve(dropin_host, dropin_res_last.records, dropin_res_last.n_records, dropin_res_last.candidates,
+                               dropin_res_last.n_candidates, dropin_sink, NULL);
+    } else
     modes_host_resolve(dropin_host, dropin_res.records, dropin_res.n_records, dropin_res.candidates,
                        dropin_res.n_candidates, dropin_sink, NULL);
     modes_host_get_stats(dropin_host, &st);

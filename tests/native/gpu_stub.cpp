@@ -105,6 +105,12 @@ int modes_gpu_fetch(modes_gpu *g, modes_gpu_result *res) {
     return MODES_OK;
 }
 
+int modes_gpu_demod_host(modes_gpu *g, const uint8_t *iq, uint64_t nbytes, uint64_t byte0, uint64_t first_block, uint64_t nblocks,
+                         modes_gpu_result *res) {
+    const int rc = modes_gpu_submit_host(g, iq, nbytes, byte0, first_block, nblocks);
+    return rc != MODES_OK ? rc : modes_gpu_fetch(g, res);
+}
+
 // --ranks: the caller's list and length (with tests/native/gather_stub.cpp: cells of a shared-memory segment)
 int modes_gpu_set_output(modes_gpu *g, void *d_records, uint64_t capacity, void *d_count) {
     g->out_records = static_cast<modes_record *>(d_records);

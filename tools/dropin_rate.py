@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
-"""What the PATCHED REFERENCE (oracle/_ref/dump1090_dropin: the reference's own main(), reader thread and sink on the two
-libraries, one 256 KiB buffer per GPU call) makes of 1 GiB of the headline noise, next to the unmodified reference and to the
-C++ host on the same file.  Prints one JSON line."""
+"""What the PATCHED REFERENCE makes of a file of the headline noise in /dev/shm, next to the unmodified reference and to the C++
+host on the same file - whole processes, wall clock, `--raw --no-fix > /dev/null`:
+
+    reference                   oracle/_ref/dump1090_ref            (first GiB only: ~2.5 s per GiB)
+    patched_reference           oracle/_ref/dump1090_dropin         integration/dump1090_gfx950.patch: one 256 KiB buffer per GPU call (first GiB)
+    patched_reference_batched   oracle/_ref/dump1090_dropin_batched integration/dump1090_gfx950_batched.patch: K buffers per hand-off,
+                                                                    K = 64, 512 (default), 2048
+    cxx_host                    dump1090_amd/bin/dump1090_amd
+
+    python tools/dropin_rate.py [GiB]        (default 8)           prints one JSON line"""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
@@ -9,27 +16,46 @@ import torch
 import oracle as orc
 from dump1090_amd import Demodulator
 
-path = "/dev/shm/modes_dropin_1g.bin"
+gib = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+path, one = "/dev/shm/modes_dropin.bin", "/dev/shm/modes_dropin_1g.bin"
 d = Demodulator(fix=False)
-iq = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:0")
-d.synth_noise(iq, 0, seed=20260922, sigma_q16=941)
-d.fill(iq[-480:], 127)
-iq.cpu().numpy().tofile(path)
+with open(path, "wb") as f:
+    for k in range(gib):
+        iq = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:0")
+        d.synth_noise(iq, k << 30, seed=20260922, sigma_q16=941)
+        if k == gib - 1:
+            d.fill(iq[-480:], 127)
+        a = iq.cpu().numpy()
+        a.tofile(f)
+        if k == 0:
+            b = a.copy(); b[-480:] = 127; b.tofile(one)
 d.close()
 del iq
+torch.cuda.empty_cache()
 env = dict(os.environ, LD_PRELOAD=orc.FIXED_TIME)
-out = {"file_mib": 1024}
-for name, exe in (("reference", orc.REF_BIN), ("patched_reference", os.path.join(ROOT, "oracle", "_ref", "dump1090_dropin")),
-                  ("cxx_host", os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd"))):
+out = {"file_gib": gib}
+
+
+def rate(name, exe, file, nbytes, runs, extra_env=None):
     if not os.path.exists(exe):
-        continue
+        return
     best, lines = 1e9, 0
-    for _ in range(2 if name == "reference" else 4):
+    e = dict(env if "dump1090_amd/bin" not in exe else os.environ, **(extra_env or {}))
+    for _ in range(runs):
         t0 = time.perf_counter()
-        p = subprocess.run([exe, "--ifile", path, "--raw", "--no-fix"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                           env=env if name != "cxx_host" else os.environ, check=True)
+        p = subprocess.run([exe, "--ifile", file, "--raw", "--no-fix"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=e, check=True)
         best = min(best, time.perf_counter() - t0)
         lines = p.stdout.count(b"\n")
-    out[name] = {"seconds": round(best, 3), "Msamples_per_s": round((1 << 29) / best / 1e6, 1), "lines": lines}
+    out[name] = {"seconds": round(best, 3), "Msamples_per_s": round(nbytes / 2 / best / 1e6, 1), "GB_per_s": round(nbytes / best / 1e9, 2),
+                 "lines": lines, "file_gib": nbytes >> 30}
+
+
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+rate("reference", orc.REF_BIN, one, 1 << 30, 1)
+rate("patched_reference", os.path.join(REFDIR, "dump1090_dropin"), one, 1 << 30, 2)
+for k in (64, 512, 2048):
+    rate("patched_reference_batched_k%d" % k, os.path.join(REFDIR, "dump1090_dropin_batched"), path, gib << 30, 4, {"MODES_DROPIN_BLOCKS": str(k)})
+rate("cxx_host", os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd"), path, gib << 30, 4)
 os.remove(path)
+os.remove(one)
 print(json.dumps(out))

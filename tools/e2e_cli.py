@@ -38,7 +38,8 @@ def run(extra, mode="--raw"):
         if ln.startswith("{"):
             tim = json.loads(ln)
     return {"args": " ".join([mode] + extra), "wall_s": round(dt, 3), "wall_GBps": round(gib * 2**30 / dt / 1e9, 2),
-            "stream_s": tim.get("stream_s"), "stream_GBps": tim.get("stream_GBps"), "init_s": tim.get("init_s"),
+            "stream_s": tim.get("stream_s"), "stream_GBps": tim.get("stream_GBps"), "init_s": tim.get("init_s"), "total_s": tim.get("total_s"),
+            "init": tim.get("init"), "teardown": tim.get("teardown"), "create_trace": [ln for ln in p.stderr.decode().splitlines() if ln.startswith("modes_gpu_create:")][:1],
             "stdout_bytes": len(p.stdout)}
 
 

@@ -1,18 +1,28 @@
 #!/bin/bash
-# rocprofv3 recipe for the bench workload (run on the GPU box from the repo root):
-#   tools/profile.sh <tag>      -> gpurun_out/prof_<tag>/{kt,pmc1,pmc2,fetch,write}/...
+# rocprofv3 recipe for the bench workloads (run on the GPU box from the repo root):
+#   tools/profile.sh <tag> [workload [extra bench.py arguments]]   workload: noise (default) | lowsnr | frames
+#   -> gpurun_out/prof_<tag>/{kt,pmc1,pmc2,fetch,write}/... + summary.txt (+ traffic.json)
 # Kernel-trace + stats in one run; counters in their own runs (never with --sys-trace etc.).
 set -u
 TAG=${1:-r01}
 shift || true
-EXTRA="$*"            # extra bench.py arguments, e.g. --scan-variant 2
+WL=${1:-noise}
+shift || true
+EXTRA="$*"            # extra bench.py arguments, e.g. --demod-variant 2
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --workload noise --no-end-to-end --no-live-traffic --steps 300 --warmup 2 --no-cpu-baseline --depth 4 --streams 1 --time-every 8 $EXTRA"   # the headline leg of the default `python bench.py`   # the timed region dominates the --stats average
-SHORT="python $R/bench.py --workload noise --no-end-to-end --no-live-traffic --settle 20 --steps 3 --warmup 1 --no-cpu-baseline --depth 1 --streams 1 --time-every 100000 $EXTRA"
+case $WL in
+  noise)  STEPS=300; SETTLE=80 ;;       # 1 GiB steps
+  lowsnr) STEPS=200; SETTLE=80 ;;       # 1 GiB steps
+  frames) STEPS=40;  SETTLE=80 ;;       # 8 GiB steps (bench.py turns --settle into ceil(80 / 8) = 10 of them)
+  *) echo "workload $WL?"; exit 2 ;;
+esac
+COMMON="--workload $WL --no-end-to-end --no-live-traffic --no-cpu-baseline --no-ceiling --streams 1 --leg-streams 1"
+BENCH="python $R/bench.py $COMMON --steps $STEPS --warmup 2 --settle $SETTLE --depth 4 --time-every 8 $EXTRA"   # the timed region dominates the --stats average
+SHORT="python $R/bench.py $COMMON --settle 20 --steps 3 --warmup 1 --depth 1 --time-every 100000 $EXTRA"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -f csv -- $BENCH > "$OUT/kt.log" 2>&1
 echo "kt rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY \
@@ -26,7 +36,10 @@ echo "fetch rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o write -f csv -- $SHORT > "$OUT/write.log" 2>&1
 echo "write rc=$?"
 cd "$R"
-python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+# launches in front of the timed region: the leg's settle steps (ceil(SETTLE / GiB per step), at least 6) + warmup... bench.py's
+# noise leg adds its warmup to --settle; the other legs settle max(6, ceil(settle / GiB)) steps of `calls` launches each
+case $WL in noise) SKIP=$((SETTLE + 2)) ;; lowsnr) SKIP=$SETTLE ;; frames) SKIP=20 ;; esac
+python tools/summarize_prof.py "$OUT" $SKIP > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 # keep the merge-back small: raw per-dispatch CSVs of the counter runs can be large
 find "$OUT" -name "*.csv" -size +4M -delete

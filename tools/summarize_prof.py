@@ -8,6 +8,8 @@ from collections import defaultdict
 trace_avg_us = {}
 
 out = sys.argv[1]
+HOT = ("scan_kernel", "demod_kernel", "select_kernel", "record_kernel", "finalize2_kernel", "finalize_kernel", "order_kernel")
+SKIP = int(sys.argv[2]) if len(sys.argv) > 2 else 82       # launches in front of the timed region (bench.py: settle + warmup)
 
 
 def find(pattern):
@@ -15,8 +17,8 @@ def find(pattern):
 
 
 def short(name):
-    for k in ("scan_fused_kernel", "scan_kernel", "demod_kernel", "finalize_kernel", "order_kernel", "prefix_kernel", "compact_candidates", "synth_noise", "fill_kernel",
-              "magnitude_kernel", "power_kernel"):
+    for k in ("scan_kernel", "demod_kernel", "select_kernel", "record_kernel", "finalize2_kernel", "finalize_kernel", "order_kernel",
+              "prefix_kernel", "compact_candidates", "synth_noise", "fill_kernel", "magnitude_kernel", "power_kernel", "stream_read_kernel"):
         if k in name:
             return k
     return name[:60]
@@ -47,8 +49,8 @@ for f in find("*kernel_trace.csv"):
         v.sort()
         print("  %-24s n=%4d  median %9.1f us  min %9.1f  max %9.1f   vgpr/agpr/sgpr/lds/scratch/wg/grid=%s" % (
             n, len(v), v[len(v) // 2] / 1e3, v[0] / 1e3, v[-1] / 1e3, meta[n]))
-        if n in order and len(order[n]) > 92:
-            tail = order[n][82:]                        # bench.py's timed steps (after its 80 settle + 2 warmup steps)
+        if n in order and len(order[n]) > SKIP + 10:
+            tail = order[n][SKIP:]                      # bench.py's timed steps (after its settle + warmup steps)
             print("  %-24s the %d launches of the timed region: avg %9.1f us" % (n, len(tail), sum(tail) / len(tail) / 1e3))
             trace_avg_us[n] = sum(tail) / len(tail) / 1e3
     kt_log = os.path.join(out, "kt.log")
@@ -66,7 +68,7 @@ for f in find("*counter_collection.csv"):
         agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     print("== counters (%s): mean per dispatch" % os.path.relpath(f, out))
     for k, cs in agg.items():
-        if k not in ("scan_fused_kernel", "scan_kernel", "demod_kernel", "finalize_kernel", "order_kernel"):
+        if k not in HOT:
             continue
         print("  %s" % k)
         for c, v in cs.items():
@@ -81,7 +83,7 @@ for f in find("*counter_collection.csv"):
     agg = defaultdict(lambda: defaultdict(list))
     for row in csv.DictReader(open(f)):
         agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    for k in ("scan_kernel", "demod_kernel"):
+    for k in HOT:
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if c in agg.get(k, {}):
                 v = agg[k][c]
