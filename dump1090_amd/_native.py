@@ -130,12 +130,12 @@ HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_set_time"
 
 GATHER_SYMBOLS = ("modes_gather_unique_id", "modes_gather_create", "modes_gather_destroy", "modes_gather_last_error",
                   "modes_gather_output", "modes_gather_set_empty", "modes_gather_counts", "modes_gather_records", "modes_gather_wait",
-                  "modes_gather_get_stats", "modes_gather_abi_version")
+                  "modes_gather_get_stats", "modes_gather_abi_version", "modes_gather_set_candidates", "modes_gather_candidates")
 
 
 class GatherConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32), ("cap_records", C.c_uint32),
-                ("nslots", C.c_uint32), ("reserved", C.c_uint32)]
+                ("nslots", C.c_uint32), ("cap_candidates", C.c_uint32)]
 
 
 class GatherStats(C.Structure):

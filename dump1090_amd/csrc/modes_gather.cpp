@@ -31,9 +31,15 @@ namespace {
 
 struct Slot {
     uint8_t *d_records = nullptr;              // root: room for every rank's list (two lists in a group of one); others: their own
-    unsigned long long *d_count = nullptr;     // this rank's length (written by finalize_kernel)
-    unsigned long long *d_all = nullptr;       // [nranks]
+    unsigned long long *d_count = nullptr;     // [2]: this rank's lengths - records (written by finalize_kernel), preamble positions
+    unsigned long long *d_all = nullptr;       // [2 * nranks]
     unsigned long long *h_all = nullptr;       // pinned
+    unsigned long long *d_cands = nullptr;     // the second list (cap_candidates > 0): root: every rank's; others: their own
+    unsigned long long *h_cands = nullptr;     // pinned, root only: the concatenation
+    unsigned long long *h_stage = nullptr;     // pinned: this rank's list on its way to d_cands ([cap_candidates]) and, behind it, its length
+    std::vector<uint64_t> ccounts;             // candidate lengths of the call whose transfers were queued
+    uint64_t ctotal = 0;
+    bool cands_set = false;
     uint8_t *h_records = nullptr;              // pinned, root only
     hipEvent_t ev_c0 = nullptr, ev_counts = nullptr, ev_r0 = nullptr, ev_records = nullptr;
     std::vector<uint64_t> counts;              // lengths of the call whose records were queued
@@ -119,10 +125,17 @@ int modes_gather_create(const modes_gather_config *cfg, const void *id, modes_ga
     g->slots.resize(g->cfg.nslots);
     for (Slot &s : g->slots) {
         CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_records), own * lists));
-        CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_count), sizeof(unsigned long long)));
-        CREATE_HIP(hipMemset(s.d_count, 0, sizeof(unsigned long long)));
-        CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_all), sizeof(unsigned long long) * (size_t)cfg->nranks));
-        CREATE_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_all), sizeof(unsigned long long) * (size_t)cfg->nranks, hipHostMallocDefault));
+        CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_count), 2 * sizeof(unsigned long long)));
+        CREATE_HIP(hipMemset(s.d_count, 0, 2 * sizeof(unsigned long long)));
+        CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_all), 2 * sizeof(unsigned long long) * (size_t)cfg->nranks));
+        CREATE_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_all), 2 * sizeof(unsigned long long) * (size_t)cfg->nranks, hipHostMallocDefault));
+        if (cfg->cap_candidates) {
+            const size_t cown = (size_t)cfg->cap_candidates * sizeof(unsigned long long);
+            CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_cands), cown * (root ? (size_t)cfg->nranks : 1)));
+            if (root) CREATE_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_cands), cown * (size_t)cfg->nranks, hipHostMallocDefault));
+            CREATE_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_stage), cown + sizeof(unsigned long long), hipHostMallocDefault));
+        }
+        s.ccounts.assign((size_t)cfg->nranks, 0);
         if (root) CREATE_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_records), own * lists, hipHostMallocDefault));
         CREATE_HIP(hipEventCreate(&s.ev_c0));
         CREATE_HIP(hipEventCreate(&s.ev_counts));
@@ -148,6 +161,9 @@ void modes_gather_destroy(modes_gather *g) {
         if (s.d_all) (void)hipFree(s.d_all);
         if (s.h_all) (void)hipHostFree(s.h_all);
         if (s.h_records) (void)hipHostFree(s.h_records);
+        if (s.d_cands) (void)hipFree(s.d_cands);
+        if (s.h_cands) (void)hipHostFree(s.h_cands);
+        if (s.h_stage) (void)hipHostFree(s.h_stage);
         for (hipEvent_t e : {s.ev_c0, s.ev_counts, s.ev_r0, s.ev_records})
             if (e) (void)hipEventDestroy(e);
     }
@@ -171,7 +187,28 @@ int modes_gather_set_empty(modes_gather *g, uint32_t slot) {
     Slot *s = slot_of(g, slot);
     if (!s) return g ? fail(g, MODES_ERR_ARG, "set_empty: slot %u of %zu", slot, g->slots.size()) : MODES_ERR_ARG;
     HIP_TRY(g, hipSetDevice(g->cfg.device));
-    HIP_TRY(g, hipMemsetAsync(s->d_count, 0, sizeof(unsigned long long), g->stream));
+    HIP_TRY(g, hipMemsetAsync(s->d_count, 0, sizeof(unsigned long long), g->stream));      // (the second length is reset by every counts)
+    return MODES_OK;
+}
+
+int modes_gather_set_candidates(modes_gather *g, uint32_t slot, const uint64_t *candidates, uint64_t n) {
+    Slot *s = slot_of(g, slot);
+    if (!s) return g ? fail(g, MODES_ERR_ARG, "set_candidates: slot %u of %zu", slot, g->slots.size()) : MODES_ERR_ARG;
+    if (!g->cfg.cap_candidates) return fail(g, MODES_ERR_ARG, "set_candidates: the communicator was made without a second list (cap_candidates = 0)");
+    if (n && !candidates) return fail(g, MODES_ERR_ARG, "set_candidates: null list");
+    if (s->counts_queued) return fail(g, MODES_ERR_STATE, "set_candidates: slot %u has an exchange in flight", slot);
+    HIP_TRY(g, hipSetDevice(g->cfg.device));
+    // (the staging buffer is free: the slot's previous exchange - which its H2D copy preceded on the gather's stream - has been
+    // waited for, or this call would have returned MODES_ERR_STATE)
+    unsigned long long *h_n = s->h_stage + g->cfg.cap_candidates;
+    *h_n = n;                                                                // the TRUE length travels, whatever fits (every rank then fails together)
+    const uint64_t fit = n < g->cfg.cap_candidates ? n : g->cfg.cap_candidates;
+    if (fit) {
+        memcpy(s->h_stage, candidates, (size_t)fit * sizeof(uint64_t));
+        HIP_TRY(g, hipMemcpyAsync(s->d_cands, s->h_stage, (size_t)fit * sizeof(uint64_t), hipMemcpyHostToDevice, g->stream));
+    }
+    HIP_TRY(g, hipMemcpyAsync(s->d_count + 1, h_n, sizeof(unsigned long long), hipMemcpyHostToDevice, g->stream));
+    s->cands_set = true;
     return MODES_OK;
 }
 
@@ -181,8 +218,10 @@ int modes_gather_counts(modes_gather *g, uint32_t slot) {
     if (s->counts_queued) return fail(g, MODES_ERR_STATE, "counts: slot %u already has an exchange in flight (wait for it first)", slot);
     HIP_TRY(g, hipSetDevice(g->cfg.device));
     HIP_TRY(g, hipEventRecord(s->ev_c0, g->stream));
-    NCCL_TRY(g, ncclAllGather(s->d_count, s->d_all, 1, ncclUint64, g->comm, g->stream));
-    HIP_TRY(g, hipMemcpyAsync(s->h_all, s->d_all, sizeof(unsigned long long) * (size_t)g->cfg.nranks, hipMemcpyDeviceToHost, g->stream));
+    if (!s->cands_set) HIP_TRY(g, hipMemsetAsync(s->d_count + 1, 0, sizeof(unsigned long long), g->stream));   // no second list in this round
+    s->cands_set = false;
+    NCCL_TRY(g, ncclAllGather(s->d_count, s->d_all, 2, ncclUint64, g->comm, g->stream));                       // (records, preamble positions) per rank
+    HIP_TRY(g, hipMemcpyAsync(s->h_all, s->d_all, 2 * sizeof(unsigned long long) * (size_t)g->cfg.nranks, hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(g, hipEventRecord(s->ev_counts, g->stream));
     s->counts_queued = true;
     s->records_queued = false;
@@ -196,14 +235,20 @@ int modes_gather_records(modes_gather *g, uint32_t slot) {
     HIP_TRY(g, hipSetDevice(g->cfg.device));
     HIP_TRY(g, hipEventSynchronize(s->ev_counts));                           // the step's one synchronisation
     const int n = g->cfg.nranks, me = g->cfg.rank;
-    s->total = 0;
+    s->total = s->ctotal = 0;
     for (int r = 0; r < n; r++) {
-        s->counts[(size_t)r] = s->h_all[r];
-        s->total += s->h_all[r];
-        if (s->h_all[r] > g->cfg.cap_records) {                              // every rank sees the same lengths: all fail together
+        const unsigned long long nrec = s->h_all[2 * r], ncand = s->h_all[2 * r + 1];
+        s->counts[(size_t)r] = nrec;
+        s->ccounts[(size_t)r] = ncand;
+        s->total += nrec;
+        s->ctotal += ncand;
+        if (nrec > g->cfg.cap_records) {                                     // every rank sees the same lengths: all fail together
             s->counts_queued = false;
-            return fail(g, MODES_ERR_OVERFLOW, "rank %d produced %llu records, the gather buffers hold %u per rank", r,
-                        (unsigned long long)s->h_all[r], g->cfg.cap_records);
+            return fail(g, MODES_ERR_OVERFLOW, "rank %d produced %llu records, the gather buffers hold %u per rank", r, nrec, g->cfg.cap_records);
+        }
+        if (ncand > g->cfg.cap_candidates) {
+            s->counts_queued = false;
+            return fail(g, MODES_ERR_OVERFLOW, "rank %d found %llu preamble positions, the gather buffers hold %u per rank", r, ncand, g->cfg.cap_candidates);
         }
     }
     const size_t rec = sizeof(modes_record);
@@ -226,6 +271,15 @@ int modes_gather_records(modes_gather *g, uint32_t slot) {
             rx += nb;
             ops++;
         }
+        size_t coff = (size_t)s->ccounts[0];                                 // the second list: the same pattern, 8-byte elements
+        for (int r = 1; r < n; r++) {
+            const size_t ne = (size_t)s->ccounts[(size_t)r];
+            if (ne == 0) continue;
+            NCCL_TRY(g, ncclRecv(s->d_cands + coff, ne, ncclUint64, r, g->comm, g->stream));
+            coff += ne;
+            rx += ne * sizeof(uint64_t);
+            ops++;
+        }
         if (n == 1 && s->counts[0]) {                                        // loopback: the same calls on the one GPU there is
             const size_t nb = (size_t)s->counts[0] * rec, half = (size_t)g->cfg.cap_records * rec;
             NCCL_TRY(g, ncclRecv(s->d_records + half, nb, ncclUint8, 0, g->comm, g->stream));
@@ -235,11 +289,18 @@ int modes_gather_records(modes_gather *g, uint32_t slot) {
             ops += 2;
             s->loopback = true;
         }
-    } else if (s->counts[(size_t)me]) {
-        const size_t nb = (size_t)s->counts[(size_t)me] * rec;
-        NCCL_TRY(g, ncclSend(s->d_records, nb, ncclUint8, 0, g->comm, g->stream));
-        tx += nb;
-        ops++;
+    } else {
+        if (s->counts[(size_t)me]) {
+            const size_t nb = (size_t)s->counts[(size_t)me] * rec;
+            NCCL_TRY(g, ncclSend(s->d_records, nb, ncclUint8, 0, g->comm, g->stream));
+            tx += nb;
+            ops++;
+        }
+        if (s->ccounts[(size_t)me]) {
+            NCCL_TRY(g, ncclSend(s->d_cands, (size_t)s->ccounts[(size_t)me], ncclUint64, 0, g->comm, g->stream));
+            tx += (size_t)s->ccounts[(size_t)me] * sizeof(uint64_t);
+            ops++;
+        }
     }
     group.open = false;
     NCCL_TRY(g, ncclGroupEnd());
@@ -250,6 +311,8 @@ int modes_gather_records(modes_gather *g, uint32_t slot) {
             HIP_TRY(g, hipMemcpyAsync(s->h_records + half, s->d_records + half, (size_t)s->counts[0] * rec, hipMemcpyDeviceToHost, g->stream));
         }
     }
+    if (me == 0 && s->ctotal)
+        HIP_TRY(g, hipMemcpyAsync(s->h_cands, s->d_cands, (size_t)s->ctotal * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(g, hipEventRecord(s->ev_records, g->stream));
     s->records_queued = true;
     g->st.calls++;
@@ -279,6 +342,16 @@ int modes_gather_wait(modes_gather *g, uint32_t slot, const modes_record **recor
     if (records) *records = root && s->total ? reinterpret_cast<const modes_record *>(s->h_records) : nullptr;
     if (n_records) *n_records = root ? s->total : 0;
     if (counts) *counts = s->counts.data();
+    return MODES_OK;
+}
+
+int modes_gather_candidates(modes_gather *g, uint32_t slot, const uint64_t **candidates, uint64_t *n) {
+    Slot *s = slot_of(g, slot);
+    if (!s || !candidates || !n) return g ? fail(g, MODES_ERR_ARG, "candidates: bad slot or null argument") : MODES_ERR_ARG;
+    if (s->counts_queued || s->records_queued) return fail(g, MODES_ERR_STATE, "candidates: wait for slot %u first", slot);
+    const bool root = g->cfg.rank == 0;
+    *candidates = root && s->ctotal ? reinterpret_cast<const uint64_t *>(s->h_cands) : nullptr;
+    *n = root ? s->ctotal : 0;
     return MODES_OK;
 }
 

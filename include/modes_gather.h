@@ -47,7 +47,8 @@ typedef struct {
     int32_t  nranks;
     uint32_t cap_records;   /* records per rank and call the buffers hold (more: MODES_ERR_OVERFLOW on EVERY rank)     */
     uint32_t nslots;        /* calls in flight (sets of buffers); 0 = 3                                                */
-    uint32_t reserved;
+    uint32_t cap_candidates;/* --stats hosts: preamble positions per rank and call the buffers of the SECOND list hold
+                               (modes_gather_set_candidates); 0 = no second list (ABI 1's `reserved`)                   */
 } modes_gather_config;
 
 typedef struct {
@@ -88,7 +89,21 @@ int  modes_gather_wait(modes_gather *g, uint32_t slot, const modes_record **reco
                        const uint64_t **counts);
 int  modes_gather_get_stats(const modes_gather *g, modes_gather_stats *out);
 
-#define MODES_GATHER_ABI 1
+/* The second list, for hosts that print the reference's --stats (dump1090.c:2993-3006): the counters need every preamble
+ * position of the stream on the rank that resolves (dump1090.c:1651 counts preambles whose first noise gate fails, too), so
+ * each rank's positions travel to rank 0 with its records - same length exchange (the all-gather carries both lengths), same
+ * group of exact-size transfers, one more device-to-host copy on rank 0.
+ * modes_gather_set_candidates: this rank's positions of the call in `slot` - framed coordinates, ascending, HOST memory
+ *   (modes_gpu_result.candidates after modes_gpu_fetch_device with keep_candidates; copied before the function returns) - or
+ *   n = 0.  Call it before the slot's modes_gather_counts; without it the slot's second list is empty in that round.
+ *   MODES_ERR_ARG when the communicator was made with cap_candidates == 0, MODES_ERR_OVERFLOW - on every rank, from
+ *   modes_gather_records - when some rank's list exceeds cap_candidates.
+ * modes_gather_candidates: after modes_gather_wait, rank 0: every rank's positions in rank order (host memory, valid until the
+ *   slot's next modes_gather_counts); other ranks: NULL / 0. */
+int  modes_gather_set_candidates(modes_gather *g, uint32_t slot, const uint64_t *candidates, uint64_t n);
+int  modes_gather_candidates(modes_gather *g, uint32_t slot, const uint64_t **candidates, uint64_t *n);
+
+#define MODES_GATHER_ABI 2
 int  modes_gather_abi_version(void);
 
 #ifdef __cplusplus

@@ -28,12 +28,15 @@ struct modes_gather {
     std::string name, err;
     size_t bytes = 0;
     uint8_t *base = nullptr;
+    bool set_flag = false;                        // set_candidates was called since the last counts
     std::vector<std::vector<modes_record>> out;   // root, per slot: the concatenation of the round being waited for
     std::vector<std::vector<uint64_t>> counts;   // per slot
+    std::vector<std::vector<uint64_t>> cands;    // root, per slot: the second list (preamble positions) of the round being waited for
     modes_gather_stats st{};
     Shared *sh() const { return reinterpret_cast<Shared *>(base); }
-    // per (slot, rank): an 8-byte length and cap_records records
-    size_t stride() const { return 64 + (size_t)cfg.cap_records * sizeof(modes_record); }
+    // per (slot, rank): an 8-byte length (+ the second list's at byte 8), cap_records records, cap_candidates positions
+    size_t stride() const { return 64 + (size_t)cfg.cap_records * sizeof(modes_record) + (size_t)cfg.cap_candidates * 8; }
+    uint8_t *cand_cell(uint32_t slot, int rank) const { return cell(slot, rank) + 64 + (size_t)cfg.cap_records * sizeof(modes_record); }
     uint8_t *cell(uint32_t slot, int rank) const { return base + 4096 + ((size_t)slot * (size_t)cfg.nranks + (size_t)rank) * stride(); }
 };
 
@@ -83,6 +86,7 @@ int modes_gather_create(const modes_gather_config *cfg, const void *id, modes_ga
     if (cfg->rank == 0) shm_unlink(g->name.c_str());
     g->counts.assign(g->cfg.nslots, std::vector<uint64_t>((size_t)cfg->nranks, 0));
     g->out.resize(g->cfg.nslots);
+    g->cands.resize(g->cfg.nslots);
     g->st.nranks = cfg->nranks;
     g->st.rank = cfg->rank;
     g->st.rccl_version = 1;
@@ -110,7 +114,19 @@ int modes_gather_set_empty(modes_gather *g, uint32_t slot) {
     return MODES_OK;
 }
 
-int modes_gather_counts(modes_gather *g, uint32_t) {
+int modes_gather_set_candidates(modes_gather *g, uint32_t slot, const uint64_t *candidates, uint64_t n) {
+    if (slot >= g->cfg.nslots || !g->cfg.cap_candidates) { g->err = "set_candidates: no second list"; return MODES_ERR_ARG; }
+    uint8_t *c = g->cell(slot, g->cfg.rank);
+    memcpy(c + 8, &n, 8);                                                    // the true length, whatever fits
+    const uint64_t fit = n < g->cfg.cap_candidates ? n : g->cfg.cap_candidates;
+    if (fit) memcpy(g->cand_cell(slot, g->cfg.rank), candidates, fit * 8);
+    g->set_flag = true;
+    return MODES_OK;
+}
+
+int modes_gather_counts(modes_gather *g, uint32_t slot) {
+    if (!g->set_flag) memset(g->cell(slot, g->cfg.rank) + 8, 0, 8);         // no second list in this round
+    g->set_flag = false;
     pthread_barrier_wait(&g->sh()->barrier);                                 // every rank's list and length are in the segment
     return MODES_OK;
 }
@@ -118,9 +134,11 @@ int modes_gather_counts(modes_gather *g, uint32_t) {
 int modes_gather_records(modes_gather *g, uint32_t slot) {
     uint64_t total = 0;
     std::vector<uint64_t> &cnt = g->counts[slot];
+    std::vector<uint64_t> ccnt((size_t)g->cfg.nranks, 0);
     for (int r = 0; r < g->cfg.nranks; r++) {
         memcpy(&cnt[(size_t)r], g->cell(slot, r), 8);
-        if (cnt[(size_t)r] > g->cfg.cap_records) { g->err = "a list exceeds the gather buffers"; return MODES_ERR_OVERFLOW; }
+        memcpy(&ccnt[(size_t)r], g->cell(slot, r) + 8, 8);
+        if (cnt[(size_t)r] > g->cfg.cap_records || ccnt[(size_t)r] > g->cfg.cap_candidates) { g->err = "a list exceeds the gather buffers"; return MODES_ERR_OVERFLOW; }
         total += cnt[(size_t)r];
     }
     if (g->cfg.rank == 0) {
@@ -131,6 +149,12 @@ int modes_gather_records(modes_gather *g, uint32_t slot) {
             memcpy(out.data() + at, g->cell(slot, r) + 64, cnt[(size_t)r] * sizeof(modes_record));
             at += cnt[(size_t)r];
             if (r) { g->st.p2p_ops += cnt[(size_t)r] ? 1 : 0; g->st.bytes_received += cnt[(size_t)r] * sizeof(modes_record); }
+        }
+        std::vector<uint64_t> &cs = g->cands[slot];
+        cs.clear();
+        for (int r = 0; r < g->cfg.nranks; r++) {
+            const uint64_t *p = reinterpret_cast<const uint64_t *>(g->cand_cell(slot, r));
+            cs.insert(cs.end(), p, p + ccnt[(size_t)r]);
         }
     }
     g->st.calls++;
@@ -143,6 +167,13 @@ int modes_gather_wait(modes_gather *g, uint32_t slot, const modes_record **recor
     if (records) *records = root && !g->out[slot].empty() ? g->out[slot].data() : nullptr;
     if (n_records) *n_records = root ? g->out[slot].size() : 0;
     if (counts) *counts = g->counts[slot].data();
+    return MODES_OK;
+}
+
+int modes_gather_candidates(modes_gather *g, uint32_t slot, const uint64_t **candidates, uint64_t *n) {
+    const bool root = g->cfg.rank == 0;
+    *candidates = root && !g->cands[slot].empty() ? g->cands[slot].data() : nullptr;
+    *n = root ? g->cands[slot].size() : 0;
     return MODES_OK;
 }
 

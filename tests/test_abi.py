@@ -43,7 +43,7 @@ def test_gather_library_exports_header():
     L = N.gather_lib()
     for n in names:
         assert getattr(L, n)
-    assert L.modes_gather_abi_version() == 1
+    assert L.modes_gather_abi_version() == 2
     assert C.sizeof(N.GatherConfig) == 24 and C.sizeof(N.GatherStats) == 56
     # without a device the create fails loudly, with a text
     import torch

@@ -268,6 +268,54 @@ def test_cli_reproduces_reference_stdout(torch_cuda, flags, lines, md5):
     assert p2.stdout == p.stdout
 
 
+def test_cli_loop_and_clean_exit(torch_cuda, tmp_path):
+    """dump1090_amd --loop on the GPU (dump1090.c:488-494): the first 2.5 laps of output over the padded capture are the
+    compiled reference's bytes (oracle/_ref travels with the snapshot), for two batch sizes; --clean-exit (the orderly teardown
+    the default exit skips) prints the plain listing and ends with status 0."""
+    import synth
+    exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
+    pad = tmp_path / "pad.bin"
+    synth.modes1_padded(os.path.join(ROOT, "tests", "golden", "modes1.bin")).tofile(pad)
+    one = subprocess.run([exe, "--ifile", str(pad), "--raw", "--clean-exit"], capture_output=True, check=True).stdout
+    assert hashlib.md5(one).hexdigest() == "4a81758c8bec5e45ffa8541c5622938a"
+    n = len(one) * 5 // 2
+
+    def laps(cmd, env=None):
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        got = b""
+        try:
+            while len(got) < n:
+                chunk = p.stdout.read(n - len(got))
+                if not chunk:
+                    break
+                got += chunk
+        finally:
+            p.kill()
+            p.wait()
+        return got
+
+    a = laps([exe, "--ifile", str(pad), "--raw", "--loop"])
+    b = laps([exe, "--ifile", str(pad), "--raw", "--loop", "--batch-blocks", "1"])
+    assert len(a) == n and a == b and a[:len(one)] == one
+    if orc.have_ref():
+        ref = laps([orc.REF_BIN, "--ifile", str(pad), "--raw", "--loop"], env=dict(os.environ, LD_PRELOAD=orc.FIXED_TIME))
+        assert ref == a
+
+
+def test_cli_two_ranks_on_two_gpus(torch_cuda, streams, tmp_path):
+    """dump1090_amd --ranks 2 where the box has two GPUs: the lists of two PROCESSES travel over RCCL between two devices -
+    stdout must be the single-process listing (on a one-GPU box the same command must fail fast: next test)."""
+    if torch_cuda.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
+    for case, batch in (("modes1", 1), ("frames", 2)):
+        path = tmp_path / (case + ".bin")
+        streams[case].tofile(path)
+        one = subprocess.run([exe, "--ifile", str(path), "--raw", "--batch-blocks", str(batch)], capture_output=True, check=True)
+        two = subprocess.run([exe, "--ifile", str(path), "--raw", "--batch-blocks", str(batch), "--ranks", "2"], capture_output=True, timeout=300)
+        assert two.returncode == 0 and two.stdout == one.stdout and len(one.stdout) > 0, two.stderr[-600:]
+
+
 @pytest.mark.parametrize("flags,name", [(["--raw"], "default"), (["--raw", "--aggressive"], "aggressive"), (["--raw", "--no-fix"], "nofix"),
                                         (["--onlyaddr"], None), ([], None)])
 def test_cli_one_process_per_gpu_gathers_over_rccl(torch_cuda, golden, streams, tmp_path, flags, name):
@@ -288,6 +336,25 @@ def test_cli_one_process_per_gpu_gathers_over_rccl(torch_cuda, golden, streams, 
         t = json.loads([ln for ln in p.stderr.decode().splitlines() if ln.startswith("{")][-1])
         assert t["ranks"] == 1 and t["rounds"] == streams[case].size // (batch * 262144) + 1
         assert t["rccl"]["p2p_ops"] >= 2 and t["rccl"]["bytes_received"] >= 64 and t["rccl"]["version"] > 20000
+
+
+def test_cli_one_process_per_gpu_prints_the_reference_stats(torch_cuda, streams, tmp_path):
+    """dump1090_amd --ranks 1 --stats: the preamble positions of every batch go through the gather's second list (H2D from the
+    context's sorted host list, the lengths in the same all-gather, D2H on rank 0) - the nine lines of the reference
+    (md5 bc3d1c04...) for several batch sizes, and the same text as the single-process host on a generated stream."""
+    exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
+    raw = os.path.join(ROOT, "tests", "golden", "modes1.bin")
+    for batch in ("1", "2", "512"):
+        p = subprocess.run([exe, "--ifile", raw, "--stats", "--ranks", "1", "--batch-blocks", batch], capture_output=True)
+        assert p.returncode == 0, p.stderr[-600:]
+        assert (p.stdout.count(b"\n"), hashlib.md5(p.stdout).hexdigest()) == (9, "bc3d1c04b24f4989f0fc4a2d1f45abdd"), (batch, p.stdout)
+    path = tmp_path / "frames.bin"
+    streams["frames"].tofile(path)
+    one = subprocess.run([exe, "--ifile", str(path), "--stats", "--batch-blocks", "2"], capture_output=True, check=True).stdout
+    two = subprocess.run([exe, "--ifile", str(path), "--stats", "--batch-blocks", "2", "--ranks", "1"], capture_output=True, check=True).stdout
+    assert one == two and one.count(b"\n") == 9
+    small = subprocess.run([exe, "--ifile", raw, "--stats", "--ranks", "1", "--gather-candidates", "8"], capture_output=True)
+    assert small.returncode == 1 and b"preamble positions" in small.stderr and small.stdout == b""
 
 
 def test_cli_more_ranks_than_gpus_fails_instead_of_hanging(torch_cuda, streams, tmp_path):

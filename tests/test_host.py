@@ -320,4 +320,25 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     assert p.stdout.count(b"fails to start: exit status 1") == 3
     # ... and so does a rank whose GPU call fails mid-stream, with its peer already inside that round's exchange (no teardown of
     # the communicator on that path: ADVICE round 3)
-    assert p.stdout.count(b"fails in GPU call") == 2 and p.stdout.count(b": exit status 1") == 5
+    assert p.stdout.count(b"fails in GPU call") == 2 and p.stdout.count(b": exit status 1") == 6
+    # --stats through the gather's second list (every rank's preamble positions on rank 0): the reference's nine lines for N = 1, 2, 3;
+    # a list that outgrows its buffers fails the job; a pipe / --loop is refused with the alternative named
+    assert p.stdout.count(b"md5 bc3d1c04b24f4989f0fc4a2d1f45abdd") == 6
+    assert b"--stats with 8 positions of room: exit status 1" in p.stdout and b"refused, --gpus named" in p.stdout
+
+
+def test_c_host_loop_replays_the_file_like_the_reference():
+    """tools/sanitize_host.sh loop-host: `dump1090_amd --loop` (dump1090.c:488-494) on the stubbed host - the first 2.5 laps of
+    output are the unmodified reference's bytes (it replays the file into the same buffer, the whitelist carries over),
+    whatever the batch size; and --clean-exit (the orderly teardown the default exit skips) prints the plain listing."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS")}
+    p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "loop-host"], capture_output=True, timeout=600, env=env)
+    assert p.returncode == 0, (p.stdout[-800:], p.stderr[-800:])
+    assert b"first lap = the plain listing" in p.stdout and b"--clean-exit: md5 4a81758c8bec5e45ffa8541c5622938a" in p.stdout
+    if os.path.exists(os.path.join(root, "oracle", "_ref", "dump1090_ref")):
+        assert b"--loop == oracle/_ref/dump1090_ref --loop" in p.stdout

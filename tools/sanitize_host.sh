@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs the CPU tests of the host library and of the header-only device arithmetic against sanitizer builds:
 #   tools/sanitize_host.sh                 UBSan, then ASan, then TSan
-#   tools/sanitize_host.sh ubsan|asan|tsan|tsan-host|ranks-host one of them
+#   tools/sanitize_host.sh ubsan|asan|tsan|tsan-host|ranks-host|loop-host one of them
 # tsan: the multi-threaded resolve (modes_host_resolve_raw_mt: worker pool, speculative pieces) in a C++ harness built
 # together with the host sources under -fsanitize=thread, on the records of the reference's capture.
 # (-fno-sanitize-recover / abort_on_error: any finding kills the test process).  The host library is built with
@@ -101,6 +101,26 @@ run_ranks_host() {
     got=$($D/dump1090_amd_stub --ifile tests/golden/modes1.bin --onlyaddr --ranks 3 --batch-blocks 1 | md5sum | cut -c1-32)
     [ "$got" = bab0f055e262e216208a5cbbdf63fe24 ] || { echo "   --onlyaddr: $got"; exit 1; }
     echo "   --onlyaddr --ranks 3: md5 $got"
+    # --stats: every rank's preamble positions travel to rank 0 as the gather's second list (dump1090.c:2993-3006 needs them all)
+    for n in 1 2 3; do for bb in 1 2; do
+        got=$($D/dump1090_amd_stub --ifile tests/golden/modes1.bin --stats --ranks $n --batch-blocks $bb | md5sum | cut -c1-32)
+        echo "   --stats --ranks $n --batch-blocks $bb: md5 $got"
+        [ "$got" = bc3d1c04b24f4989f0fc4a2d1f45abdd ] || { echo "   expected bc3d1c04b24f4989f0fc4a2d1f45abdd"; exit 1; }
+    done; done
+    # a second list that outgrows its buffers fails every rank together (status 1), it is not truncated
+    set +e
+    timeout 20 $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --stats --ranks 2 --batch-blocks 1 --gather-candidates 8 > /dev/null 2> $D/fail.err
+    rc=$?
+    set -e
+    echo "   --stats with 8 positions of room: exit status $rc"
+    [ "$rc" = 1 ] && grep -q "exceeds the gather buffers\|gather" $D/fail.err || { cat $D/fail.err; exit 1; }
+    # a pipe or --loop has one reader: --ranks says so and names the alternative
+    set +e
+    $D/dump1090_amd_stub --ifile - --raw --ranks 2 < tests/golden/modes1.bin > /dev/null 2> $D/fail.err; rc1=$?
+    $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --loop --raw --ranks 2 > /dev/null 2>> $D/fail.err; rc2=$?
+    set -e
+    [ "$rc1" = 1 ] && [ "$rc2" = 1 ] && [ "$(grep -c 'use --gpus 2' $D/fail.err)" = 2 ] || { cat $D/fail.err; exit 1; }
+    echo "   --ifile - / --loop with --ranks: refused, --gpus named"
     # a rank whose GPU does not come up while its peers already wait in the gather: the job ends with status 1, it does not hang
     # (rank 0's watchdog kills the other ranks; a rank never outlives rank 0)
     for bad in 0 1 2; do
@@ -122,11 +142,49 @@ run_ranks_host() {
         [ "$rc" = 1 ] || { cat $D/fail.err; exit 1; }
     done
 }
+# loop-host: --loop (dump1090.c:488-494: at the end of the file the reader seeks back and keeps filling the SAME buffer - the
+# stream is the file repeated for ever, the whitelist carries over from lap to lap) and --clean-exit, on the stubbed host: the
+# first 2.5 laps' worth of output bytes must be the unmodified reference's (where oracle/_ref/dump1090_ref exists: this
+# container and the GPU box), and in any case start with one lap's listing.
+run_loop_host() {
+    echo "== loop-host =="
+    D=/tmp/modes_loop_host
+    mkdir -p $D
+    gcc -O1 -g -c -o $D/modes_oracle.o oracle/modes_oracle.c
+    g++ -O1 -g -std=c++17 -Iinclude -o $D/dump1090_amd_stub dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+        dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp $D/modes_oracle.o -lpthread -lm -ldl -rdynamic
+    python - <<'PY'
+import sys
+sys.path[:0] = [".", "tests", "oracle"]
+import synth
+synth.modes1_padded("tests/golden/modes1.bin").tofile("/tmp/modes_loop_host/pad.bin")
+PY
+    one=$($D/dump1090_amd_stub --ifile $D/pad.bin --raw --clean-exit | tee $D/one.txt | md5sum | cut -c1-32)
+    echo "   one lap, --clean-exit: md5 $one"
+    [ "$one" = 4a81758c8bec5e45ffa8541c5622938a ] || exit 1
+    n=$(( $(wc -c < $D/one.txt) * 5 / 2 ))
+    set +e
+    for bb in 1 3 512; do
+        timeout 60 $D/dump1090_amd_stub --ifile $D/pad.bin --raw --loop --batch-blocks $bb 2> /dev/null | head -c $n > $D/loop_$bb.txt
+    done
+    set -e
+    head -c $(wc -c < $D/one.txt) $D/loop_1.txt | cmp - $D/one.txt || { echo "   the first lap differs from a plain run"; exit 1; }
+    cmp $D/loop_1.txt $D/loop_3.txt && cmp $D/loop_1.txt $D/loop_512.txt || { echo "   the replay depends on the batch size"; exit 1; }
+    echo "   --loop: $n bytes (2.5 laps), the same for --batch-blocks 1, 3, 512; first lap = the plain listing; md5 $(md5sum < $D/loop_1.txt | cut -c1-32)"
+    if [ -x oracle/_ref/dump1090_ref ]; then
+        set +e
+        LD_PRELOAD=$PWD/oracle/_ref/libfixedtime.so timeout 60 oracle/_ref/dump1090_ref --ifile $D/pad.bin --raw --loop 2> /dev/null | head -c $n > $D/loop_ref.txt
+        set -e
+        cmp $D/loop_1.txt $D/loop_ref.txt || { echo "   --loop differs from the reference's"; exit 1; }
+        echo "   --loop == oracle/_ref/dump1090_ref --loop over the same 2.5 laps"
+    fi
+}
 case "${1:-all}" in
     ubsan) run_one ubsan ;;
     asan)  run_one asan ;;
     tsan)  run_tsan ;;
     tsan-host) run_tsan_host ;;
     ranks-host) run_ranks_host ;;
-    *)     run_one ubsan; run_one asan; run_tsan; run_tsan_host; run_ranks_host ;;
+    loop-host) run_loop_host ;;
+    *)     run_one ubsan; run_one asan; run_tsan; run_tsan_host; run_ranks_host; run_loop_host ;;
 esac
