@@ -313,6 +313,36 @@ def launcher_command(argv, gpus, port=None):
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def visible_gpus():
+    """GPUs this process can use: hipGetDeviceCount through torch (it honours the *_VISIBLE_DEVICES lists and what the container
+    may open).  Called by the parent of a self-launched N-rank run only - the ranks are separate processes."""
+    import torch
+    return torch.cuda.device_count()
+
+
+def ipc_probe(dist, torch, dev, rank, world, seconds=20.0):
+    """The first transfer between two ranks' devices is where a wrong IPC mode or a missing peer-to-peer path shows - as a hang.
+    A 64-byte ring (rank r -> r + 1) right behind init_process_group, watched: when it does not complete in `seconds` the rank
+    says which HSA_ENABLE_IPC_MODE_LEGACY it ran with, leaves $MODES_PROBE_MARK for a self-launched parent (which then starts the
+    job over with the other value) and ends the process - a wrong guess costs seconds, not the lease."""
+    a = torch.full((64,), 0x5a, dtype=torch.uint8, device=dev)
+    b = torch.zeros(64, dtype=torch.uint8, device=dev)
+    ops = [dist.P2POp(dist.isend, a, (rank + 1) % world), dist.P2POp(dist.irecv, b, (rank - 1) % world)]
+    works = dist.batch_isend_irecv(ops)
+    t0 = time.perf_counter()
+    while not all(w.is_completed() for w in works):
+        if time.perf_counter() - t0 > seconds:
+            print("bench.py rank %d of %d: the first 64-byte isend/irecv ring did not complete in %.0f s (HSA_ENABLE_IPC_MODE_LEGACY=%s)" % (
+                rank, world, seconds, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset")), file=sys.stderr, flush=True)
+            mark = os.environ.get("MODES_PROBE_MARK")
+            if mark:
+                open(mark, "w").close()
+            os._exit(75)
+        time.sleep(0.002)
+    torch.cuda.synchronize(dev)
+    assert bool((b == 0x5a).all()), "the probe ring delivered other bytes than were sent"
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,8 +404,25 @@ def parse_args(argv=None):
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # no launcher around us: become one (one process per GPU; rank 0 of the children prints the line)
-        sys.exit(subprocess.call(launcher_command(sys.argv[1:], args.gpus)))
+        # no launcher around us: become one (one process per GPU; rank 0 of the children prints the line).  RCCL wants a device per
+        # rank: say so here, in one line and at once, instead of N ranks failing somewhere inside the rendezvous
+        if args.backend == "nccl":
+            have = visible_gpus()
+            if have < args.gpus:
+                sys.exit("bench.py --gpus %d: %d GPU(s) visible on this box (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); RCCL needs one "
+                         "device per rank (--backend gloo runs the ranks' control flow on fewer)" % (args.gpus, have))
+        # one restart: a rank whose first transfer over the new process group does not complete (ipc_probe) leaves a mark; HSA reads
+        # HSA_ENABLE_IPC_MODE_LEGACY when a process starts, so the other value needs new ranks
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        mark = os.path.join(tempfile.gettempdir(), "modes_ipc_probe_%d" % os.getpid())
+        rc = subprocess.call(launcher_command(sys.argv[1:], args.gpus), env=dict(os.environ, MODES_PROBE_MARK=mark))
+        if rc != 0 and os.path.exists(mark):
+            os.remove(mark)
+            other = "1" if os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" else "0"
+            print("bench.py: the first transfer between the ranks did not complete with HSA_ENABLE_IPC_MODE_LEGACY=%s; starting over with %s" % (
+                os.environ["HSA_ENABLE_IPC_MODE_LEGACY"], other), file=sys.stderr, flush=True)
+            rc = subprocess.call(launcher_command(sys.argv[1:], args.gpus), env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=other))
+        sys.exit(rc)
 
     # stdout carries ONE line: the JSON.  Libraries write there too (RCCL prints a five-line version banner with printf when a
     # communicator is made, flushed at exit): keep the real stdout for the line and give everything else stderr as fd 1.
@@ -411,6 +458,7 @@ def main():
         limit = datetime.timedelta(seconds=180)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
+            ipc_probe(dist, torch, dev, rank, world)           # (a group of one sends to itself: the same calls on a one-GPU box)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=limit)
 
@@ -592,6 +640,11 @@ def main():
             d["listing_check"] = leg["check"]
             if world > 1:
                 d["kernel_ms_per_rank"] = per_rank
+                # a sub-linear step is either a slow rank or rank 0's host half: both are in the line
+                per_step = lambda r: leg["calls_per_step"] * (r["scan"] + r["demod"])
+                d["kernel_ms_per_step_max_rank"] = round(max(per_step(r) for r in per_rank), 4)
+                d["kernel_ms_per_step_min_rank"] = round(min(per_step(r) for r in per_rank), 4)
+                d["rank0_resolve_ms_per_step"] = (leg.get("host_ms_per_call") or {}).get("resolve_per_step")
             if dist_on:
                 d["rccl"] = comm_facts(leg, steps)
                 # a leg with records to gather whose gather moved nothing did not measure the N > 1 path

@@ -69,6 +69,7 @@ struct Options {
     bool clean_exit = false;               // --clean-exit: free everything before returning (default: the process just ends)
     int ranks = 0;                         // --ranks N: one process per GPU, record lists gathered to rank 0 over RCCL
     uint32_t gather_cap = 1u << 18;        // --gather-records: records per rank and round the gather buffers hold
+    char **argv = nullptr;                 // for the one restart --ranks may need (the other IPC mode)
     uint32_t gather_cands = 0;             // --gather-candidates: preamble positions per rank and round (--stats); 0 = positions of a batch / 64
 };
 
@@ -329,6 +330,27 @@ int run_ranks(const Options &opt, double t_start) {
     std::mutex kid_mu;
     std::atomic<bool> watch_stop{false};
     std::thread watchdog;
+    // The communicator's first transfer between two processes' devices is where a wrong IPC mode shows (this pool's hosts only do
+    // dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0 - a guess made on one-GPU boxes).  HSA reads the variable when the runtime starts,
+    // so the other value needs new processes: rank 0 ends its peers and runs the same command line once more with it - a wrong
+    // guess then costs seconds, not the job.  Nothing has been printed by then.  A peer whose probe fails exits with kProbeStatus.
+    constexpr int kProbeStatus = 75;
+    int saved_stdout = -1;                                                   // the real stdout once fd 1 has been given to the libraries
+    auto restart_with_other_ipc_mode = [&]() {                               // rank 0 only; returns only when there is no second try
+        if (N < 2 || getenv("MODES_IPC_RETRIED") || !opt.argv) return;
+        const char *cur = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+        const char *other = (cur && !strcmp(cur, "0")) ? "1" : "0";
+        fprintf(stderr, "--ranks: the first transfer over the new communicator failed with HSA_ENABLE_IPC_MODE_LEGACY=%s; starting over with %s\n",
+                cur ? cur : "unset", other);
+        fflush(stderr);
+        for (size_t i = 0; i < kids.size(); i++) if (kid_status[i] == -1) kill(kids[i], SIGKILL);
+        for (size_t i = 0; i < kids.size(); i++) if (kid_status[i] == -1) { int st; waitpid(kids[i], &st, 0); }
+        setenv("HSA_ENABLE_IPC_MODE_LEGACY", other, 1);
+        setenv("MODES_IPC_RETRIED", "1", 1);
+        if (saved_stdout >= 0) dup2(saved_stdout, 1);
+        execv("/proc/self/exe", opt.argv);
+        perror("--ranks: execv");
+    };
     if (rank == 0 && !kids.empty())
         watchdog = std::thread([&] {
             while (!watch_stop.load()) {
@@ -339,6 +361,7 @@ int run_ranks(const Options &opt, double t_start) {
                         if (kid_status[i] != -1 || waitpid(kids[i], &st, WNOHANG) != kids[i]) continue;
                         kid_status[i] = st;
                         if (WIFEXITED(st) && WEXITSTATUS(st) == 0) continue;
+                        if (WIFEXITED(st) && WEXITSTATUS(st) == kProbeStatus) restart_with_other_ipc_mode();
                         fprintf(stderr, "--ranks: rank %zu ended with status %d%s; stopping the other ranks\n", i + 1,
                                 WIFEXITED(st) ? WEXITSTATUS(st) : WTERMSIG(st), WIFEXITED(st) ? "" : " (signal)");
                         for (size_t j = 0; j < kids.size(); j++) if (kid_status[j] == -1) kill(kids[j], SIGKILL);
@@ -370,7 +393,8 @@ int run_ranks(const Options &opt, double t_start) {
     // RCCL prints a version banner on stdout when a communicator is made: stdout is the message sink of this program, so
     // the library side of the process gets stderr as its stdout and the sink keeps the real one
     fflush(stdout);
-    FILE *out = fdopen(dup(1), "w");
+    saved_stdout = dup(1);
+    FILE *out = saved_stdout >= 0 ? fdopen(saved_stdout, "w") : nullptr;
     if (!out || dup2(2, 1) < 0) { perror("--ranks: stdout"); return finish(1); }
     GatherApi G;
     if (!G.load()) return finish(1);
@@ -399,7 +423,17 @@ int run_ranks(const Options &opt, double t_start) {
     modes_gather_config gc{device, rank, N, opt.gather_cap, (uint32_t)depth, cap_cands};
     modes_gather *g = nullptr;
     const double t_id = now_s();
-    if (G.create(&gc, id, &g) != MODES_OK) { fprintf(stderr, "--ranks: rank %d: %s\n", rank, G.last_error(nullptr)); return finish(1); }
+    if (const int crc = G.create(&gc, id, &g); crc != MODES_OK) {
+        fprintf(stderr, "--ranks: rank %d: %s\n", rank, G.last_error(nullptr));
+        if (crc == MODES_GATHER_ERR_PROBE) {
+            if (rank != 0) { fflush(stderr); _exit(kProbeStatus); }              // rank 0's watchdog takes it from here
+            {
+                std::lock_guard<std::mutex> lk(kid_mu);                          // (not while the watchdog is reaping)
+                restart_with_other_ipc_mode();
+            }
+        }
+        return finish(1);
+    }
     const double t_comm = now_s();
     const size_t batch_bytes = (size_t)opt.batch_blocks * MODES_DATA_LEN;
     std::vector<Lane> lanes((size_t)depth);
@@ -535,6 +569,7 @@ int run_ranks(const Options &opt, double t_start) {
 int main(int argc, char **argv) {
     const double t_start = now_s();
     Options opt;
+    opt.argv = argv;
     int single_device = 0, ngpus = 0;
     for (int j = 1; j < argc; j++) {
         const bool more = j + 1 < argc;

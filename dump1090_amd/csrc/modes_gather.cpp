@@ -16,8 +16,12 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -118,6 +122,44 @@ int modes_gather_create(const modes_gather_config *cfg, const void *id, modes_ga
     {
         ncclResult_t r = ncclCommInitRank(&g->comm, cfg->nranks, u, cfg->rank);
         if (r != ncclSuccess) { fail(g, MODES_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", cfg->rank, cfg->nranks, ncclGetErrorString(r)); return bail(MODES_ERR_HIP); }
+    }
+    {   // the probe: a 64-byte ring over the new communicator, watched - a transfer that never completes is the failure mode of
+        // a wrong IPC mode / a missing P2P path, and nothing else would ever report it
+        double limit = 20.0;
+        if (const char *v = getenv("MODES_GATHER_PROBE_SECONDS")) limit = atof(v);
+        if (limit > 0.0) {
+            uint8_t *d_probe = nullptr;
+            CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&d_probe), 128));
+            CREATE_HIP(hipMemsetAsync(d_probe, 0x5a, 64, g->stream));
+            const int next = (cfg->rank + 1) % cfg->nranks, prev = (cfg->rank + cfg->nranks - 1) % cfg->nranks;
+            ncclResult_t r = ncclGroupStart();
+            if (r == ncclSuccess) r = ncclRecv(d_probe + 64, 64, ncclUint8, prev, g->comm, g->stream);
+            if (r == ncclSuccess) r = ncclSend(d_probe, 64, ncclUint8, next, g->comm, g->stream);
+            const ncclResult_t e = ncclGroupEnd();
+            if (r == ncclSuccess) r = e;
+            hipError_t q = hipErrorNotReady;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (r == ncclSuccess) {
+                q = hipStreamQuery(g->stream);
+                if (q != hipErrorNotReady) break;
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) break;
+                usleep(500);
+            }
+            const char *ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+            if (r != ncclSuccess || q != hipSuccess) {
+                fail(g, MODES_GATHER_ERR_PROBE, "probe: the first 64-byte ncclSend/ncclRecv ring of rank %d of %d %s (%s; HSA_ENABLE_IPC_MODE_LEGACY=%s)",
+                     cfg->rank, cfg->nranks, r != ncclSuccess ? "was refused" : q == hipErrorNotReady ? "did not complete in time" : "failed",
+                     r != ncclSuccess ? ncclGetErrorString(r) : hipGetErrorString(q), ipc ? ipc : "unset");
+                // (no teardown: a communicator with a transfer stuck in it cannot be destroyed; the host ends the process)
+                fail(nullptr, MODES_GATHER_ERR_PROBE, "%s", g->err.c_str());
+                return MODES_GATHER_ERR_PROBE;
+            }
+            uint8_t back[64];
+            CREATE_HIP(hipMemcpy(back, d_probe + 64, 64, hipMemcpyDeviceToHost));
+            (void)hipFree(d_probe);
+            for (uint8_t b : back)
+                if (b != 0x5a) { fail(g, MODES_GATHER_ERR_PROBE, "probe: the ring delivered other bytes than were sent"); return bail(MODES_GATHER_ERR_PROBE); }
+        }
     }
     const bool root = cfg->rank == 0;
     const size_t own = (size_t)cfg->cap_records * sizeof(modes_record);

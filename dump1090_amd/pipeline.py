@@ -31,6 +31,7 @@ class Resolver(threading.Thread):
         self._res = None
         self.submitted = 0              # items handed in (main thread) / worked off completely (resolver thread)
         self.completed = 0
+        self.resolve_s = 0.0            # seconds inside the resolve + formatting of the TIMED steps (this thread)
         self.start()
 
     def submit(self, recs, counts, first_call, last_call, timed, done_event, keep_text=True):
@@ -41,7 +42,10 @@ class Resolver(threading.Thread):
         self.q.put((recs, counts, first_call, last_call, timed, done_event, keep_text))
 
     def _resolve(self, recs, timed, keep):
+        t_a = time.perf_counter()
         n, text = self._res.raw_listing(recs, None, threads=self.threads, text=keep)
+        if timed:
+            self.resolve_s += time.perf_counter() - t_a
         if keep:
             self.step_text.append(text)
         self.step_lines += n
@@ -88,7 +92,10 @@ class Resolver(threading.Thread):
                         # (modes_host_resolve_raw_mtv): with a call per (rank, call) piece rank 0 of an 8-GPU run spent
                         # 16 x 0.5 ms per step here against 2.2 ms of kernels
                         segs = [call[r] for r in range(len(counts)) for call, _ in self._parts]
+                        t_a = time.perf_counter()
                         n, text = self._res.raw_listing_segments(segs, threads=self.threads, text=keep)
+                        if timed:
+                            self.resolve_s += time.perf_counter() - t_a
                         if keep:
                             self.step_text.append(text)
                         self.step_lines += n
@@ -421,6 +428,9 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         if resolver.error is not None:
             raise resolver.error
         out.update(msgs=resolver.msgs, listing=resolver.last_text, lines=resolver.last_lines)
+        # rank 0's host half per STEP (its own thread, next to the launches): the resolve + --raw formatting of everything the
+        # step gathered - what bounds an N-GPU step when it exceeds the kernels' time per rank
+        out["host_ms_per_call"]["resolve_per_step"] = round(resolver.resolve_s / max(1, steps) * 1e3, 4)
         resolver.stop()
     for d in demods:
         d.close()

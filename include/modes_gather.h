@@ -62,9 +62,16 @@ typedef struct {
     double   gather_ms;             /* GPU time of the exchanges on the gather's stream (counts + records), summed      */
 } modes_gather_stats;
 
+/* modes_gather_create only: the communicator came up but its first transfers did not complete - see below */
+#define MODES_GATHER_ERR_PROBE (-6)
+
 /* Rank 0: a fresh id (MODES_GATHER_ID_BYTES bytes).  Every rank passes the same id to modes_gather_create. */
 int  modes_gather_unique_id(void *id);
-/* Collective: returns when all nranks ranks have joined. */
+/* Collective: returns when all nranks ranks have joined AND a 64-byte ncclSend / ncclRecv ring (rank r -> r + 1) has completed on
+ * the new communicator: the first transfer between two devices of two processes is where a wrong IPC mode or a missing
+ * peer-to-peer path shows, and it shows as a hang.  The probe has 20 s ($MODES_GATHER_PROBE_SECONDS; 0 = no probe); when it
+ * runs out the call returns MODES_GATHER_ERR_PROBE and the text names the value of HSA_ENABLE_IPC_MODE_LEGACY the process
+ * ran with - the host's cue to start the job once more with the other one (dump1090_amd --ranks does). */
 int  modes_gather_create(const modes_gather_config *cfg, const void *id, modes_gather **out);
 void modes_gather_destroy(modes_gather *g);
 /* Text of the last error on g (or of the last failed create / unique_id of this thread when g == NULL). */

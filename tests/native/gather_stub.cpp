@@ -52,6 +52,15 @@ int modes_gather_unique_id(void *id) {
 }
 
 int modes_gather_create(const modes_gather_config *cfg, const void *id, modes_gather **out) {
+    // MODES_STUB_PROBE_FAIL=<ranks, comma separated or "all">: the first transfer over the "communicator" never completes on these
+    // ranks - unless this is the host's second try (MODES_IPC_RETRIED), which succeeds: the restart path of dump1090_amd --ranks
+    if (const char *f = getenv("MODES_STUB_PROBE_FAIL"))
+        if (!getenv("MODES_IPC_RETRIED")) {
+            char want[16];
+            snprintf(want, sizeof want, "%d", cfg->rank);
+            if (!strcmp(f, "all") || strstr(f, want)) { usleep(100 * 1000); return MODES_GATHER_ERR_PROBE; }
+            pause();                                                         // the others would wait in the rendezvous for ever
+        }
     modes_gather *g = new modes_gather;
     g->cfg = *cfg;
     if (g->cfg.nslots == 0) g->cfg.nslots = 3;

@@ -120,3 +120,16 @@ def test_bench_measures_the_scan_kernels_hbm_traffic_itself():
     r = parse(p.stdout)["roofline"]
     assert r["traffic_source"].startswith("rocprofv3 --kernel-trace --pmc FETCH_SIZE pass run by this bench.py"), r["traffic_source"]
     assert 0.98 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.08, r
+
+
+def test_more_ranks_than_gpus_is_one_clear_line_at_once():
+    """`python bench.py --gpus N` over RCCL on a box with fewer than N devices: one line on stderr, status != 0, within seconds -
+    not N ranks failing inside the rendezvous (what the first contact with a mis-sized lease would look like)."""
+    import time
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + SMALL, capture_output=True, timeout=120, env=env)
+    assert p.returncode != 0 and time.perf_counter() - t0 < 30
+    assert p.stdout == b"" and b"GPU(s) visible on this box" in p.stderr and p.stderr.count(b"\n") <= 2, p.stderr[-600:]

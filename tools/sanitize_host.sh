@@ -131,6 +131,13 @@ run_ranks_host() {
         echo "   rank $bad fails to start: exit status $rc"
         [ "$rc" = 1 ] || { cat $D/fail.err; exit 1; }
     done
+    # the start-up probe: the first transfer over the new communicator does not complete (on every rank / on one peer only /
+    # on rank 0 only) - rank 0 starts the job over ONCE with the other IPC mode, and that run prints the listing
+    for who in all 1 0; do
+        got=$(MODES_STUB_PROBE_FAIL=$who timeout 60 $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw --ranks 3 --batch-blocks 1 2> $D/probe.err | md5sum | cut -c1-32)
+        echo "   probe fails on rank(s) $who: md5 $got, $(grep -c 'starting over with' $D/probe.err) restart"
+        [ "$got" = 4a81758c8bec5e45ffa8541c5622938a ] && [ "$(grep -c 'starting over with' $D/probe.err)" = 1 ] || { cat $D/probe.err; exit 1; }
+    done
     # a rank that fails MID-STREAM (two ranks, three batches: rank 0's second GPU call / rank 1's only one): the peer is already
     # in that round's exchange, nobody tears an RCCL communicator down on that path (main.cpp run_ranks) - status 1, promptly
     for bad in 0:1 1:0; do
