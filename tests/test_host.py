@@ -315,7 +315,10 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS")}
     p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "ranks-host"], capture_output=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout[-800:], p.stderr[-800:])
-    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 9 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
+    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 12 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
+    # (three of the twelve: the start-up probe of the communicator fails - on every rank, on a peer, on rank 0 - and rank 0 starts the
+    # job over once with the other IPC mode; that second run prints the listing)
+    assert p.stdout.count(b", 1 restart") == 3
     # a rank that fails to start while its peers wait in the gather ends the job (status 1), whichever rank it is
     assert p.stdout.count(b"fails to start: exit status 1") == 3
     # ... and so does a rank whose GPU call fails mid-stream, with its peer already inside that round's exchange (no teardown of
