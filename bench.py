@@ -362,7 +362,6 @@ def parse_args(argv=None):
     ap.add_argument("--strong-steps", type=int, default=8, help="timed steps of the strong-scaling leg (64 GiB each)")
     ap.add_argument("--cpu-mib", type=int, default=1024, help="MiB of the workload timed on the CPU baseline")
     ap.add_argument("--run-chunks", type=int, default=0)
-    ap.add_argument("--scan-variant", type=int, default=0, help="0 = production scan kernel, 1 = fused single-pass scan")
     ap.add_argument("--demod-variant", type=int, default=0, help="modes_gpu_config.demod_variant (include/modes_gfx950.h)")
     ap.add_argument("--depth", type=int, default=0, help="detect calls in flight (contexts used in rotation); default 4, and 6 when "
                                                         "the record lists are gathered (N > 1): that pipeline has two more stages")
@@ -488,7 +487,7 @@ def main():
                 return getattr(self._d, k)
 
         def make():
-            d = Demodulator(device=local, run_chunks=args.run_chunks, scan_variant=args.scan_variant, overlap=args.overlap,
+            d = Demodulator(device=local, run_chunks=args.run_chunks, overlap=args.overlap,
                             demod_variant=args.demod_variant, max_records=cap_records if dist_on else 0, **flags)
             return d if timing else NoTiming(d)
         return run_steps(make, iq, lo, calls, flags, steps, warm, args.depth, world=world, rank=rank, dist=dist,

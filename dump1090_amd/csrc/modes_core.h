@@ -166,67 +166,11 @@ MODES_HD uint32_t modes_power_pair(uint32_t w) {
     return pk_add(pk_mul(ai, ai), pk_mul(aq, aq));            /* v_pk_mul_lo + v_pk_mad      */
 }
 
-/* Scan of 8 consecutive preamble positions against a 24-sample window of
- * powers.  E[t] = (s[2t], s[2t+1]) for window samples 0..23; position i
- * (0..7) looks at window samples i..i+14.  Returns a mask with bit (i>>1) for
- * even i and bit 16+(i>>1) for odd i set when position i MAY be a preamble:
- *
- *   - the ten ordering relations of dump1090.c:1602-1611, exactly (on s), as
- *       s0 > max(s1,s3,s4,s5,s6), s2 > max(s1,s3), s7 > s8, s9 > max(s8,s6)
- *   - a necessary condition for the level tests of dump1090.c:1624-1642:
- *     a quiet sample x in {4,5,11..14} needs m_x < floor((m0+m2+m7+m9)/6) with
- *     m = round(360 sqrt(s)), hence 360 sqrt(s_x) - 1/2 <= (360 SUM sqrt(s_k) + 2)/6 - 1,
- *     i.e. sqrt(s_x) < SUM sqrt(s_k)/6 <= sqrt(SUM s_k)/3 (Cauchy-Schwarz), i.e.
- *     9 s_x < SUM s_k.  With h = s >> 2 (so s <= 4h+3): 9 s_x < 4 SUM h + 12, which
- *     implies s_x <= (SUM h + 4) >> 1.  That last form fits 16-bit packed math.
- *
- * Never rejects a position the reference accepts; the (few) false accepts are
- * removed by modes_preamble_exact in the demod kernel.  ~90 VALU ops per call.
- */
-MODES_HD uint32_t modes_scan8(const uint32_t E[12]) {
-    uint32_t O[11];                                   /* O[t] = (s[2t+1], s[2t+2])  */
-#pragma unroll
-    for (int t = 0; t < 11; t++) O[t] = (E[t] >> 16) | (E[t + 1] << 16);   /* v_alignbit */
-    uint32_t hit = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {                     /* positions i = 2q, 2q+1     */
-        /* X(k) = (s[i+k], s[i+1+k]) : even k -> E[q+k/2], odd k -> O[q+(k-1)/2]   */
-        const uint32_t x0 = E[q], x1 = O[q], x2 = E[q + 1], x3 = O[q + 1], x4 = E[q + 2], x5 = O[q + 2],
-                       x6 = E[q + 3], x7 = O[q + 3], x8 = E[q + 4], x9 = O[q + 4], x11 = O[q + 5],
-                       x12 = E[q + 6], x13 = O[q + 6], x14 = E[q + 7];
-        const uint32_t m13 = pk_max(x1, x3);
-        const uint32_t m45 = pk_max(x4, x5);
-        uint32_t r = pk_subs(x0, pk_max(pk_max(m13, m45), x6));      /* s0 > s1,s3,s4,s5,s6 */
-        r = pk_min(r, pk_subs(x2, m13));                             /* s2 > s1,s3          */
-        r = pk_min(r, pk_subs(x7, x8));                              /* s7 > s8             */
-        r = pk_min(r, pk_subs(x9, pk_max(x8, x6)));                  /* s9 > s8,s6          */
-        /* level bound */
-        const uint32_t sumh = pk_add(pk_add(pk_shr2(x0), pk_shr2(x2)), pk_add(pk_shr2(x7), pk_shr2(x9)));
-        const uint32_t lim1 = pk_shr1(pk_add(sumh, 0x00060006u));    /* ((sumh+4)>>1) + 1   */
-        const uint32_t quiet = pk_max(pk_max(m45, pk_max(x11, x12)), pk_max(x13, x14));
-        r = pk_min(r, pk_subs(lim1, quiet));                         /* quiet <= (sumh+4)>>1 */
-        hit |= pk_min(r, 0x00010001u) << q;
-    }
-    return hit;
-}
-/* The ordering half of modes_scan8 only: r[q] holds, for positions 2q (low half) and 2q+1 (high
- * half), a non-zero value iff the ten relations of dump1090.c:1602-1611 hold.  ~60 VALU ops. */
-MODES_HD void modes_order8(const uint32_t E[12], uint32_t r[4]) {
-    uint32_t O[11];
-#pragma unroll
-    for (int t = 0; t < 11; t++) O[t] = (E[t] >> 16) | (E[t + 1] << 16);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t x0 = E[q], x1 = O[q], x2 = E[q + 1], x3 = O[q + 1], x4 = E[q + 2], x5 = O[q + 2],
-                       x6 = E[q + 3], x7 = O[q + 3], x8 = E[q + 4], x9 = O[q + 4];
-        const uint32_t m13 = pk_max(x1, x3);
-        uint32_t v = pk_subs(x0, pk_max(pk_max(m13, pk_max(x4, x5)), x6));   /* s0 > s1,s3,s4,s5,s6 */
-        v = pk_min(v, pk_subs(x2, m13));                                       /* s2 > s1,s3          */
-        v = pk_min(v, pk_subs(pk_min(x7, x9), x8));                            /* s7 > s8, s9 > s8    */
-        v = pk_min(v, pk_subs(x9, x6));                                        /* s9 > s6             */
-        r[q] = v;
-    }
-}
+/* The level tests of dump1090.c:1624-1642 as a NECESSARY condition on powers (what modes_level_bound evaluates):
+ * a quiet sample x in {4,5,11..14} needs m_x < floor((m0+m2+m7+m9)/6) with m = round(360 sqrt(s)), hence
+ * 360 sqrt(s_x) - 1/2 <= (360 SUM sqrt(s_k) + 2)/6 - 1, i.e. sqrt(s_x) < SUM sqrt(s_k)/6 <= sqrt(SUM s_k)/3
+ * (Cauchy-Schwarz), i.e. 9 s_x < SUM s_k.  It never rejects a position the reference accepts; the false accepts are
+ * removed by modes_preamble_exact in the demodulation kernels. */
 
 /* Saturated powers for the production scan kernel: min(s, 32767).  32768 is attained only by
  * I = Q = 255 and 32767 is not a sum of two squares, so the clamp keeps every ordering relation
@@ -278,7 +222,7 @@ MODES_HD void modes_power8_sat(const uint32_t w[4], uint32_t out[4]) {
 }
 
 /* The ordering relations of dump1090.c:1602-1611 for 8 positions, production form.  Same max/min
- * tree as modes_order8 (packed, half-rate ops), but the four final compares and their conjunction
+ * tree in packed ops (half rate), but the four final compares and their conjunction
  * are plain 32-bit subtracts and ANDs (full-rate ops on gfx950, tools/ubench_valu.hip):
  *     a > b   <=>   bit 15 of (b - a) mod 2^16          for a, b <= 32767.
  * A 32-bit subtract of two packed pairs gives the low half exactly; the high half sees the low
@@ -315,13 +259,11 @@ MODES_HD uint32_t modes_order8_mask(const uint32_t r[4]) {
 
 /* Necessary condition for the level tests of dump1090.c:1624-1642 on powers, in plain integers
  * (the beta pass runs it on one position per lane):  9 * max(quiet) < s0 + s2 + s7 + s9.
- * Derivation in the comment of modes_scan8. */
+ * Derivation above. */
 MODES_HD bool modes_level_bound(uint32_t s0, uint32_t s2, uint32_t s7, uint32_t s9, uint32_t quiet_max) {
     return 9u * quiet_max < s0 + s2 + s7 + s9 + 4u;      /* + 4: the four pulses may be saturated powers (each <= 1 low) */
 }
 
-/* position i of modes_scan8's mask */
-MODES_HD uint32_t modes_scan8_bit(int i) { return 1u << (((i & 1) << 4) + (i >> 1)); }
 #endif /* __clang__ */
 
 /* ----------------------------------------------------------- demodulation */

@@ -20,8 +20,6 @@
 // level tests as a necessary condition in s.  Because the reference's magnitude LUT is
 // strictly monotone in s, the ordering tests are exact on s; everything forwarded
 // (~0.07 % of positions) is re-checked exactly (LUT) by demod_kernel.
-// scan_fused_kernel (scan_variant 1) is the single-pass first version, kept as an
-// independent implementation the tests compare the production kernel with.
 //
 // No MFMA (integer scan: the roofline is HBM, the limiter in practice VALU issue - DESIGN.md 3.1),
 // no CUDA compatibility layer, wave64 only.
@@ -52,7 +50,6 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kChunkSamples = 512;          // one wavefront iteration: 64 lanes x 8 samples
 constexpr int kChunkBytes = 1024;
-constexpr int kScanWaves = 4;               // wavefronts per scan workgroup
 constexpr int kLookback = 16;               // positions of the previous chunk scanned with this one
 
 // ------------------------------------------------------------------------------------
@@ -83,10 +80,6 @@ __device__ __forceinline__ uint4 load_iq16(const uint8_t *iq, int64_t off, int64
         }
     }
     return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
-}
-
-__device__ __forceinline__ uint4 power16(uint4 v) {
-    return make_uint4(modes_power_pair(v.x), modes_power_pair(v.y), modes_power_pair(v.z), modes_power_pair(v.w));
 }
 
 // min(s, 32767): what the production scan kernel works on (modes_core.h)
@@ -277,86 +270,6 @@ struct ScanParams {
     ResultHeader *hdr;
 };
 
-__global__ __launch_bounds__(kScanWaves * kWave) void scan_fused_kernel(ScanParams P) {
-    // wave-private ring: 2 chunk slots x 256 dwords (512 powers each)
-    __shared__ __attribute__((aligned(16))) uint32_t ring_all[kScanWaves][512];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t run = blockIdx.x * kScanWaves + wave;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *P.hdr = ResultHeader{0, 0, {0, 0}};   // demod_kernel reserves record slots in it
-    if (run >= P.nruns) return;
-    uint32_t *ring = ring_all[wave];
-
-    const int64_t c0 = (int64_t)run * P.run_chunks;
-    const int64_t c1 = (c0 + (int64_t)P.run_chunks < (int64_t)P.nchunks) ? c0 + (int64_t)P.run_chunks : (int64_t)P.nchunks;
-    const uint8_t *iq = P.iq;
-    const int64_t lo = P.lo, hi = P.hi;
-
-    // prologue: powers of the last 16 samples of chunk c0-1 (lanes 62, 63)
-    if (lane >= 62) {
-        uint4 s = power16(load_iq16(iq, (c0 - 1) * kChunkBytes + lane * 16, lo, hi));
-        *reinterpret_cast<uint4 *>(&ring[(((c0 - 1) & 1) * 256) + lane * 4]) = s;
-    }
-    // software prefetch, two chunks deep
-    uint4 cur = load_iq16(iq, c0 * kChunkBytes + lane * 16, lo, hi);
-    uint4 nxt = load_iq16(iq, (c0 + 1) * kChunkBytes + lane * 16, lo, hi);
-
-    uint32_t count = 0;
-    uint32_t *my_slots = P.slots + (uint64_t)run * P.slot_cap;
-
-    for (int64_t c = c0; c < c1; c++) {
-        const uint4 raw = cur;
-        cur = nxt;
-        nxt = load_iq16(iq, (c + 2) * kChunkBytes + lane * 16, lo, hi);
-
-        const uint4 s = power16(raw);
-        *reinterpret_cast<uint4 *>(&ring[((c & 1) * 256) + lane * 4]) = s;
-        // LDS operations of one wavefront execute in issue order: the reads below see the
-        // writes above without a barrier; only the compiler must not reorder them.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // window of 24 powers starting at position 512c - 16 + 8*lane (dword index mod 512)
-        const uint32_t d0 = (uint32_t)(((c & 1) * 256) + 512 - 8 + lane * 4) & 511u;
-        uint32_t E[12];
-        {
-            const uint4 a = *reinterpret_cast<const uint4 *>(&ring[d0]);
-            const uint4 b = *reinterpret_cast<const uint4 *>(&ring[(d0 + 4) & 511u]);
-            const uint4 d = *reinterpret_cast<const uint4 *>(&ring[(d0 + 8) & 511u]);
-            E[0] = a.x; E[1] = a.y; E[2] = a.z; E[3] = a.w;
-            E[4] = b.x; E[5] = b.y; E[6] = b.z; E[7] = b.w;
-            E[8] = d.x; E[9] = d.y; E[10] = d.z; E[11] = d.w;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        const uint32_t hit = modes_scan8(E);
-
-        // wavefront compaction, ascending position order
-        uint64_t lanes_hit = __ballot(hit != 0);
-        const int64_t pbase = c * kChunkSamples - kLookback;
-        while (lanes_hit) {
-            const int L = __builtin_ctzll(lanes_hit);
-            lanes_hit &= lanes_hit - 1;
-            const uint32_t m = __builtin_amdgcn_readlane(hit, L);
-            const int64_t p = pbase + 8 * L + lane;               // lanes 0..7 look at one position each
-            bool has = false;
-            if (lane < 8) {
-                has = (m & modes_scan8_bit(lane)) != 0 && p >= P.p_begin && p < P.p_end &&
-                      (((uint64_t)p + P.g0) & (MODES_BLOCK_STRIDE - 1)) < MODES_BLOCK_POSITIONS;   // j < 131070, :1593
-            }
-            const uint64_t hb = __ballot(has);
-            if (has) {
-                const uint32_t idx = count + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1));
-                if (idx < P.slot_cap) my_slots[idx] = (uint32_t)p;
-            }
-            count += (uint32_t)__builtin_popcountll(hb);
-        }
-    }
-    if (lane == 0) P.counts[run] = count;                 // true count; demod_kernel flags count > slot_cap
-}
-
 // ------------------------------------------------------------------------------------
 // demod_kernel parameters
 // ------------------------------------------------------------------------------------
@@ -401,8 +314,7 @@ struct DemodParams {
 };
 
 // ------------------------------------------------------------------------------------
-// scan_kernel (production, scan_variant 0) - same work decomposition as scan_fused_kernel, but
-// split in two passes because the stage is VALU-issue-bound (DESIGN.md 3.1 has the measured
+// scan_kernel - two passes over every chunk, because the stage is VALU-issue-bound (DESIGN.md 3.1 has the measured
 // issue costs: every packed / VOP3 op is half rate on gfx950):
 //
 //   alpha  every position: the ten ORDERING relations (exact on s for even positions, superset
@@ -571,6 +483,17 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
         const uint32_t E[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, s.x, s.y, s.z, s.w};
         uint32_t r[4];
         modes_order8_swar(E, r);
+#if defined(SCAN_ABL_EXTRA)
+        // calibration build (timing only; tools/ab_scan.py): SCAN_ABL_EXTRA more full-rate VALU instructions per chunk, on a
+        // chain that feeds the survivor test so that they cannot be dropped - what one more instruction per chunk costs a
+        // kernel that is VALU-bound (the price list of everything one might still fuse into it)
+        {
+            uint32_t extra = r[0];
+#pragma unroll
+            for (int t = 0; t < SCAN_ABL_EXTRA; t++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(extra) : "v"(E[t % 12]));
+            r[3] |= extra & 1u;                                              // bit 0 is not a flag bit (MODES_ORDER_FLAGS)
+        }
+#endif
 
         // ---- alpha survivors -> queue; beta (level bound) whenever the next push might not fit ----
         const bool any = (((r[0] | r[1]) | (r[2] | r[3])) & MODES_ORDER_FLAGS) != 0;
@@ -2178,6 +2101,11 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
         }
         if (ctx->cfg.demod_variant == 0) ctx->cfg.demod_variant = (uint32_t)n;
     }
+    if (ctx->cfg.scan_variant != 0) {
+        const uint32_t v = ctx->cfg.scan_variant;
+        delete ctx;
+        return fail(nullptr, MODES_ERR_ARG, "scan_variant %u: there is one scan kernel (the single-pass first version was removed in round 4)", v);
+    }
     if (ctx->cfg.demod_variant == 1 || ctx->cfg.demod_variant > 3) {
         const uint32_t v = ctx->cfg.demod_variant;
         delete ctx;
@@ -2499,12 +2427,9 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     ctx->timed = timed;
     hipEvent_t *ek = ctx->ev_k;
     auto ev = [&](int k) -> hipEvent_t { return timed ? ek[k] : nullptr; };
-    const dim3 scan_grid(ctx->cfg.scan_variant == 1 ? (nruns + kScanWaves - 1) / kScanWaves : (nruns + kScan2Waves - 1) / kScan2Waves);
+    const dim3 scan_grid((nruns + kScan2Waves - 1) / kScan2Waves);
     mark(1);
-    if (ctx->cfg.scan_variant == 1)
-        hipExtLaunchKernelGGL(scan_fused_kernel, scan_grid, dim3(kScanWaves * kWave), 0, st, ev(0), ev(1), 0, sp);
-    else
-        hipExtLaunchKernelGGL(scan_kernel, scan_grid, dim3(kScan2Waves * kWave), 0, st, ev(0), ev(1), 0, sp);
+    hipExtLaunchKernelGGL(scan_kernel, scan_grid, dim3(kScan2Waves * kWave), 0, st, ev(0), ev(1), 0, sp);
     mark(2);
     // cfg.overlap == 1: everything after the scan moves to the context's own stream (ordered behind the
     // scan), so the next kernel on the caller's stream - typically another context's scan -

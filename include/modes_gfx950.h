@@ -59,7 +59,7 @@ typedef struct {
     uint32_t run_chunks;       /* tuning: 512-sample chunks per wavefront run, 0=auto */
     uint32_t slot_cap;         /* tuning: forwarded positions per run, 0=auto         */
     uint32_t max_records;      /* record-list capacity; 0 = automatic (starts at 1<<18 and grows)  */
-    uint32_t scan_variant;     /* 0 = production scan kernel; others: see DESIGN.md   */
+    uint32_t scan_variant;     /* must be 0 (1 was the single-pass first version of the scan kernel, removed in round 4: MODES_ERR_ARG) */
     uint32_t overlap;          /* 0: all kernels in order on the caller's stream.  1: only the scan kernel runs
                                   there; the demod and order kernels follow on the context's own stream, so work
                                   the caller queues next (another context's scan) may overlap them.  2: only the

@@ -13,27 +13,6 @@ void shim_mag_exact(const uint32_t *s_sat, uint64_t n, uint32_t *out) {
     for (uint64_t k = 0; k < n; k++) out[k] = modes_mag_exact(s_sat[k]);
 }
 
-// modes_power_pair + modes_scan8 over a whole stream, 8 positions per call, as the
-// scan kernel's lanes do.  flags[p] = 1 if position p is forwarded.
-void shim_scan_stream(const uint8_t *iq, uint64_t nsamples, uint8_t *flags) {
-    auto power2 = [&](uint64_t first) -> uint32_t {   // (s[first], s[first+1]), 127 beyond the end
-        uint8_t b[4] = {127, 127, 127, 127};
-        for (int t = 0; t < 4; t++) {
-            uint64_t off = 2 * first + t;
-            if (off < 2 * nsamples) b[t] = iq[off];
-        }
-        uint32_t w;
-        memcpy(&w, b, 4);
-        return modes_power_pair(w);
-    };
-    for (uint64_t p0 = 0; p0 < nsamples; p0 += 8) {
-        uint32_t E[12];
-        for (int t = 0; t < 12; t++) E[t] = power2(p0 + 2 * t);
-        uint32_t hit = modes_scan8(E);
-        for (int i = 0; i < 8 && p0 + i < nsamples; i++) flags[p0 + i] = (hit & modes_scan8_bit(i)) != 0;
-    }
-}
-
 // modes_power_pair_sat + modes_order8_swar (the production scan kernel's alpha pass) over a stream.
 // flags[p] = 1 if position p survives the ordering test.
 void shim_order_stream(const uint8_t *iq, uint64_t nsamples, uint8_t *flags) {

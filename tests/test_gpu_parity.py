@@ -468,14 +468,16 @@ def test_tuning_parameters_do_not_change_results(torch_cuda, streams):
     data = streams["frames"]
     iq = to_dev(torch_cuda, data)
     base = None
-    for rc, variant in ((0, 0), (1, 0), (3, 0), (16, 0), (64, 0), (0, 1), (5, 1), (64, 1), (2, 0), (7, 0)):
-        d = Demodulator(keep_candidates=True, run_chunks=rc, scan_variant=variant)
+    for rc, dv in ((0, 0), (1, 0), (3, 3), (16, 2), (64, 3), (5, 2), (64, 2), (2, 0), (7, 3)):     # run length x demodulation path
+        d = Demodulator(keep_candidates=True, run_chunks=rc, demod_variant=dv)
         d.detect(iq)
         recs, cands, _ = d.fetch()
         if base is None:
             base = (recs, cands)
-        assert np.array_equal(recs, base[0]) and np.array_equal(cands, base[1]), (rc, variant)
+        assert np.array_equal(recs, base[0]) and np.array_equal(cands, base[1]), (rc, dv)
         d.close()
+    with pytest.raises(ModesError, match="scan_variant 1"):      # the single-pass first version of the scan is gone (round 4)
+        Demodulator(scan_variant=1)
     d = Demodulator(run_chunks=64, slot_cap=1)          # far too few slots: must fail, not drop
     d.detect(iq)
     with pytest.raises(ModesError, match="MODES_ERR_OVERFLOW"):

@@ -33,6 +33,7 @@ for s in "$@"; do
     prof_frames) bash tools/profile.sh ${TAG}_frames frames > "$O/prof_frames.log" 2>&1; tail -n 60 "$O/prof_frames.log" ;;
     e2e)       MODES_GPU_CREATE_TRACE=1 run e2e 600 python tools/e2e_cli.py 8 ;;
     dropin)    run dropin 600 python tools/dropin_rate.py ;;
+    rccl_init) run rccl_init 300 bash tools/rccl_init_time.sh ;;
     *)         echo "unknown step $s" ;;
   esac
 done
