@@ -52,11 +52,21 @@ static struct {                              /* the hand-off, written by the rea
 static int dropin_inflight = -1;             /* context whose batch has been submitted but not fetched                    */
 static modes_gpu_result dropin_res_last;     /* the last batch's records, fetched together with its predecessor's         */
 static int dropin_have[2];                   /* dropin_res / dropin_res_last hold a batch to resolve                      */
+/* $MODES_DROPIN_TIMING: one JSON line on stderr when the last batch has been resolved - how long the GPU start-up took and how
+ * long the stream itself (first read .. last message), which is what a long-running host sees (tools/dropin_rate.py) */
+static double dropin_t0, dropin_t_init, dropin_t_first_read;
+static uint64_t dropin_bytes;
+static double dropin_now(void) {
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec;
+}
 
 /* once, after modesInit() (dump1090.c:2943) */
 static void modesInitGpu(void) {
     modes_gpu_config gc;
     modes_host_config hc;
+    dropin_t0 = dropin_now();
     memset(&gc, 0, sizeof(gc));
     gc.device = 0;
     gc.fix_errors = Modes.fix_errors;
@@ -75,6 +85,7 @@ static void modesInitGpu(void) {
         exit(1);
     }
     dropin_ctx[0] = dropin_gpu;
+    dropin_t_init = dropin_now();
 }
 
 static void dropin_die(const char *what, modes_gpu *g) {
@@ -154,6 +165,7 @@ static void modesGpuReadFile(void) {
     off_t pos = 0;
     int w = 0, last = 0, seekable;
     dropin_setup_batched();
+    dropin_t_first_read = dropin_now();
     seekable = Modes.fd != STDIN_FILENO && !Modes.loop && lseek(Modes.fd, 0, SEEK_CUR) != (off_t)-1;
     pthread_mutex_lock(&Modes.data_mutex);
     while (!last) {
@@ -186,6 +198,7 @@ static void modesGpuReadFile(void) {
             }
         }
         last = got < batch;
+        dropin_bytes += got;
         dropin_hand.which = w;
         dropin_hand.carry = carry;
         dropin_hand.fresh = got;
@@ -270,9 +283,17 @@ static void modesGpuResolve(void) {
         if (dropin_have[0])
             modes_host_resolve(dropin_host, dropin_res.records, dropin_res.n_records, dropin_res.candidates, dropin_res.n_candidates,
                                dropin_sink, NULL);
-        if (dropin_have[1])
+        if (dropin_have[1]) {
             modes_host_resolve(dropin_host, dropin_res_last.records, dropin_res_last.n_records, dropin_res_last.candidates,
                                dropin_res_last.n_candidates, dropin_sink, NULL);
+            if (getenv("MODES_DROPIN_TIMING")) {
+                const double t = dropin_now(), stream = t - dropin_t_first_read;
+                fprintf(stderr, "{\"bytes\": %llu, \"blocks_per_handoff\": %llu, \"gpu_init_s\": %.4f, \"reader_setup_s\": %.4f, \"stream_s\": %.4f, "
+                                "\"stream_GBps\": %.2f, \"stream_Msamples_per_s\": %.1f}\n",
+                        (unsigned long long)dropin_bytes, (unsigned long long)dropin_k, dropin_t_init - dropin_t0, dropin_t_first_read - dropin_t_init,
+                        stream, stream > 0 ? (double)dropin_bytes / stream / 1e9 : 0.0, stream > 0 ? (double)dropin_bytes / 2.0 / stream / 1e6 : 0.0);
+            }
+        }
     } else
     modes_host_resolve(dropin_host, dropin_res.records, dropin_res.n_records, dropin_res.candidates,
                        dropin_res.n_candidates, dropin_sink, NULL);

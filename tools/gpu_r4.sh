@@ -14,6 +14,9 @@ for s in "$@"; do
     smoke)     run smoke 400 python __graft_entry__.py smoke ;;
     parity)    run parity 900 python -m pytest tests/test_gpu_parity.py tests/test_dropin.py -m gpu -q --maxfail=6 -p no:cacheprovider ;;
     parity2)   MODES_GPU_DEMOD_VARIANT=2 run parity2 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --maxfail=6 -p no:cacheprovider ;;
+    forced)    MODES_GPU_DEMOD_VARIANT=2 run pytest_gpu_forced_two_kernel_path 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_dropin.py -m gpu -q -p no:cacheprovider -k "not sixty_four"
+               MODES_GPU_DEMOD_VARIANT=3 run pytest_gpu_forced_one_kernel_path 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_dropin.py -m gpu -q -p no:cacheprovider -k "not sixty_four" ;;
+    fuzz)      run fuzz_parity 900 python tools/fuzz_parity.py 2000 500 ;;
     benchtest) run benchtest 1500 python -m pytest tests/test_gpu_bench.py -m gpu -q --maxfail=6 -p no:cacheprovider ;;
     full8)     run full8 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --maxfail=3 -p no:cacheprovider -k "not sixty_four" ;;
     full)      run full 1500 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --maxfail=3 -p no:cacheprovider ;;
