@@ -356,7 +356,9 @@ def parse_args(argv=None):
     ap.add_argument("--frames-steps", type=int, default=40,
                     help="timed steps of the frames leg (8 GiB each: with 6 the fill and drain of the pipeline were a fifth of the time)")
     ap.add_argument("--lowsnr-mib", type=int, default=1024, help="MiB of I/Q per GPU of the low-SNR leg (configs[4])")
-    ap.add_argument("--lowsnr-steps", type=int, default=40)
+    ap.add_argument("--lowsnr-steps", type=int, default=200,
+                    help="timed steps of the low-SNR leg (1 GiB each: the fill and drain of the four-deep pipeline is ~0.3 ms per timed region - "
+                         "3 %% of 40 steps, 0.6 %% of 200)")
     ap.add_argument("--frames-total-mib", type=int, default=65536,
                     help="MiB of the strong-scaling leg's stream, the same at every N (default: configs[3]'s 64 GiB); 0 = no such leg")
     ap.add_argument("--strong-steps", type=int, default=8, help="timed steps of the strong-scaling leg (64 GiB each)")

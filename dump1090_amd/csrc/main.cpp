@@ -63,7 +63,10 @@ struct Options {
     std::vector<int> devices;              // HIP ordinals, one per "GPU" of the split (the same ordinal may repeat)
     uint64_t batch_blocks = 512;           // 128 MiB of samples per GPU call
     int read_threads = 16;                 // parallel pread() slices for regular files (8 GiB file, 256-core host: 42 GB/s at 8, 45 at 32, 30 at 64)
-    int depth = 3;                         // batches in flight per device (lanes = depth x devices)
+    int depth = 2;                         // batches in flight per device (lanes = depth x devices).  Two: one is read / copied to the GPU while
+                                           // the other one's kernels run and its records are resolved.  A third lane only helps when the resolve of
+                                           // a batch takes longer than reading the next one (message-dense input), and costs 128 MiB more pinned
+                                           // memory whose set-up competes with the first reads: 8 GiB file, whole process 0.57 s against 0.71
     bool use_mmap = true;                  // regular files: copy out of a mapping of the file instead of pread()
     int resolve_threads = 8;               // --raw only: pieces of a batch resolved in parallel (modes_host_resolve_raw_mt)
     bool clean_exit = false;               // --clean-exit: free everything before returning (default: the process just ends)
@@ -100,7 +103,7 @@ void show_help() {
         "--gather-records <n>     With --ranks: records per rank and round the gather buffers hold (default: 262144).\n"
         "--gather-candidates <n>  With --ranks --stats: preamble positions per rank and round (default: a batch's positions / 64).\n"
         "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).\n"
-        "--depth <n>              Batches in flight per device (default: 3).\n"
+        "--depth <n>              Batches in flight per device (default: 2; --ranks: at least 3).\n"
         "--read-threads <n>       Threads reading a regular file (default: 16).\n"
         "--no-mmap                Read a regular file with pread() instead of copying out of a mapping of it.\n"
         "--resolve-threads <n>    With --raw: threads that resolve one batch (default: 8; the listing does not depend on it).\n"

@@ -27,6 +27,7 @@
 #include "modes_gfx950.h"
 #include "modes_host.h"
 #include <stddef.h>
+#include <time.h>
 
 _Static_assert(sizeof(struct modesMessage) == MODES_MESSAGE_SIZE, "struct modesMessage: size differs from libmodes_host's");
 _Static_assert(offsetof(struct modesMessage, flight) == MODES_MESSAGE_OFFSET_FLIGHT, "struct modesMessage: layout");
@@ -56,10 +57,10 @@ static int dropin_have[2];                   /* dropin_res / dropin_res_last hol
  * long the stream itself (first read .. last message), which is what a long-running host sees (tools/dropin_rate.py) */
 static double dropin_t0, dropin_t_init, dropin_t_first_read;
 static uint64_t dropin_bytes;
-static double dropin_now(void) {
-    struct timeval tv;
-    gettimeofday(&tv, NULL);
-    return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec;
+static double dropin_now(void) {                                          /* (monotonic: test runs pin time() and gettimeofday()) */
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
 /* once, after modesInit() (dump1090.c:2943) */
