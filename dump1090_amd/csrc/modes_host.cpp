@@ -76,6 +76,8 @@ struct modes_host {
     int64_t now_s = 0;                    // never advanced by a file run: nothing expires (the default)
     bool have_candidates = false;
     struct IcaoLog *log = nullptr;        // set while a piece of a batch is resolved speculatively (modes_host_resolve_raw_mt)
+    bool lean = false;                    // set by the --raw resolvers: the sink reads msg / msgbits / crcok only, so the decode stops
+                                          // when those (and the whitelist) are settled - no altitude, squawk, position, velocity fields
 };
 
 // What a speculative piece did to / asked of the whitelist: which slots it wrote, and every lookup that was answered from
@@ -179,7 +181,7 @@ void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMess
     static const char ais[] = "?ABCDEFGHIJKLMNOPQRSTUVWXYZ????? ???????????????0123456789??????";
     // The reference leaves the fields a message type does not use uninitialised (mm is a stack
     // variable, :1732); zero them so the struct is a function of the input.
-    memset(mm, 0, sizeof *mm);
+    if (!h->lean) memset(mm, 0, sizeof *mm);                                      // (lean: every field read afterwards is assigned below)
     memcpy(mm->msg, att->msg, MODES_LONG_MSG_BYTES);
     unsigned char *msg = mm->msg;
 
@@ -214,7 +216,7 @@ void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMess
     mm->fs = msg[0] & 7;                                                          // :1145
     mm->dr = msg[1] >> 3 & 31;
     mm->um = ((msg[1] & 7) << 3) | msg[2] >> 5;
-    {   // squawk, :1163-1179 (Gillham interleave C1 A1 C2 A2 C4 A4 0 B1 D1 B2 D2 B4 D4)
+    if (!h->lean) {   // squawk, :1163-1179 (Gillham interleave C1 A1 C2 A2 C4 A4 0 B1 D1 B2 D2 B4 D4)
         const int a = ((msg[3] & 0x80) >> 5) | ((msg[2] & 0x02) >> 0) | ((msg[2] & 0x08) >> 3);
         const int b = ((msg[3] & 0x02) << 1) | ((msg[3] & 0x08) >> 2) | ((msg[3] & 0x20) >> 5);
         const int c = ((msg[2] & 0x01) << 2) | ((msg[2] & 0x04) >> 1) | ((msg[2] & 0x10) >> 4);
@@ -247,6 +249,8 @@ void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMess
         }
     }
 
+    mm->phase_corrected = 0;                                                      // :1309
+    if (h->lean) return;                                                          // crcok, the address and the whitelist are settled
     if (mm->msgtype == 0 || mm->msgtype == 4 || mm->msgtype == 16 || mm->msgtype == 20)   // :1213
         mm->altitude = decode_ac13(msg, &mm->unit);
 
@@ -420,6 +424,8 @@ uint64_t modes_host_resolve_raw(modes_host *h, const modes_record *recs, uint64_
                                 char *out, uint64_t cap, uint64_t *nbytes) {
     RawSink s{h, out, cap, 0, 0};
     if (out && cap) out[0] = 0;                                                   // an empty (or wholly cut) listing is ""
+    struct Lean { modes_host *h; bool was; ~Lean() { h->lean = was; } } lean{h, h->lean};
+    h->lean = true;
     modes_host_resolve(h, recs, nrecs, cands, ncand, raw_sink, &s);
     if (nbytes) *nbytes = s.n;
     return s.msgs;
@@ -533,12 +539,15 @@ void run_piece(Piece &p) {
     const modes_record *recs = p.recs;
     p.log = IcaoLog{};
     p.text.clear();
+    p.text.reserve((size_t)(p.hi - p.lo) * 31 + 64);                              // a line per record at most: no regrowth while appending
     p.host.st = modes_host_stats{};
     p.host.have_candidates = false;
     p.host.log = &p.log;
+    p.host.lean = true;
     TextSink sink{&p.host, &p.text, 0};
     modes_host_resolve(&p.host, recs + p.lo, p.hi - p.lo, nullptr, 0, text_sink, &sink);
     p.host.log = nullptr;
+    p.host.lean = false;
     p.msgs = sink.msgs;
 }
 }  // namespace
@@ -682,23 +691,37 @@ uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *se
     return msgs;
 }
 
-static int format_hex_line(const struct modesMessage *mm, char *buf, const char *hex) {
-    int n = 0;
-    buf[n++] = '*';
-    for (int b = 0; b < mm->msgbits / 8; b++) {
-        buf[n++] = hex[mm->msg[b] >> 4];
-        buf[n++] = hex[mm->msg[b] & 15];
+// '*' + two hex digits per byte + ";\n".  A byte -> its two digits through a 256-entry table (one 2-byte store per message
+// byte): the line formatter is half of the --raw resolve's time per message (rank 0 of an 8-GPU run formats 524,000 lines per
+// step), and a digit-by-digit loop was 32 ns of its 62.
+namespace {
+struct HexPairs {
+    char lower[256][2], upper[256][2];
+    HexPairs() {
+        const char *lo = "0123456789abcdef", *up = "0123456789ABCDEF";
+        for (int b = 0; b < 256; b++) {
+            lower[b][0] = lo[b >> 4]; lower[b][1] = lo[b & 15];
+            upper[b][0] = up[b >> 4]; upper[b][1] = up[b & 15];
+        }
     }
-    buf[n++] = ';';
-    buf[n++] = '\n';
-    buf[n] = 0;
-    return n;
+};
+const HexPairs kHex;
+inline int format_hex_line(const struct modesMessage *mm, char *buf, const char (*pairs)[2]) {
+    const int nbytes = mm->msgbits / 8;
+    buf[0] = '*';
+    char *o = buf + 1;
+    for (int b = 0; b < nbytes; b++, o += 2) memcpy(o, pairs[mm->msg[b]], 2);
+    o[0] = ';';
+    o[1] = '\n';
+    o[2] = 0;
+    return 3 + 2 * nbytes;
 }
+}  // namespace
 int modes_format_raw(const struct modesMessage *mm, char *buf) {                  // :1324-1326
-    return format_hex_line(mm, buf, "0123456789abcdef");
+    return format_hex_line(mm, buf, kHex.lower);
 }
 int modes_format_raw_net(const struct modesMessage *mm, char *buf) {              // modesSendRawOutput, :2381-2393
-    return format_hex_line(mm, buf, "0123456789ABCDEF");
+    return format_hex_line(mm, buf, kHex.upper);
 }
 
 int modes_format_onlyaddr(const struct modesMessage *mm, char *buf) {             // :1319
