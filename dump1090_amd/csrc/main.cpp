@@ -819,6 +819,7 @@ int main(int argc, char **argv) {
         }
         cv.notify_all();
     }
+    const double t_read_done = now_s();                                     // the last batch is submitted
     {
         std::lock_guard<std::mutex> g(m);
         reader_done = true;
@@ -847,11 +848,11 @@ int main(int argc, char **argv) {
             fprintf(stderr,
                     "{\"bytes\": %llu, \"devices\": %d, \"lanes\": %d, \"init_s\": %.4f, \"stream_s\": %.4f, \"total_s\": %.4f, "
                     "\"stream_GBps\": %.2f, \"stream_Msamples_per_s\": %.1f, \"sink_calls\": %llu, "
-                    "\"init\": {\"first_context_s\": %.4f, \"first_buffer_s\": %.4f, \"all_lanes_s\": %.4f}, \"teardown\": null}\n",
+                    "\"init\": {\"first_context_s\": %.4f, \"first_buffer_s\": %.4f, \"all_lanes_s\": %.4f}, \"drain_s\": %.4f, \"teardown\": null}\n",
                     (unsigned long long)total_bytes, ndev, nlanes, t_ready - t_start, stream_s, now_s() - t_start,
                     stream_s > 0 ? total_bytes / stream_s / 1e9 : 0.0, stream_s > 0 ? total_bytes / 2 / stream_s / 1e6 : 0.0,
                     (unsigned long long)n_messages_out, t_created[0] - t_start, t_pinned[0] - t_start,
-                    *std::max_element(t_pinned.begin(), t_pinned.end()) - t_start);
+                    *std::max_element(t_pinned.begin(), t_pinned.end()) - t_start, t_end - t_read_done);
             fflush(stderr);
         }
         _exit(rc);
@@ -872,12 +873,12 @@ int main(int argc, char **argv) {
         fprintf(stderr,
                 "{\"bytes\": %llu, \"devices\": %d, \"lanes\": %d, \"init_s\": %.4f, \"stream_s\": %.4f, \"total_s\": %.4f, "
                 "\"stream_GBps\": %.2f, \"stream_Msamples_per_s\": %.1f, \"sink_calls\": %llu, "
-                "\"init\": {\"first_context_s\": %.4f, \"first_buffer_s\": %.4f, \"all_lanes_s\": %.4f}, "
+                "\"init\": {\"first_context_s\": %.4f, \"first_buffer_s\": %.4f, \"all_lanes_s\": %.4f}, \"drain_s\": %.4f, "
                 "\"teardown\": {\"flush_s\": %.4f, \"host_s\": %.4f, \"lanes_s\": %.4f, \"unmap_s\": %.4f}}\n",
                 (unsigned long long)total_bytes, ndev, nlanes, t_ready - t_start, stream_s, t_unmapped - t_start,
                 stream_s > 0 ? total_bytes / stream_s / 1e9 : 0.0, stream_s > 0 ? total_bytes / 2 / stream_s / 1e6 : 0.0,
                 (unsigned long long)n_messages_out, t_created[0] - t_start, t_pinned[0] - t_start,
-                *std::max_element(t_pinned.begin(), t_pinned.end()) - t_start,
+                *std::max_element(t_pinned.begin(), t_pinned.end()) - t_start, t_end - t_read_done,
                 t_flushed - t_end, t_host - t_flushed, t_lanes - t_host, t_unmapped - t_lanes);
     }
     return rc;
