@@ -32,14 +32,15 @@ means "the driver's command: every leg (noise, frames, low SNR, the 64 GiB strea
 
 if [ -w /dev/shm ]; then
   python - <<'PY'
-import sys, os
+import sys
 sys.path[:0] = [".", "tests"]
-import synth
-st = synth.config3_stream(4, 262144 // 16)            # 4 GiB of configs[3]'s generator (the 64 GiB stream needs 64 GiB of /dev/shm)
-with open("/dev/shm/modes_fc.bin", "wb") as f:
-    step = 1 << 28
-    for lo in range(0, st.nbytes, step):
-        st.window(lo, min(st.nbytes, lo + step)).tofile(f)
+import torch, bench
+total_blocks = 262144 // 16                          # 4 GiB of configs[3]'s generator (the 64 GiB stream needs 64 GiB of /dev/shm)
+dev = torch.device("cuda", 0)
+with open("/dev/shm/modes_fc.bin", "wb") as f:       # built on the GPU (the numpy generator takes minutes for this), 1 GiB at a time
+    for lo in range(0, total_blocks * 262144, 1 << 30):
+        iq, _ = bench.build_frames_shard(torch, dev, total_blocks, lo, lo + (1 << 30), seed=4)
+        iq.cpu().numpy().tofile(f)
 PY
   one=$(dump1090_amd/bin/dump1090_amd --ifile /dev/shm/modes_fc.bin --raw | md5sum | cut -c1-32)
   step ranks${N}_file 600 dump1090_amd/bin/dump1090_amd --ifile /dev/shm/modes_fc.bin --raw --ranks $N --timing
