@@ -320,9 +320,11 @@ def visible_gpus():
     return torch.cuda.device_count()
 
 
-def ipc_probe(dist, torch, dev, rank, world, seconds=20.0):
+def ipc_probe(dist, torch, dev, rank, world, seconds=120.0):
     """The first transfer between two ranks' devices is where a wrong IPC mode or a missing peer-to-peer path shows - as a hang.
-    A 64-byte ring (rank r -> r + 1) right behind init_process_group, watched: when it does not complete in `seconds` the rank
+    A 64-byte ring (rank r -> r + 1) right behind init_process_group, watched: when it does not complete in `seconds` (generous:
+    on a fresh box RCCL's first communicator alone has taken 60-100 s while the image pages in, and the first send / recv between
+    two ranks sets up its channels on top of that - a slow start must not be taken for a hang) the rank
     says which HSA_ENABLE_IPC_MODE_LEGACY it ran with, leaves $MODES_PROBE_MARK for a self-launched parent (which then starts the
     job over with the other value) and ends the process - a wrong guess costs seconds, not the lease."""
     a = torch.full((64,), 0x5a, dtype=torch.uint8, device=dev)
@@ -453,10 +455,10 @@ def main():
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        # a rank that stops answering ends the job with an error after three minutes (the default is ten) instead of
-        # holding the node
+        # a rank that stops answering ends the job with an error after five minutes (the default is ten) instead of
+        # holding the node (not three: the first RCCL start on a fresh box has taken 60-100 s by itself)
         import datetime
-        limit = datetime.timedelta(seconds=180)
+        limit = datetime.timedelta(seconds=300)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
             ipc_probe(dist, torch, dev, rank, world)           # (a group of one sends to itself: the same calls on a one-GPU box)

@@ -125,7 +125,7 @@ int modes_gather_create(const modes_gather_config *cfg, const void *id, modes_ga
     }
     {   // the probe: a 64-byte ring over the new communicator, watched - a transfer that never completes is the failure mode of
         // a wrong IPC mode / a missing P2P path, and nothing else would ever report it
-        double limit = 20.0;
+        double limit = 120.0;                                               // generous: a cold box has taken 60-100 s for the communicator alone
         if (const char *v = getenv("MODES_GATHER_PROBE_SECONDS")) limit = atof(v);
         if (limit > 0.0) {
             uint8_t *d_probe = nullptr;

@@ -12,9 +12,9 @@ export HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}      # dmabuf
 step() { name=$1; limit=$2; shift 2; echo "== $name: $*"; ( time timeout $limit "$@" ) > "$O/$name.log" 2>&1; rc=$?; echo "   rc=$rc  $(grep -m1 '^{' "$O/$name.log" | cut -c1-300)"; return $rc; }
 means() { echo "   -> if this fails: $*"; }
 
-step ranks2_small 180 dump1090_amd/bin/dump1090_amd --ifile tests/golden/modes1.bin --raw --ranks 2 --batch-blocks 1 --timing
+step ranks2_small 400 dump1090_amd/bin/dump1090_amd --ifile tests/golden/modes1.bin --raw --ranks 2 --batch-blocks 1 --timing
 means "two PROCESSES, two devices, 3 batches: the unique id pipe, ncclCommInitRank across processes, the first ncclSend/ncclRecv between two GPUs." \
-      "'hipIpcGetMemHandle: invalid argument' = the IPC mode (try HSA_ENABLE_IPC_MODE_LEGACY=1); a hang that ends after 20 s with 'probe' = the" \
+      "'hipIpcGetMemHandle: invalid argument' = the IPC mode (try HSA_ENABLE_IPC_MODE_LEGACY=1); a hang that ends after 120 s with 'probe' = the" \
       "communicator came up but the first transfer did not complete (xGMI / P2P access between the two devices)."
 md5=$(dump1090_amd/bin/dump1090_amd --ifile tests/golden/modes1.bin --raw --ranks 2 --batch-blocks 1 2>/dev/null | md5sum | cut -c1-32)
 echo "   --ranks 2 listing md5 $md5 (the reference's: 4a81758c8bec5e45ffa8541c5622938a)"
