@@ -151,3 +151,13 @@ def test_weak_listing_check_still_rejects_foreign_lines():
     with pytest.raises(AssertionError, match="stream order"):
         half = len(lines) // 2
         bench.check_listing(join(lines[half:] + lines[:half]), expected, weak=True)
+
+
+def test_committed_counter_pass_belongs_to_these_kernel_sources():
+    """profiles/traffic_latest.json (the committed rocprofv3 FETCH_SIZE pass bench.py falls back on, and reports next to its live
+    pass as roofline.committed_traffic) is stamped with the hash of the kernel sources it was measured on: a kernel edit without
+    a new pass would silently turn the field into null."""
+    got, note = bench.measured_traffic(1024)
+    assert got is not None, note
+    assert 1.0 < got / 2 ** 30 < 1.08, (got, note)                 # the scan kernel reads every sample once (+ look-backs)
+    assert bench.TRACE_AVG_MS and 0.15 < bench.TRACE_AVG_MS < 0.25
