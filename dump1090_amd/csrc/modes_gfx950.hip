@@ -344,10 +344,7 @@ constexpr int kDemodAux = DEMOD_AUX;   // the demod kernel's sample loads (candi
                                        // nt or nt | sc1: 0.0408 ms instead of 0.0354 (they re-read what the scan just streamed), sc0: same
 constexpr int kQCap = 64;             // queue entries per wavefront: one beta pass
 constexpr int kQStride = 17;          // dwords per entry: 11 window + 4 results + 1 position + 1 pad (odd: no bank conflicts)
-#ifndef SCAN_WG_WAVES
-#define SCAN_WG_WAVES 2
-#endif
-constexpr int kScan2Waves = SCAN_WG_WAVES;
+constexpr int kScan2Waves = 2;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -452,20 +449,10 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
     // chunk c0 + k lives in ring slot k & 1 (64 x 16 bytes each).  Loop-invariant LDS pointers.
     // A lane's 24-sample window = the 16 samples of the two lanes before it (previous chunk's lanes
     // 62, 63 for lanes 0, 1: the ring wraps) + its own 8 samples, which never leave its registers.
-#if defined(SCAN_RING1)
-    // experiment (tools/ab_scan.py): ONE chunk slot + a 32-byte side slot for the previous chunk's lanes 62, 63 instead of two chunk
-    // slots - 1 KiB of LDS less per wavefront (28 instead of 24 wavefronts per CU) for one more (two-lane) LDS write per chunk
-    uint4 *const wr0 = ring4 + lane, *const wr1 = wr0;
-    uint4 *const side = ring4 + 64 + (lane & 1);                             // lanes 62, 63 -> side[0], side[1]
-    const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring4);
-    const uint32_t rd0a = ring_lds + 16u * (lane >= 2 ? lane - 2 : 64 + lane), rd0b = ring_lds + 16u * (lane >= 1 ? lane - 1 : 65);
-    const uint32_t rd1a = rd0a, rd1b = rd0b;
-#else
     uint4 *const wr0 = ring4 + lane, *const wr1 = ring4 + 64 + lane;
     const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring4);  // LDS byte address (low half of the flat address)
     const uint32_t rd0a = ring_lds + 16u * ((126 + lane) & 127), rd0b = ring_lds + 16u * ((127 + lane) & 127);
     const uint32_t rd1a = ring_lds + 16u * ((190 + lane) & 127), rd1b = ring_lds + 16u * ((191 + lane) & 127);
-#endif
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t *>(iq + (GUARD ? 0 : base_off)), 0, 0x7fffffff, 0x00020000);
@@ -493,10 +480,6 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(a), "=&v"(b) : "v"(rda), "v"(rdb) : "memory");
         wave_lds_fence();
-#if defined(SCAN_RING1)
-        if (lane >= 62) *side = s;                                           // for lanes 0, 1 of the next chunk (after this chunk's reads)
-        wave_lds_fence();
-#endif
         const uint32_t E[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, s.x, s.y, s.z, s.w};
         uint32_t r[4];
         modes_order8_swar(E, r);
@@ -553,11 +536,7 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
     // prologue: the last 16 samples of chunk c0-1 go to the tail of slot 1 (lanes 62, 63)
     {
         const uint4 s = power16_scan(load_iq16(iq, base_off - kChunkBytes + lane_off, lo, hi));
-#if defined(SCAN_RING1)
-        if (lane >= 62) *side = s;
-#else
         if (lane >= 62) *wr1 = s;
-#endif
     }
     uint4 x = load_at(0), y = load_at(kChunkBytes);                          // two chunks in flight
     uint32_t k = 0, off = 2 * kChunkBytes;
@@ -577,11 +556,7 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
 }
 
 __global__ __launch_bounds__(kScan2Waves * kWave) void scan_kernel(ScanParams P) {
-#if defined(SCAN_RING1)
-    __shared__ uint4 ring_all[kScan2Waves][66];
-#else
     __shared__ uint4 ring_all[kScan2Waves][128];
-#endif
     __shared__ uint32_t queue_all[kScan2Waves][kQCap * kQStride];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: addresses stay in SGPRs
