@@ -1,4 +1,4 @@
-"""A/B of kernel builds on one box: python tools/ab_scan.py [--rounds R] [--workload noise|lowsnr|frames] [--demod-variant V] lib1.so lib2.so ...
+"""A/B of kernel builds on one box: python tools/ab_scan.py [--rounds R] [--workload noise|lowsnr|frames] [--demod-variant V] [--run-chunks R] lib1.so lib2.so ...
 (--workload lowsnr: 1 GiB of BASELINE configs[4]'s stream, --aggressive; frames: 1 GiB of configs[2]'s, --fix; default: the
 bench noise, --fix.  The same library may be named twice with different MODES_* knobs only through separate builds.)
 All libraries are loaded into ONE process (each dlopen has its own namespace) and measured on the same 1 GiB of the
@@ -19,9 +19,9 @@ sys.path.insert(0, '@ROOT@'); sys.path.insert(0, '@ROOT@/tests')
 import numpy as np, torch
 from dump1090_amd import _native as N
 from dump1090_amd import Demodulator
-libs = sys.argv[4:]
-rounds, workload, variant = int(sys.argv[1]), sys.argv[2], int(sys.argv[3])
-flags = dict(fix=True, aggressive=(workload == "lowsnr"), demod_variant=variant)
+libs = sys.argv[5:]
+rounds, workload, variant, run_chunks = int(sys.argv[1]), sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+flags = dict(fix=True, aggressive=(workload == "lowsnr"), demod_variant=variant, run_chunks=run_chunks)
 if workload == "noise":
     iq = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:0")
     g = Demodulator(fix=True)
@@ -74,15 +74,16 @@ print(json.dumps(res))
 
 def main():
     args = sys.argv[1:]
-    rounds, workload, variant = 4, "noise", 0
+    rounds, workload, variant, run_chunks = 4, "noise", 0, 0
     while args and args[0].startswith("--"):
         if args[0] == "--rounds": rounds = int(args[1])
         elif args[0] == "--workload": workload = args[1]
         elif args[0] == "--demod-variant": variant = int(args[1])
+        elif args[0] == "--run-chunks": run_chunks = int(args[1])
         else: sys.exit("unknown option " + args[0])
         args = args[2:]
     libs = [os.path.abspath(a) for a in args]
-    out = subprocess.run([sys.executable, "-c", CHILD, str(rounds), workload, str(variant)] + libs, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-c", CHILD, str(rounds), workload, str(variant), str(run_chunks)] + libs, capture_output=True, text=True, timeout=900)
     line = [l for l in out.stdout.splitlines() if l.startswith("[")]
     if not line:
         print("FAILED", out.stderr[-1500:]); sys.exit(1)
