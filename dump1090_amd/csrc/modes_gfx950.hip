@@ -268,14 +268,7 @@ struct ScanParams {
     uint32_t *slots;      // [nruns][slot_cap]
     uint32_t *counts;     // [nruns]  (true count, may exceed slot_cap -> overflow flag)
     ResultHeader *hdr;
-#if defined(SCAN_GAMMA)
-    const uint16_t *lut;  // experiment: the magnitude table (its first 512 entries go to LDS per run)
-    uint32_t *gstat;      // [nruns][2]: preambles, gate survivors the wavefront found itself
-#endif
 };
-#if defined(SCAN_GAMMA)
-__device__ void scan_gamma(const ScanParams &P, uint32_t run, int lane, uint32_t *queue, uint32_t n, const uint32_t *my_slots, int64_t c0);
-#endif
 
 // ------------------------------------------------------------------------------------
 // demod_kernel parameters
@@ -560,17 +553,6 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
     if (qn) scan_beta(P, queue, qn, lane, my_slots, count);
 #endif
     if (lane == 0) P.counts[run] = count;                 // true count; demod_kernel flags count > slot_cap
-#if defined(SCAN_GAMMA)
-    // EXPERIMENT (timing + counts only): the exact preamble predicate and the noise-gate pre-test for the run's
-    // own forwarded positions, by this wavefront, at the end of its run - what "select inside the scan" costs the scan kernel.
-    // The slot lists are still written and the demodulation kernels still run: their counts check this code's.
-    if (!GUARD) {
-        // the slot list this wavefront just stored is read back (sc1 loads: from the L2): its stores must have been acknowledged.
-        // (An agent-scope fence here is an L2 write-back per run: the kernel took 1.76 ms instead of 0.19.)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        scan_gamma(P, run, lane, queue, count < P.slot_cap ? count : P.slot_cap, my_slots, c0);
-    }
-#endif
 }
 
 __global__ __launch_bounds__(kScan2Waves * kWave) void scan_kernel(ScanParams P) {
@@ -1368,100 +1350,6 @@ __device__ __forceinline__ uint32_t sel_sum(const uint32_t (&d)[8], uint32_t sh1
     return acc;
 }
 
-#if defined(SCAN_GAMMA)
-// magnitude of a saturated power through a 512-entry table in LDS (1 KiB: it fits into the wavefront's idle queue), the exact
-// square-root form beyond it (strong signals)
-struct LutSmall {
-    const uint16_t *p;
-    __device__ __forceinline__ uint32_t at(uint32_t s) const { return s < 512u ? (uint32_t)p[s] : modes_mag_exact(s); }
-};
-template <bool FLAGS>
-__device__ __forceinline__ uint32_t gamma_sum(const uint32_t (&d)[8], uint32_t sh16, const LutSmall lut, uint32_t *first) {
-    uint32_t acc = 0, f = 0;
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const uint32_t ix = pk_lut_index(sel_dword(d, k, sh16));
-        const uint32_t a = lut.at(ix & 0xffffu), b = lut.at(ix >> 16);
-        if (FLAGS && k < 6) {
-            const uint32_t dd = __builtin_amdgcn_sad_u16(a, b, 0u);
-            f |= (dd < 256u ? 1u : 0u) << k | (a > b ? 1u : 0u) << (8 + k);
-            if (k == 0) f |= (a == b ? 1u : 0u) << 16;
-            acc += dd;
-        } else {
-            acc = __builtin_amdgcn_sad_u16(a, b, acc);
-        }
-    }
-    if (FLAGS) *first = f;
-    return acc;
-}
-__device__ void scan_gamma(const ScanParams &P, uint32_t run, int lane, uint32_t *queue, uint32_t n, const uint32_t *my_slots, int64_t c0) {
-    // the table's first 512 entries: 16 bytes per lane, into the (now idle) queue; the preamble list behind it
-    uint16_t *s_lut = reinterpret_cast<uint16_t *>(queue);
-    uint32_t *plist = queue + 256;
-    reinterpret_cast<uint4 *>(s_lut)[lane] = reinterpret_cast<const uint4 *>(P.lut)[lane];
-    wave_lds_fence();
-    const LutSmall lut{s_lut};
-    const int64_t gbase = c0 * kChunkSamples - 64;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.iq) + 2 * gbase, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(my_slots), 0, 0x7fffffff, 0x00020000);
-    uint32_t npre_total = 0, nsurv_total = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        // ---- stage 1: one lane per forwarded position (the wavefront's own stores, read back past the L1: sc1) ----
-        const bool act = base + (uint32_t)lane < n;
-        uint32_t p = 0;
-        if (act) p = __builtin_amdgcn_raw_buffer_load_b32(srsrc, 4u * (base + (uint32_t)lane), 0, 16);
-        bool ok = false;
-        if (act) {
-            const uint32_t voff = (uint32_t)(2 * ((int64_t)p - gbase));
-            const u32x4 wa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0), wb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16u, 0, 0);
-            const uint32_t w[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
-            int m[16];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t ix = pk_lut_index(w[i]);
-                m[2 * i] = (int)lut.at(ix & 0xffffu);
-                m[2 * i + 1] = (int)lut.at(ix >> 16);
-            }
-            struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
-            ok = modes_preamble_exact(Win{m});
-        }
-        const uint64_t okb = __ballot(ok);
-        const uint32_t npre = (uint32_t)__builtin_popcountll(okb);
-        if (ok) plist[lanes_below(okb)] = p;
-        wave_lds_fence();
-        npre_total += npre;
-        // ---- stage 2: the gate pre-test, 8 lanes per preamble, 8 preambles per round ----
-        const int grp = lane >> 3, t = lane & 7, head = lane & ~7;
-        for (uint32_t r0 = 0; r0 < npre; r0 += 8) {
-            const bool gact = r0 + (uint32_t)grp < npre;
-            const uint32_t pc = gact ? plist[r0 + (uint32_t)grp] : 0u;
-            const uint32_t voff = (uint32_t)(2 * ((int64_t)pc - gbase)) + 32u;
-            uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (gact) sel_load(rsrc, voff, t, d);
-            uint32_t first = 0, d56 = 0;
-            if (gact) d56 = gamma_sum<true>(d, ((voff + 28u * (uint32_t)t) & 2u) << 3, lut, &first);
-            d56 = sel_reduce8(d56);
-            const uint32_t f0 = (uint32_t)__shfl((int)first, head, 64);
-            const bool is_long = modes_len_by_df(modes_df_first6(f0 & 0x3fu, (f0 >> 8) & 0x3fu, ((f0 >> 16) & 1u) != 0)) == 112;
-            bool pass = gact && !is_long && d56 / 28 >= 2550;
-            if (__any(gact && is_long)) {                                     // the other 56 pairs of the long ones, in place
-                uint32_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d2 = 0;
-                const uint32_t voff2 = voff + 224u;
-                if (gact && is_long) {
-                    sel_load(rsrc, voff2, t, e);
-                    d2 = gamma_sum<false>(e, ((voff2 + 28u * (uint32_t)t) & 2u) << 3, lut, nullptr);
-                }
-                d2 = sel_reduce8(d2);
-                if (gact && is_long) pass = (d2 + d56) / 56 >= 2550;
-            }
-            nsurv_total += (uint32_t)__builtin_popcountll(__ballot(pass && t == 0));
-        }
-        wave_lds_fence();
-    }
-    if (lane == 0) { P.gstat[2 * run] = npre_total; P.gstat[2 * run + 1] = nsurv_total; }
-}
-#endif
-
 __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void select_kernel(SelectParams P) {
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[MODES_LUT_ENTRIES];
     __shared__ uint32_t s_pre[kDemodGroup + 1];        // exclusive prefix of the batch's (clamped) run counts
@@ -2156,17 +2044,6 @@ static int grow(modes_gpu *ctx, T **ptr, size_t *have, size_t want_bytes) {
 }
 
 static int wait_results(modes_gpu *ctx);
-#if defined(SCAN_GAMMA)
-static uint32_t *g_gstat = nullptr;
-static uint32_t g_gstat_runs = 0;
-extern "C" int modes_gpu_gamma_totals(unsigned long long *pre, unsigned long long *surv) {      // experiment: what the scan kernel counted itself
-    std::vector<uint32_t> h((size_t)g_gstat_runs * 2);
-    if (hipMemcpy(h.data(), g_gstat, h.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    *pre = *surv = 0;
-    for (uint32_t r = 0; r < g_gstat_runs; r++) { *pre += h[2 * r]; *surv += h[2 * r + 1]; }
-    return 0;
-}
-#endif
 
 static int grid_for(uint64_t items, int per_block) {
     uint64_t b = (items + per_block - 1) / per_block;
@@ -2490,18 +2367,6 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     sp.slots = ctx->d_slots;
     sp.counts = d_counts;
     sp.hdr = ctx->d_hdr;
-#if defined(SCAN_GAMMA)
-    {
-        static uint32_t *d_gstat = nullptr;
-        static size_t gstat_bytes = 0;
-        if ((rc = grow(ctx, &d_gstat, &gstat_bytes, (size_t)nruns * 2 * sizeof(uint32_t))) != MODES_OK) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(d_gstat, 0, (size_t)nruns * 2 * sizeof(uint32_t), st));
-        sp.lut = ctx->d_lut;
-        sp.gstat = d_gstat;
-        g_gstat = d_gstat;
-        g_gstat_runs = nruns;
-    }
-#endif
 
     DemodParams dp{};
     dp.iq = sp.iq;
