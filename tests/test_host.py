@@ -315,7 +315,7 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS")}
     p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "ranks-host"], capture_output=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout[-800:], p.stderr[-800:])
-    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 12 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
+    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 13 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
     # (three of the twelve: the start-up probe of the communicator fails - on every rank, on a peer, on rank 0 - and rank 0 starts the
     # job over once with the other IPC mode; that second run prints the listing)
     assert p.stdout.count(b", 1 restart") == 3
@@ -326,7 +326,8 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     assert p.stdout.count(b"fails in GPU call") == 2 and p.stdout.count(b": exit status 1") == 6
     # --stats through the gather's second list (every rank's preamble positions on rank 0): the reference's nine lines for N = 1, 2, 3;
     # a list that outgrows its buffers fails the job; a pipe / --loop is refused with the alternative named
-    assert p.stdout.count(b"md5 bc3d1c04b24f4989f0fc4a2d1f45abdd") == 6
+    assert p.stdout.count(b"md5 bc3d1c04b24f4989f0fc4a2d1f45abdd") == 7        # N = 1, 2, 3 x two batch sizes, and N = 8
+    assert b"--raw --ranks 8 --batch-blocks 1: md5 4a81758c" in p.stdout              # eight processes, five of them without a batch
     assert b"--stats with 8 positions of room: exit status 1" in p.stdout and b"refused, --gpus named" in p.stdout
 
 
