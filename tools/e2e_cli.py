@@ -30,6 +30,8 @@ out = {"file_gib": gib, "host_cores": os.cpu_count(), "runs": []}
 
 
 def run(extra, mode="--raw"):
+    time.sleep(1.0)          # the kernel is still tearing the previous process down (its GPU queues, pinned pages) when subprocess.run returns:
+                             # a process started right behind it waits ~0.1 s longer for the HIP runtime to come up
     t0 = time.perf_counter()
     p = subprocess.run([exe, "--ifile", path, mode, "--no-fix", "--timing"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
     dt = time.perf_counter() - t0
