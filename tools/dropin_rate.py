@@ -43,6 +43,7 @@ def rate(name, exe, file, nbytes, runs, extra_env=None):
     e = dict(env if "dump1090_amd/bin" not in exe else os.environ, MODES_DROPIN_TIMING="1", **(extra_env or {}))
     args = ["--timing"] if "dump1090_amd/bin" in exe else []
     for _ in range(runs):
+        time.sleep(1.0)      # (a process started right behind another GPU process's exit waits ~0.1 s longer for the HIP runtime: tools/e2e_cli.py)
         t0 = time.perf_counter()
         p = subprocess.run([exe, "--ifile", file, "--raw", "--no-fix"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, check=True)
         dt = time.perf_counter() - t0
