@@ -130,6 +130,6 @@ def test_more_ranks_than_gpus_is_one_clear_line_at_once():
     n = torch.cuda.device_count() + 1
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     t0 = time.perf_counter()
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + SMALL, capture_output=True, timeout=120, env=env)
-    assert p.returncode != 0 and time.perf_counter() - t0 < 30
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + SMALL, capture_output=True, timeout=300, env=env)
+    assert p.returncode != 0 and time.perf_counter() - t0 < 90       # (seconds once torch is in the page cache; no rendezvous, no ranks)
     assert p.stdout == b"" and b"GPU(s) visible on this box" in p.stderr and p.stderr.count(b"\n") <= 2, p.stderr[-600:]
