@@ -205,3 +205,44 @@ def test_config4_sixty_four_gib_in_eight_shards_matches_reference(torch_cuda):
         want = reference_stdout(iq.cpu().numpy(), "default", "--raw")
         assert hashlib.md5(got.encode()).hexdigest() == hashlib.md5(want.encode()).hexdigest()
     d.close()
+
+
+def test_hosts_on_the_eight_gib_file_print_the_reference_listing(torch_cuda):
+    """BASELINE configs[2] as a FILE (8 GiB in /dev/shm, the generator's stream of seed 3) through the two hosts a user would run -
+    the C++ host and the reference's own main() with the batched patch (integration/dump1090_gfx950_batched.patch, K = 512 buffers per
+    hand-off) - and, with --aggressive, configs[4]'s 1 GiB low-SNR file: stdout == the compiled reference's listing of the very
+    stream (tests/golden/config_listings.json: 65,519 / 2,519 lines), byte for byte."""
+    import hashlib
+    import json
+    import shutil
+    import subprocess
+    import bench
+    torch = torch_cuda
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.disk_usage("/dev/shm").free < 10 * 2 ** 30:
+        pytest.skip("needs 9 GiB of /dev/shm")
+    batched = os.path.join(root, "oracle", "_ref", "dump1090_dropin_batched")
+    cxx = os.path.join(root, "dump1090_amd", "bin", "dump1090_amd")
+    assert os.path.exists(batched), "oracle/_ref/dump1090_dropin_batched must travel with the snapshot"
+    with open(os.path.join(root, "tests", "golden", "config_listings.json")) as f:
+        gold = json.load(f)
+    dev = torch.device("cuda", 0)
+    for key, kw, flags in (("frames:3:32768", {}, ["--raw"]), ("lowsnr:5:4096", bench.LOWSNR, ["--raw", "--aggressive"])):
+        kind, seed, nblocks = key.split(":")
+        seed, nblocks = int(seed), int(nblocks)
+        path = "/dev/shm/modes_fullsize_%s.bin" % kind
+        try:
+            with open(path, "wb") as f:                                      # built on the GPU, 1 GiB at a time
+                for lo in range(0, nblocks * 262144, 1 << 30):
+                    iq, _ = bench.build_frames_shard(torch, dev, nblocks, lo, min(nblocks * 262144, lo + (1 << 30)), seed=seed, **kw)
+                    iq.cpu().numpy().tofile(f)
+                    del iq
+            torch.cuda.empty_cache()
+            for exe, env in ((cxx, None), (batched, dict(os.environ, MODES_DROPIN_BLOCKS="512"))):
+                p = subprocess.run([exe, "--ifile", path] + flags, capture_output=True, env=env, timeout=600)
+                assert p.returncode == 0, p.stderr[-400:]
+                got = (p.stdout.count(b"\n"), hashlib.md5(p.stdout).hexdigest())
+                assert got == (gold[key]["lines"], gold[key]["md5"]), (key, os.path.basename(exe), got)
+        finally:
+            if os.path.exists(path):
+                os.remove(path)
