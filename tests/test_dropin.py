@@ -207,3 +207,33 @@ def test_batched_dropin_on_a_generated_stream_equals_the_cxx_host(tmp_path):
     for k in ("7", "512"):
         got = subprocess.run([BATCHED, "--ifile", str(path), "--raw"], capture_output=True, check=True, env=dict(os.environ, MODES_DROPIN_BLOCKS=k)).stdout
         assert got == want, k
+
+
+def _first_bytes(cmd, n, env=None):
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+    got = b""
+    try:
+        while len(got) < n:
+            chunk = p.stdout.read(n - len(got))
+            if not chunk:
+                break
+            got += chunk
+    finally:
+        p.kill()
+        p.wait()
+    return got
+
+
+def test_batched_reader_replays_the_file_like_the_reference(stub_hosted):
+    """--loop through the batched reader (dump1090.c:488-494: at the end of the file the reader seeks back and keeps filling the same
+    hand-off): the first 2.5 laps of output are the unmodified reference's bytes (where oracle/_ref/dump1090_ref exists), for K = 1
+    and for a K that spans several laps."""
+    one = subprocess.run([stub_hosted["batched"], "--ifile", stub_hosted["padded"], "--raw"], capture_output=True, check=True,
+                         env=dict(os.environ, MODES_DROPIN_BLOCKS="64")).stdout
+    n = len(one) * 5 // 2
+    laps = {k: _first_bytes([stub_hosted["batched"], "--ifile", stub_hosted["padded"], "--raw", "--loop"], n,
+                            dict(os.environ, MODES_DROPIN_BLOCKS=str(k))) for k in (1, 7)}
+    assert len(laps[1]) == n and laps[1] == laps[7] and laps[1][:len(one)] == one
+    if orc.have_ref():
+        ref = _first_bytes([orc.REF_BIN, "--ifile", stub_hosted["padded"], "--raw", "--loop"], n, dict(os.environ, LD_PRELOAD=orc.FIXED_TIME))
+        assert ref == laps[1]
