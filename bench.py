@@ -34,9 +34,9 @@ modes_gpu_submit_host (H2D over PCIe + kernels) in rotating contexts - the PCIe-
     python bench.py [--gpus N] [--steps K] [--warmup W]          N > 1: starts its own N ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...        (the same thing)
 
-Before the W warmup steps the headline leg runs `--settle` (80) more untimed steps: the chip's power management
-needs ~40 back-to-back steps to reach its sustained clocks (tools/scan_steps.py); the K timed steps are
-therefore the sustained rate, which is what a stream of many batches sees.
+Before the W warmup steps the headline leg runs `--settle` (240) more untimed steps: the chip's power management
+needs ~160 back-to-back steps (35 ms) to reach its sustained clocks (profiles/r07/scan_us_per_launch.txt); the K timed
+steps are therefore the sustained rate, which is what a stream of many batches sees.
 
 Prints ONE JSON line on rank 0 - and nothing else on stdout: whatever libraries print there (RCCL's version banner) is
 sent to stderr.  `roofline` is for the scan kernel (the only stage that reads every sample): algorithmic bytes = 2 per
@@ -369,10 +369,10 @@ def parse_args(argv=None):
     ap.add_argument("--demod-variant", type=int, default=0, help="modes_gpu_config.demod_variant (include/modes_gfx950.h)")
     ap.add_argument("--depth", type=int, default=0, help="detect calls in flight (contexts used in rotation); default 4, and 6 when "
                                                         "the record lists are gathered (N > 1): that pipeline has two more stages")
-    ap.add_argument("--settle", type=int, default=80,
-                    help="extra untimed steps before the W warmup steps: the chip's power management needs ~40 "
-                         "back-to-back steps (13 ms) to settle - the scan kernel runs 0.22, 0.27, 0.21 ms at steps "
-                         "1, 10, 60 of a sustained run (tools/scan_steps.py)")
+    ap.add_argument("--settle", type=int, default=240,
+                    help="extra untimed steps before the W warmup steps: the chip's power management needs ~160 "
+                         "back-to-back steps (35 ms) to settle - the scan kernel runs 0.20, 0.27, 0.24, 0.20, 0.19, 0.185 ms at "
+                         "launches 1, 15, 30, 80, 140, 200 of a sustained run (profiles/r07/scan_us_per_launch.txt)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="modes_gpu_config.overlap: 0 = scan, demod and order kernels in order on one stream; 2 = the "
                          "order kernel (a few microseconds, no LDS) runs on the context's own stream next to the following "
@@ -533,7 +533,7 @@ def main():
         # collectives pair up)
         max_blocks = total_blocks // world + 1
         calls = split_calls(first_block, nblocks, (max_blocks + args.call_blocks - 1) // args.call_blocks, lo, total_bytes)
-        # settle like the headline leg: the chip needs ~13 ms of back-to-back kernels to reach its sustained clocks, and the
+        # settle like the headline leg: the chip needs ~35 ms of back-to-back kernels to reach its sustained clocks, and the
         # seconds of host-side stream building in front of this leg restart that transient.  --settle counts
         # steps of the 1 GiB workload; a leg with G GiB per step and GPU gets ceil(settle / G) of its own steps, at least 6.
         gib_per_step = max((hi - lo) / 2 ** 30, 1e-3)

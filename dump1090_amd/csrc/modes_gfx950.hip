@@ -14,7 +14,7 @@
 // scan_kernel is the only stage that touches every sample; it never materialises
 // magnitudes.  Each lane turns 16 bytes (8 I/Q pairs) into 8 packed-u16 powers
 // s = (I-127)^2+(Q-127)^2, shares them with its wavefront through a wave-private
-// 2 KiB LDS ring (no workgroup barrier anywhere), reads the two lanes before it and
+// 1 KiB LDS ring (no workgroup barrier anywhere), reads the two lanes before it and
 // evaluates 8 preamble positions (alpha: the ordering relations, modes_order8_swar);
 // the ~1.5 % survivors are queued in LDS and a dense second pass (beta) applies the
 // level tests as a necessary condition in s.  Because the reference's magnitude LUT is
@@ -321,11 +321,11 @@ struct DemodParams {
 //          for odd ones: modes_order8_swar).  ~1.5 % of positions survive; lanes owning a survivor
 //          push {their 24-sample window, the four result words, the window's position} into a
 //          wave-private LDS queue.
-//   beta   whenever 64 entries are queued: one lane per entry, plain 32-bit integers: the level
+//   beta   whenever the queue (59 entries) cannot take the next chunk's: one lane per entry, plain 32-bit integers: the level
 //          bound 9*max(quiet) < s0+s2+s7+s9 for the survivors of that entry.  Dense lanes, so the
 //          level test costs ~10x less per chunk than evaluating it packed at every position.
 //
-// The chunk loop is unrolled by two so that ring-slot parity is static: all LDS addresses are
+// The chunk loop is unrolled by two so that the ring's two address sets are static: all LDS addresses are
 // loop-invariant VGPRs, the prefetched chunk lives in the registers it was loaded into (no
 // rotation moves), and global addresses are SGPR base + constant lane offset.
 //
@@ -342,7 +342,15 @@ constexpr int kScanAux = SCAN_AUX;
 #endif
 constexpr int kDemodAux = DEMOD_AUX;   // the demod kernel's sample loads (candidates only: ~150 MB per GiB): default policy.
                                        // nt or nt | sc1: 0.0408 ms instead of 0.0354 (they re-read what the scan just streamed), sc0: same
-constexpr int kQCap = 64;             // queue entries per wavefront: one beta pass
+// LDS per wavefront: the ring (66 x 16 B) + the queue.  59 entries: 2 x (1056 + 59 x 68) = 10,136 B per workgroup = 16 workgroups =
+// 32 wavefronts per CU, the most a CU holds (8 per SIMD; 55 VGPRs).  With the two-slot ring and 64 entries of rounds 1-3 it was 24:
+// profiles/r07/ab_scan_ring66.txt (-3 %; the kernel is VALU-bound and wants every wavefront it can get: 20 per CU +4 %, 16 +9 %).
+#ifndef SCAN_QCAP
+#define SCAN_QCAP 59
+#endif
+constexpr int kQCap = SCAN_QCAP;      // queue entries per wavefront: one beta pass (a lane per entry: at most 64; the push handles < 64)
+static_assert(kQCap >= 32 && kQCap <= 64, "queue capacity");
+constexpr int kRingEntries = 66;
 constexpr int kQStride = 17;          // dwords per entry: 11 window + 4 results + 1 position + 1 pad (odd: no bank conflicts)
 constexpr int kScan2Waves = 2;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -446,13 +454,18 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
     const int64_t base_off = c0 * kChunkBytes;
     const uint32_t lane_off = (uint32_t)lane * 16u;
 
-    // chunk c0 + k lives in ring slot k & 1 (64 x 16 bytes each).  Loop-invariant LDS pointers.
-    // A lane's 24-sample window = the 16 samples of the two lanes before it (previous chunk's lanes
-    // 62, 63 for lanes 0, 1: the ring wraps) + its own 8 samples, which never leave its registers.
-    uint4 *const wr0 = ring4 + lane, *const wr1 = ring4 + 64 + lane;
+    // A lane's 24-sample window = the 16 samples of the two lanes before it (previous chunk's lanes 62, 63 for lanes 0, 1) + its own
+    // 8 samples, which never leave its registers.  The ring: loop-invariant LDS pointers, the chunk loop unrolled by two.
+    // 66 entries of 16 bytes instead of two slots of 64: lanes 0 .. 61 of EVERY chunk write entries 2 .. 63 (a wavefront's LDS
+    // operations execute in order: the previous chunk's reads are done), only lanes 62, 63 - the two that the NEXT chunk's lanes
+    // 0, 1 look back to - alternate between entries 64, 65 (even chunks) and 0, 1 (odd chunks).  An even chunk then reads entries
+    // lane and lane + 1; an odd chunk the same except lanes 0, 1 (entries 64, 65) and lane 63's second read (entry 0).  Entries 0, 1
+    // lie 64 entries below 64, 65: the same banks as the two-slot ring, every 16-lane group of a b128 operation conflict-free.
+    // Every address is still a loop-invariant VGPR; 992 bytes less LDS per wavefront for no instruction.
+    uint4 *const wr0 = ring4 + 2 + lane, *const wr1 = ring4 + (lane < 62 ? 2 + lane : lane - 62);
     const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>(ring4);  // LDS byte address (low half of the flat address)
-    const uint32_t rd0a = ring_lds + 16u * ((126 + lane) & 127), rd0b = ring_lds + 16u * ((127 + lane) & 127);
-    const uint32_t rd1a = ring_lds + 16u * ((190 + lane) & 127), rd1b = ring_lds + 16u * ((191 + lane) & 127);
+    const uint32_t rd0a = ring_lds + 16u * lane, rd0b = rd0a + 16u;
+    const uint32_t rd1a = ring_lds + 16u * (lane < 2 ? 64 + lane : lane), rd1b = ring_lds + 16u * (lane == 0 ? 65 : lane == 63 ? 0 : lane + 1);
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t *>(iq + (GUARD ? 0 : base_off)), 0, 0x7fffffff, 0x00020000);
@@ -505,18 +518,9 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
         if (hb) {
 #endif
             const uint32_t npush = (uint32_t)__builtin_popcountll(hb);
-            if (qn + npush > kQCap) {
-#if !defined(SCAN_ABL_NOBETA)
-                scan_beta(P, queue, qn, lane, my_slots, count);
-#endif
-                qn = 0;
-                wave_lds_fence();
-            }
-            if (any) {
-                // rank among the pushing lanes: v_mbcnt counts the mask bits below this lane
-                // (v_mbcnt adds the count to its last operand: the queue fill comes in for free)
-                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, qn));
-                uint32_t *e = queue + __umul24(slot, (uint32_t)kQStride);            // v_mad_u32_u24, not a 32-bit multiply
+            const uint32_t pos = (uint32_t)(c * kChunkSamples - kLookback + 8 * lane);
+            auto push_entry = [&](uint32_t slot) {
+                uint32_t *e = queue + __umul24(slot, (uint32_t)kQStride);                // v_mad_u32_u24, not a 32-bit multiply
 #pragma unroll
                 for (int t = 0; t < 11; t++) {
 #if defined(SCAN_ABL_PUSH)
@@ -526,14 +530,40 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) e[11 + q] = r[q];
-                e[15] = (uint32_t)(c * kChunkSamples - kLookback + 8 * lane);
+                e[15] = pos;
+            };
+            // The level pass empties the queue whenever this chunk's entries do not fit.  `base`: pushing lanes (by rank) that are
+            // queued already - not 0 only when MORE lanes push than the whole queue holds (kQCap < 64; every lane of a wavefront can
+            // own an ordering survivor, tests/test_gpu_parity.py::test_every_lane_pushes): kQCap of them go in and through the pass
+            // first.  Entries stay in lane order = position order either way.
+            uint32_t base = 0;
+            bool mine = any;                                                 // this lane still has to push
+            while (qn + (npush - base) > kQCap) {
+                if (kQCap < kWave && qn == 0) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u)) - base;
+                    if (mine && rank < (uint32_t)kQCap) push_entry(rank);
+                    mine = mine && rank >= (uint32_t)kQCap;
+                    qn = kQCap;
+                    base += kQCap;
+                    wave_lds_fence();
+                }
+#if !defined(SCAN_ABL_NOBETA)
+                scan_beta(P, queue, qn, lane, my_slots, count);
+#endif
+                qn = 0;
+                wave_lds_fence();
             }
-            qn += npush;
+            if (mine) {
+                // rank among the pushing lanes: v_mbcnt counts the mask bits below this lane
+                // (v_mbcnt adds the count to its last operand: the queue fill comes in for free)
+                push_entry(__builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, qn - base)));
+            }
+            qn += npush - base;
             wave_lds_fence();
         }
     };
 
-    // prologue: the last 16 samples of chunk c0-1 go to the tail of slot 1 (lanes 62, 63)
+    // prologue: the last 16 samples of chunk c0-1 go where an odd chunk's lanes 62, 63 write (entries 0, 1)
     {
         const uint4 s = power16_scan(load_iq16(iq, base_off - kChunkBytes + lane_off, lo, hi));
         if (lane >= 62) *wr1 = s;
@@ -556,8 +586,13 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
 }
 
 __global__ __launch_bounds__(kScan2Waves * kWave) void scan_kernel(ScanParams P) {
-    __shared__ uint4 ring_all[kScan2Waves][128];
+    __shared__ uint4 ring_all[kScan2Waves][kRingEntries];
     __shared__ uint32_t queue_all[kScan2Waves][kQCap * kQStride];
+#if defined(SCAN_LDS_PAD)
+    // occupancy experiment (tools/ab_scan.py): SCAN_LDS_PAD more bytes of LDS per workgroup -> fewer wavefronts per CU
+    __shared__ uint32_t lds_pad[SCAN_LDS_PAD / 4];
+    if (P.nruns == 0xFFFFFFFFu) { lds_pad[threadIdx.x] = 1; __syncthreads(); P.counts[threadIdx.x] = lds_pad[threadIdx.x ^ 1]; }   // never: keeps the array
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: addresses stay in SGPRs
     const uint32_t run = blockIdx.x * kScan2Waves + wave;

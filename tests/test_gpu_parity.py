@@ -553,6 +553,32 @@ def test_slot_overflow_is_retried_not_dropped(torch_cuda):
     d.close()
 
 
+def test_every_lane_pushes(torch_cuda):
+    """A period-16 signal with TWO valid preambles per period (9 and 7 samples apart): every lane of every scan wavefront owns an
+    ordering survivor in every chunk - 64 queue entries from one chunk, more than the scan kernel's queue holds (59 since round 4:
+    the push hands the first 59 to the level pass and queues the rest).  Shifted copies move the pattern across the lanes' 8-sample
+    windows; 1/8 of all positions are preambles, so the per-run slot lists overflow and are retried too."""
+    from dump1090_amd import Demodulator
+    level = np.array([2, 0, 14, 20, 2, 16, 0, 2, 1, 0, 10, 1, 20, 1, 10, 0])        # preambles at 3 and 12 (mod 16)
+    n = 2 * synth.DATA_LEN
+    iq = np.full(n, 127, dtype=np.uint8)
+    ns = n // 2
+    seg = ns // 8
+    for k in range(8):                                                   # 8 segments, the pattern shifted by k (and k + 8 inside)
+        s = np.arange(seg - 64)
+        iq[0::2][k * seg:k * seg + seg - 64] = 127 + 4 * level[(s + k) % 16]
+    iq[-480:] = 127
+    for run_chunks in (0, 2):                                            # 2: every run is two chunks - the pass at the end of a run too
+        d = Demodulator(keep_candidates=True, check_crc=False, run_chunks=run_chunks)
+        d.detect(to_dev(torch_cuda, iq))
+        recs, cands, info = d.fetch()
+        want_r, want_c = oracle_records(iq, 1)
+        assert want_c.size > ns // 9                                     # two preambles per 16 samples
+        assert np.array_equal(cands, want_c)
+        assert_records_equal(recs, want_r, "every lane pushes")
+        d.close()
+
+
 def test_dense_capture_grows_record_list_and_matches_reference(torch_cuda):
     """The reference's own capture is far denser than any real feed (~750 records per MiB).  Tiled to
     1.5 GiB it yields more records than the automatic list capacity (2^20): the library must grow the

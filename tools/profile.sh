@@ -15,9 +15,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 case $WL in
-  noise)  STEPS=300; SETTLE=80 ;;       # 1 GiB steps
-  lowsnr) STEPS=200; SETTLE=80 ;;       # 1 GiB steps
-  frames) STEPS=40;  SETTLE=80 ;;       # 8 GiB steps (bench.py turns --settle into ceil(80 / 8) = 10 of them)
+  noise)  STEPS=300; SETTLE=240 ;;       # 1 GiB steps
+  lowsnr) STEPS=200; SETTLE=240 ;;       # 1 GiB steps
+  frames) STEPS=40;  SETTLE=240 ;;      # 8 GiB steps (bench.py turns --settle into ceil(240 / 8) = 30 of them)
   *) echo "workload $WL?"; exit 2 ;;
 esac
 COMMON="--workload $WL --no-end-to-end --no-live-traffic --no-cpu-baseline --no-ceiling --streams 1 --leg-streams 1"
@@ -38,7 +38,7 @@ echo "write rc=$?"
 cd "$R"
 # launches in front of the timed region: the leg's settle steps (ceil(SETTLE / GiB per step), at least 6) + warmup... bench.py's
 # noise leg adds its warmup to --settle; the other legs settle max(6, ceil(settle / GiB)) steps of `calls` launches each
-case $WL in noise) SKIP=$((SETTLE + 2)) ;; lowsnr) SKIP=$SETTLE ;; frames) SKIP=20 ;; esac
+case $WL in noise) SKIP=$((SETTLE + 2)) ;; lowsnr) SKIP=$SETTLE ;; frames) SKIP=60 ;; esac
 python tools/summarize_prof.py "$OUT" $SKIP > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 # keep the merge-back small: raw per-dispatch CSVs of the counter runs can be large
