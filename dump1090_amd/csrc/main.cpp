@@ -774,6 +774,7 @@ int main(int argc, char **argv) {
     std::condition_variable unmap_cv;
     std::vector<std::pair<uint8_t *, size_t>> unmap_q;
     bool unmap_stop = false;
+    size_t unmapped_to = 0;                 // [0, unmapped_to) of the mapping has been handed to the unmapper (batches are consecutive)
     std::thread unmapper([&] {
         for (;;) {
             std::vector<std::pair<uint8_t *, size_t>> work;
@@ -819,6 +820,7 @@ int main(int argc, char **argv) {
             {
                 std::lock_guard<std::mutex> g(unmap_m);
                 unmap_q.emplace_back(const_cast<uint8_t *>(map) + pos_before, (size_t)got & ~(size_t)4095);
+                unmapped_to = (size_t)pos_before + ((size_t)got & ~(size_t)4095);
             }
             unmap_cv.notify_one();
         }
@@ -899,7 +901,10 @@ int main(int argc, char **argv) {
         modes_gpu_destroy(ln.gpu);
     }
     const double t_lanes = now_s();
-    if (map) munmap(const_cast<uint8_t *>(map), map_len);
+    // Only what the unmapper has not released: the pages it gave back during the run are free address space, and whatever was
+    // allocated since (growing output buffers, late lanes' pinned memory, HIP's pools, thread stacks) may live there by now -
+    // unmapping the whole original range would take that memory away from under its owners.
+    if (map && unmapped_to < map_len) munmap(const_cast<uint8_t *>(map) + unmapped_to, map_len - unmapped_to);
     if (fd > 0) close(fd);
     const double t_unmapped = now_s();
     if (opt.timing) {

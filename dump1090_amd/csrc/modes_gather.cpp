@@ -62,6 +62,7 @@ struct modes_gather {
     std::vector<Slot> slots;
     modes_gather_stats st{};
     std::string err;
+    uint8_t *d_probe = nullptr;        // the first-contact probe's 128 bytes (modes_gather_create); released with the object
 };
 
 static int fail(modes_gather *g, int code, const char *fmt, ...) {
@@ -128,8 +129,8 @@ int modes_gather_create(const modes_gather_config *cfg, const void *id, modes_ga
         double limit = 120.0;                                               // generous: a cold box has taken 60-100 s for the communicator alone
         if (const char *v = getenv("MODES_GATHER_PROBE_SECONDS")) limit = atof(v);
         if (limit > 0.0) {
-            uint8_t *d_probe = nullptr;
-            CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&d_probe), 128));
+            CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_probe), 128));     // (owned by g: every way out through bail() frees it)
+            uint8_t *const d_probe = g->d_probe;
             CREATE_HIP(hipMemsetAsync(d_probe, 0x5a, 64, g->stream));
             const int next = (cfg->rank + 1) % cfg->nranks, prev = (cfg->rank + cfg->nranks - 1) % cfg->nranks;
             ncclResult_t r = ncclGroupStart();
@@ -150,13 +151,16 @@ int modes_gather_create(const modes_gather_config *cfg, const void *id, modes_ga
                 fail(g, MODES_GATHER_ERR_PROBE, "probe: the first 64-byte ncclSend/ncclRecv ring of rank %d of %d %s (%s; HSA_ENABLE_IPC_MODE_LEGACY=%s)",
                      cfg->rank, cfg->nranks, r != ncclSuccess ? "was refused" : q == hipErrorNotReady ? "did not complete in time" : "failed",
                      r != ncclSuccess ? ncclGetErrorString(r) : hipGetErrorString(q), ipc ? ipc : "unset");
-                // (no teardown: a communicator with a transfer stuck in it cannot be destroyed; the host ends the process)
+                // (no teardown - g, its stream, the communicator and the probe's 128 bytes stay: a communicator with a transfer stuck
+                //  in it cannot be destroyed.  The caller must not create another communicator and has to end the process:
+                //  modes_gather.h says so.)
                 fail(nullptr, MODES_GATHER_ERR_PROBE, "%s", g->err.c_str());
                 return MODES_GATHER_ERR_PROBE;
             }
             uint8_t back[64];
             CREATE_HIP(hipMemcpy(back, d_probe + 64, 64, hipMemcpyDeviceToHost));
             (void)hipFree(d_probe);
+            g->d_probe = nullptr;
             for (uint8_t b : back)
                 if (b != 0x5a) { fail(g, MODES_GATHER_ERR_PROBE, "probe: the ring delivered other bytes than were sent"); return bail(MODES_GATHER_ERR_PROBE); }
         }
@@ -209,6 +213,7 @@ void modes_gather_destroy(modes_gather *g) {
         for (hipEvent_t e : {s.ev_c0, s.ev_counts, s.ev_r0, s.ev_records})
             if (e) (void)hipEventDestroy(e);
     }
+    if (g->d_probe) (void)hipFree(g->d_probe);
     if (g->comm) (void)ncclCommDestroy(g->comm);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;

@@ -72,7 +72,10 @@ int  modes_gather_unique_id(void *id);
  * peer-to-peer path shows, and it shows as a hang.  The probe has 120 s ($MODES_GATHER_PROBE_SECONDS; 0 = no probe; generous
  * because on a fresh box RCCL's own start has taken 60-100 s while the image pages in); when it
  * runs out the call returns MODES_GATHER_ERR_PROBE and the text names the value of HSA_ENABLE_IPC_MODE_LEGACY the process
- * ran with - the host's cue to start the job once more with the other one (dump1090_amd --ranks does). */
+ * ran with - the host's cue to start the job once more with the other one (dump1090_amd --ranks does).
+ * AFTER MODES_GATHER_ERR_PROBE THE PROCESS MUST EXIT: a communicator with a transfer stuck in it cannot be torn down, so the
+ * object, its stream and the communicator are deliberately left behind; do not create another communicator in this process
+ * (a restart means a new process - HSA reads the IPC mode at process start anyway).  Every other failure frees everything. */
 int  modes_gather_create(const modes_gather_config *cfg, const void *id, modes_gather **out);
 void modes_gather_destroy(modes_gather *g);
 /* Text of the last error on g (or of the last failed create / unique_id of this thread when g == NULL). */

@@ -94,9 +94,12 @@ static void dropin_die(const char *what, modes_gpu *g) {
     exit(1);                                                              /* like dump1090.c:339-343 */
 }
 
-/* A file run lives half a second: what main()'s `return 0` would still do - the HIP runtime's exit handlers, unpinning and freeing
- * the buffers one by one (~0.1 s) - the kernel does for a dead process anyway.  Registered AFTER the runtime's own handlers (so it
- * runs before them), keeps the exit status, flushes stdio first.  $MODES_DROPIN_CLEAN_EXIT keeps the orderly exit. */
+/* OPT-IN ($MODES_DROPIN_FAST_EXIT=1): a file run lives half a second, and what main()'s `return 0` would still
+ * do - the HIP runtime's exit handlers, unpinning and freeing the buffers one by one (~0.1 s) - the kernel does for a dead
+ * process anyway.  Registered AFTER the runtime's own handlers (so it runs before them), keeps the exit status, flushes
+ * stdio first.  It is a process-wide side effect - every atexit / on_exit handler registered earlier, by the hosting program or
+ * its libraries, is skipped, on error exits too - so a file that is #included into someone else's main() does not do it
+ * unasked: the default is the orderly exit. */
 static void dropin_fast_exit(int status, void *arg) {
     (void)arg;
     fflush(NULL);
@@ -124,7 +127,7 @@ static void dropin_setup_batched(void) {
         dropin_buf[i] = p;
         modes_gpu_set_timing(dropin_ctx[i], 0);                           /* no timing events between the kernels */
     }
-    if (!getenv("MODES_DROPIN_CLEAN_EXIT")) on_exit(dropin_fast_exit, NULL);
+    if (getenv("MODES_DROPIN_FAST_EXIT")) on_exit(dropin_fast_exit, NULL);
     dropin_batched = 1;
 }
 

@@ -40,7 +40,7 @@ def rate(name, exe, file, nbytes, runs, extra_env=None):
     if not os.path.exists(exe):
         return
     best, lines, inner = 1e9, 0, None
-    e = dict(env if "dump1090_amd/bin" not in exe else os.environ, MODES_DROPIN_TIMING="1", **(extra_env or {}))
+    e = dict(env if "dump1090_amd/bin" not in exe else os.environ, MODES_DROPIN_TIMING="1", MODES_DROPIN_FAST_EXIT="1", **(extra_env or {}))
     args = ["--timing"] if "dump1090_amd/bin" in exe else []
     for _ in range(runs):
         time.sleep(1.0)      # (a process started right behind another GPU process's exit waits ~0.1 s longer for the HIP runtime: tools/e2e_cli.py)

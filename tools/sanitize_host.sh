@@ -111,7 +111,8 @@ run_ranks_host() {
     for mode in --raw --stats; do
         got=$($D/dump1090_amd_stub --ifile tests/golden/modes1.bin $mode --ranks 8 --batch-blocks 1 | md5sum | cut -c1-32)
         echo "   $mode --ranks 8 --batch-blocks 1: md5 $got"
-        [ "$got" = 4a81758c8bec5e45ffa8541c5622938a ] || [ "$got" = bc3d1c04b24f4989f0fc4a2d1f45abdd ] || { echo "   unexpected"; exit 1; }
+        case $mode in --raw) want=4a81758c8bec5e45ffa8541c5622938a ;; --stats) want=bc3d1c04b24f4989f0fc4a2d1f45abdd ;; esac
+        [ "$got" = "$want" ] || { echo "   expected $want for $mode"; exit 1; }
     done
     # a second list that outgrows its buffers fails every rank together (status 1), it is not truncated
     set +e
@@ -175,6 +176,20 @@ PY
     one=$($D/dump1090_amd_stub --ifile $D/pad.bin --raw --clean-exit | tee $D/one.txt | md5sum | cut -c1-32)
     echo "   one lap, --clean-exit: md5 $one"
     [ "$one" = 4a81758c8bec5e45ffa8541c5622938a ] || exit 1
+    # --clean-exit on a file of many batches: the pages of the mapping are handed back batch by batch while the stream runs, and the
+    # orderly teardown must unmap only what is left (unmapping the whole original range again takes whatever was
+    # allocated in the freed holes since - output buffers, lanes - away from under its owners)
+    python - <<'PY'
+import numpy as np
+one = np.fromfile("/tmp/modes_loop_host/pad.bin", dtype=np.uint8)
+np.tile(one, 48).tofile("/tmp/modes_loop_host/pad48.bin")
+PY
+    for bb in 2 7; do
+        $D/dump1090_amd_stub --ifile $D/pad48.bin --raw --clean-exit --batch-blocks $bb --depth 3 > $D/many.txt || { echo "   --clean-exit on 48 laps: status $?"; exit 1; }
+        many=$(wc -l < $D/many.txt)
+        head -c $(wc -c < $D/one.txt) $D/many.txt | cmp - $D/one.txt || { echo "   --clean-exit, 48 laps in one file: the first lap differs"; exit 1; }
+        echo "   --clean-exit, 48 laps as one file, --batch-blocks $bb: $many lines, status 0"
+    done
     n=$(( $(wc -c < $D/one.txt) * 5 / 2 ))
     set +e
     for bb in 1 3 512; do
