@@ -265,23 +265,10 @@ struct ScanParams {
     uint32_t run_chunks;
     uint32_t nruns;
     uint32_t slot_cap;
-    uint32_t *slots;      // [nruns] x (slot_cap positions, then win_cap windows): slot_stride() dwords per run
+    uint32_t *slots;      // [nruns][slot_cap]
     uint32_t *counts;     // [nruns]  (true count, may exceed slot_cap -> overflow flag)
     ResultHeader *hdr;
-    uint32_t win_cap;     // the first win_cap forwarded positions of a run also leave a window (0: none does)
 };
-
-// A *window* is what the scan kernel knows about a position it forwards, left for the demodulation stage so that the exact
-// preamble predicate (dump1090.c:1602-1650) needs no second look at the sample stream: the saturated powers (| kPowBias) of
-// samples p0 .. p0 + 21, p0 = p & ~7, two per dword - the first eleven dwords of the lane's queue entry, exactly as they lie
-// in LDS - and the position p itself in the twelfth.  48 bytes (kWinDwords), written with three 16-byte stores and read back the same way
-// (sequentially: consecutive forwarded positions of a run are consecutive entries), instead of ~1.25 scattered 128-byte
-// lines per forwarded position (466,000 lines = 39 % of the stage's line traffic on noise: DESIGN.md 3.2).  Only the first
-// win_cap positions of a run get one; the demodulation kernels read the samples themselves for the rest.
-constexpr uint32_t kWinDwords = 12;
-// A run's list: slot_cap positions (u32), padded to 16 bytes, then win_cap windows.  One allocation, one pointer in every kernel.
-__host__ __device__ __forceinline__ uint32_t slot_win_off(uint32_t slot_cap) { return (slot_cap + 3u) & ~3u; }                              // dwords
-__host__ __device__ __forceinline__ uint32_t slot_stride(uint32_t slot_cap, uint32_t win_cap) { return slot_win_off(slot_cap) + kWinDwords * win_cap; }
 
 // ------------------------------------------------------------------------------------
 // demod_kernel parameters
@@ -312,7 +299,6 @@ struct DemodParams {
     uint32_t slot_cap;
     const uint32_t *slots;
     const uint32_t *counts;
-    uint32_t win_cap;          // windows per run behind its slot_cap positions (ScanParams)
     DeviceTables tab;
     int maxfix;                // 0 = --no-fix, 1 = default, 2 = --aggressive   (dump1090.c:1115)
     uint32_t *cand_slots;      // [nruns][slot_cap] or nullptr
@@ -385,41 +371,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 //     at the two ends of a call and for one window per buffer: one test per entry, a per-position loop only there;
 //   * a lane forwards at most one position in all but ~1 pass in 200: one ballot ranks the lanes; the general
 //     prefix (a ballot per bit of the per-lane count) runs only when some lane has two.
-// The windows of a run (ScanParams) leave the wavefront sixteen at a time.  A store instruction costs the SIMD the same whether one
-// lane is active or all 64 - three 16-byte stores behind every level pass that forwards something (1.5 lanes on average) made the
-// kernel 10 us per GiB slower, with stores that the buffer range check drops just the same (profiles/r08/ab_scan_window_stores.txt) -
-// so the 48 bytes of a window are first gathered from the forwarding lane's queue entry into THREE registers of four lanes
-// (window k of the buffer: lanes 4k .. 4k + 3, twelve bytes each), and the buffer goes out with ONE 12-byte store per lane
-// when it holds 16 windows or the run ends: ~1.4 store instructions per run instead of ~21.
-struct WinBuf {
-    uint32_t r0, r1, r2;      // per lane: dwords 3t .. 3t + 2 of window (lane >> 2), t = lane & 3
-    uint32_t n;               // windows in the buffer (wave-uniform)
-    uint32_t done;            // windows of the run already in memory (wave-uniform)
-};
-__device__ __forceinline__ void scan_flush_windows(WinBuf &B, uint32_t *my_win, int lane) {
-    if ((uint32_t)lane < 4u * B.n) {
-        uint32_t *d = my_win + (B.done * kWinDwords + 3u * (uint32_t)lane);
-        d[0] = B.r0; d[1] = B.r1; d[2] = B.r2;
-    }
-    B.done += B.n;
-    B.n = 0;
-}
-// position p (wave-uniform) of queue entry L (wave-uniform) -> the next place of the buffer
-__device__ __forceinline__ void scan_capture_window(WinBuf &B, const uint32_t *queue, uint32_t *my_win, int lane, uint32_t L, uint32_t p) {
-    const uint32_t t = (uint32_t)lane & 3u;
-    const uint32_t *src = queue + L * kQStride + 3u * t;
-    if (((uint32_t)lane >> 2) == B.n) {
-        B.r0 = src[0];
-        B.r1 = src[1];
-        B.r2 = t == 3u ? p : src[2];                            // the twelfth dword is the position
-    }
-    if (++B.n == 16u) {
-        wave_lds_fence();
-        scan_flush_windows(B, my_win, lane);
-    }
-}
 __device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *queue, uint32_t nb, int lane,
-                                          uint32_t *my_slots, uint32_t *my_win, WinBuf &B, uint32_t &count) {
+                                          uint32_t *my_slots, uint32_t &count) {
     const bool act = (uint32_t)lane < nb;
     const uint32_t *e = queue + lane * kQStride;
     uint32_t f = 0, p0 = 0;
@@ -461,25 +414,10 @@ __device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *q
     // its records by position without a sort.
     const uint64_t any = __ballot(fwd8 != 0);
     if (any == 0) return;                                                    // wave-uniform
-#if !defined(SCAN_NO_WINDOWS)
-    // Windows for the first win_cap positions of the run, in position order (= the order of their slot numbers): a wave-uniform
-    // walk over the forwarding lanes and their positions, each window gathered by four lanes of the buffer.
-    if (B.done + B.n < P.win_cap) {
-        for (uint64_t m = any; m; m &= m - 1) {
-            const uint32_t L = (uint32_t)__builtin_ctzll(m);
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)p0, (int)L);
-            for (uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)fwd8, (int)L); bits; bits &= bits - 1)
-                if (B.done + B.n < P.win_cap) scan_capture_window(B, queue, my_win, lane, L, base + (uint32_t)__builtin_ctz(bits));
-        }
-    }
-    const uint32_t with_window = P.win_cap;                                  // slot numbers below it need no slot: the window has the position
-#else
-    const uint32_t with_window = 0;
-#endif
     const uint64_t multi = __ballot((fwd8 & (fwd8 - 1)) != 0);
     if (multi == 0) {                                                        // one position per forwarding lane
         const uint32_t idx = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
-        if (fwd8 != 0 && idx >= with_window && idx < P.slot_cap) my_slots[idx] = p0 + (uint32_t)__builtin_ctz(fwd8);
+        if (fwd8 != 0 && idx < P.slot_cap) my_slots[idx] = p0 + (uint32_t)__builtin_ctz(fwd8);
         count += (uint32_t)__builtin_popcountll(any);
         return;
     }
@@ -498,7 +436,7 @@ __device__ __forceinline__ void scan_beta(const ScanParams &P, const uint32_t *q
     while (fwd8) {
         const int i = __builtin_ctz(fwd8);
         fwd8 &= fwd8 - 1;
-        if (idx >= with_window && idx < P.slot_cap) my_slots[idx] = p0 + (uint32_t)i;
+        if (idx < P.slot_cap) my_slots[idx] = p0 + (uint32_t)i;
         idx++;
     }
     count += total;
@@ -543,9 +481,7 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
     };
 
     uint32_t count = 0, qn = 0;                                              // wave-uniform
-    uint32_t *my_slots = P.slots + (uint64_t)run * slot_stride(P.slot_cap, P.win_cap);
-    uint32_t *my_win = my_slots + slot_win_off(P.slot_cap);
-    WinBuf B{0u, 0u, 0u, 0u, 0u};
+    uint32_t *my_slots = P.slots + (uint64_t)run * P.slot_cap;
 
     // one chunk: powers `s` to slot `wr`, neighbours' through `rda/rdb`, alpha, push, maybe beta
     auto step = [&](const uint4 &s, uint4 *wr, uint32_t rda, uint32_t rdb, int64_t c) {
@@ -612,7 +548,7 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
                     wave_lds_fence();
                 }
 #if !defined(SCAN_ABL_NOBETA)
-                scan_beta(P, queue, qn, lane, my_slots, my_win, B, count);
+                scan_beta(P, queue, qn, lane, my_slots, count);
 #endif
                 qn = 0;
                 wave_lds_fence();
@@ -644,9 +580,8 @@ __device__ __forceinline__ void scan_run(const ScanParams &P, uint32_t run, int 
     }
     if (k < nk) step(power16_scan(x), wr0, rd0a, rd0b, c0 + k);             // odd tail (last run only)
 #if !defined(SCAN_ABL_NOBETA)
-    if (qn) scan_beta(P, queue, qn, lane, my_slots, my_win, B, count);
+    if (qn) scan_beta(P, queue, qn, lane, my_slots, count);
 #endif
-    if (B.n) { wave_lds_fence(); scan_flush_windows(B, my_win, lane); }
     if (lane == 0) P.counts[run] = count;                 // true count; demod_kernel flags count > slot_cap
 }
 
@@ -893,38 +828,6 @@ __device__ __forceinline__ bool preamble_at_fast(__amdgpu_buffer_rsrc_t rsrc, ui
     return modes_preamble_exact(Win{m});
 }
 
-// The same predicate from a window of the scan kernel (ScanParams): no sample is loaded, no power computed.  The window holds
-// samples p0 .. p0 + 21 (p0 = p & ~7) two per dword; the 15 the predicate needs start i = p & 7 samples in: one funnel
-// shift for the odd half of i, two rounds of selects for the rest (registers cannot be indexed per lane).
-// Returns the position through *pos.
-template <class Lut>
-__device__ __forceinline__ bool preamble_from_window(const uint32_t *entry, const Lut lut, uint32_t *pos) {
-    const u32x4 *w = reinterpret_cast<const u32x4 *>(entry);
-    const u32x4 a = w[0], b = w[1], c = w[2];
-    const uint32_t d[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
-    const uint32_t p = d[11], i = p & 7u;
-    *pos = p;
-    const uint32_t sh = (i & 1u) << 4;
-    uint32_t D[11], T[10];
-#pragma unroll
-    for (int k = 0; k < 11; k++) D[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);   // D[10]'s high half is not a sample; nobody reads it
-    // The two selects as bit-field inserts under masks the compiler cannot see through (written "h ? D[k + 1] : D[k]" they
-    // become an indexed load from a copy of D in the private segment).
-    uint32_t m1 = 0u - ((i >> 1) & 1u), m2 = 0u - (i >> 2);
-    asm("" : "+v"(m1), "+v"(m2));
-#pragma unroll
-    for (int k = 0; k < 10; k++) T[k] = (m1 & D[k + 1]) | (~m1 & D[k]);
-    int m[16];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint32_t v = (m2 & T[k + 2]) | (~m2 & T[k]);                                // samples i + 2k, i + 2k + 1
-        m[2 * k] = (int)lut.p[v & 0x7fffu];                                               // (bit 15: kPowBias)
-        m[2 * k + 1] = (int)lut.p[(v >> 16) & 0x7fffu];
-    }
-    struct Win { const int *m; __device__ int operator()(int t) const { return m[t]; } };
-    return modes_preamble_exact(Win{m});
-}
-
 // Noise-gate pre-test (dump1090.c:1713-1723): the sum of |lo - hi| over 56 consecutive bit pairs
 // (a short message, or the second half of a long one) by a group of kGateLanes = 4 lanes.
 // The 56 pairs are 224 consecutive bytes at a 2-byte aligned address; lane t of the group fetches the
@@ -1115,11 +1018,6 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
 #ifdef MODES_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
-    // the first batch's run counts are requested before the table: one round trip to memory instead of two in front of stage 1
-    uint32_t first_count = 0;
-#if !defined(DEMOD_LATE_COUNTS)
-    if (threadIdx.x < (uint32_t)kDemodGroup && blockIdx.x * kDemodGroup + threadIdx.x < P.nruns) first_count = P.counts[blockIdx.x * kDemodGroup + threadIdx.x];
-#endif
     stage_lut<kDemodThreads>(s_lut, P.tab.lut);
     for (uint32_t i = threadIdx.x; i < (uint32_t)kSynWords; i += kDemodThreads) s_esyn[i] = P.tab.esyn[i];
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
@@ -1157,11 +1055,7 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
         if (wave == 0) {                                                     // one run per lane
             uint32_t cnt = 0;
             if (run0 + lane < P.nruns) {
-#if !defined(DEMOD_LATE_COUNTS)
-                const uint32_t true_count = batch == blockIdx.x ? first_count : P.counts[run0 + lane];
-#else
                 const uint32_t true_count = P.counts[run0 + lane];
-#endif
                 if (true_count > P.slot_cap) atomicOr(&s_flags[1], 1u);        // the scan dropped positions: the call fails
                 cnt = min(true_count, P.slot_cap);
                 tot_fwd += true_count;
@@ -1181,34 +1075,28 @@ __global__ __launch_bounds__(kDemodWaves * 64) __attribute__((amdgpu_num_sgpr(80
         uint32_t ncand = 0;
         uint32_t prior = 0;                                                  // records of the batch's earlier blocks
         const uint64_t cand_base = (uint64_t)batch * kDemodGroup * P.slot_cap;
-        // position number e of the batch: entry *idx = e - s_pre[rr] of run rr, the last run that starts at or before e
-        auto locate = [&](uint32_t e, uint32_t *idx) -> uint32_t {
+        // position number e of the batch: entry e - s_pre[rr] of run rr, the last run that starts at or before e
+        auto slot_of = [&](uint32_t e) -> uint32_t {
             uint32_t rr = 0;
 #pragma unroll
             for (int step = kDemodGroup / 2; step >= 1; step >>= 1)
                 if (s_pre[rr + step] <= e) rr += step;
-            *idx = e - s_pre[rr];
-            return run0 + rr;
+            return P.slots[(uint64_t)(run0 + rr) * P.slot_cap + (e - s_pre[rr])];
         };
+        uint32_t p_next = (uint32_t)tid < n ? slot_of((uint32_t)tid) : 0u;
         for (uint32_t base = 0; base < n; base += kDemodThreads) {
             // ---------------- stage 1 ----------------
             TRACE_T(ts1);
             const uint32_t e = base + (uint32_t)tid;
             const bool active = e < n;
-            uint32_t idx = 0, p = 0;
-            const uint32_t run = active ? locate(e, &idx) : 0u;
-            // The first win_cap positions of a run come with the scan kernel's window: the predicate needs no look at the stream
-            // (and the position is in the window: nothing depends on a second gather).  The rest - none on noise - read their 15
-            // samples themselves, 16-byte loads when the window is inside the span, guarded 2-byte loads next to its ends.
-            const bool fat = active && idx < P.win_cap;
-            bool ok = false;
-            const uint32_t *my_slots = P.slots + (uint64_t)run * slot_stride(P.slot_cap, P.win_cap);
-            if (fat) ok = preamble_from_window(my_slots + slot_win_off(P.slot_cap) + idx * kWinDwords, lut, &p);
-            if (active && !fat) {
-                p = my_slots[idx];
-                ok = samples_inside((int64_t)p, (int64_t)p + 15, lo, hi) ? preamble_at_fast(rsrc, (uint32_t)(2 * ((int64_t)p - gbase)), lut)
-                                                                         : preamble_at_guarded(iq, lo, hi, lut, p);
-            }
+            const uint32_t p = p_next;
+            // the next block's position travels through this block's stages: one dependent gather less per block
+            p_next = e + kDemodThreads < n ? slot_of(e + kDemodThreads) : 0u;
+            // fast path when every lane's 16-sample window is inside the span (wave-uniform test)
+            const bool in1 = !active || samples_inside((int64_t)p, (int64_t)p + 15, lo, hi);
+            bool ok;
+            if (__all(in1)) ok = active && preamble_at_fast(rsrc, (uint32_t)(2 * ((int64_t)p - gbase)), lut);
+            else            ok = active && preamble_at_guarded(iq, lo, hi, lut, p);
             // Preambles whose whole message window (samples p-1 .. p+239) lies inside the span go to the
             // pre-test list; the few next to an end of the span go straight to stage 3 (guarded loads).
             const bool whole = samples_inside((int64_t)p - 1, (int64_t)p + 239, lo, hi);
@@ -1431,7 +1319,6 @@ struct SelectParams {
     uint32_t nruns, run_chunks, slot_cap;
     const uint32_t *slots;      // [nruns][slot_cap] forwarded positions, ascending per run (scan kernel)
     const uint32_t *counts;     // [nruns]
-    uint32_t win_cap;           // windows per run behind its slot_cap positions (ScanParams)
     const uint16_t *lut;
     uint32_t *cand_slots;       // [nbatches][kDemodGroup * slot_cap] preamble positions (keep_candidates) or nullptr
     uint32_t *cand_counts;      // [nbatches]
@@ -1513,20 +1400,12 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
     __shared__ uint32_t s_n[2];                        // [0] long ones, [1] edge ones of the block
     __shared__ uint32_t s_flags;                       // WgTotals.flags bits
     __shared__ uint32_t s_fwd;                         // forwarded positions of the workgroup's batches (a call has < 2^32 positions)
-    __shared__ uint32_t s_cnt0[kDemodGroup];           // run counts of the workgroup's first batch
 #ifdef MODES_TRACE
     const unsigned long long t_start = wall_clock64();
     unsigned long long tr_t[4] = {0, 0, 0, 0};          // batch set-up, stage 1 (+ compaction), stage 2a, stage 2b + edge + write-out
 #endif
-    {   // the first batch's run counts are requested before the table (demod_kernel) and wait in LDS: this kernel has no register to spare
-        uint32_t first_count = 0;
-#if !defined(DEMOD_LATE_COUNTS)
-        if (threadIdx.x < (uint32_t)kDemodGroup && blockIdx.x * kDemodGroup + threadIdx.x < P.nruns) first_count = P.counts[blockIdx.x * kDemodGroup + threadIdx.x];
-#endif
-        stage_lut<kSelThreads>(s_lut, P.lut);          // (staged UNDER the first batch's position loads instead: 7 us longer - the
+    stage_lut<kSelThreads>(s_lut, P.lut);              // (staged UNDER the first batch's position loads instead: 7 us longer - the
                                                        //  table's loads queue behind them; profiles/r05)
-        if (threadIdx.x < (uint32_t)kDemodGroup) s_cnt0[threadIdx.x] = first_count;
-    }
     const int tid = (int)threadIdx.x;
     [[maybe_unused]] const int lane = tid & 63;             // (the trace build reads it)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1543,7 +1422,7 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
     for (uint32_t batch = blockIdx.x; batch < P.nbatches; batch += gridDim.x) {
         // The thread's number is taken afresh per batch and per block of positions (sel_tid): everything derived from it - a
         // dozen LDS addresses - is then recomputed where it is used instead of living in a register for the whole kernel
-        // (hoisted out of the loops they ended up in the private segment: this kernel has exactly its 64 registers).
+        // (hoisted out of the loops they end up in the private segment: this kernel has exactly its 64 registers).
         const int tid = sel_tid(), lane = tid & 63;
         const uint32_t run0 = batch * kDemodGroup;
         TRACE_T(tb0);
@@ -1551,12 +1430,8 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(iq) + 2 * gbase, 0, 0x7fffffff, 0x00020000);
         if (wave == 0) {                                                     // one run per lane
             uint32_t cnt = 0;
-#if !defined(DEMOD_LATE_COUNTS)
-            if (batch != blockIdx.x)                                           // (the first batch's are there already)
-#endif
-                s_cnt0[lane] = run0 + lane < P.nruns ? P.counts[run0 + lane] : 0u;
             if (run0 + lane < P.nruns) {
-                const uint32_t true_count = s_cnt0[lane];                      // (written by this lane or, before a barrier, by thread `lane`)
+                const uint32_t true_count = P.counts[run0 + lane];
                 if (true_count > P.slot_cap) atomicOr(&s_flags, 1u);           // the scan dropped positions: the call fails
                 cnt = min(true_count, P.slot_cap);
                 atomicAdd(&s_fwd, true_count);                                 // (one LDS instruction per batch: a running per-lane sum would
@@ -1575,13 +1450,12 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pre[kDemodGroup]);     // workgroup-uniform values live in SGPRs:
         const uint64_t list_base = (uint64_t)batch * kDemodGroup * P.slot_cap;   // of the batch's candidate and survivor lists
         uint32_t ncand = 0, prior = 0;
-        auto locate = [&](uint32_t e, uint32_t *idx) -> uint32_t {
+        auto slot_of = [&](uint32_t e) -> uint32_t {
             uint32_t rr = 0;
 #pragma unroll
             for (int step = kDemodGroup / 2; step >= 1; step >>= 1)
                 if (s_pre[rr + step] <= e) rr += step;
-            *idx = e - s_pre[rr];
-            return run0 + rr;
+            return P.slots[(uint64_t)(run0 + rr) * P.slot_cap + (e - s_pre[rr])];
         };
         // exclusive prefix of one count per wavefront over the workgroup: -> (this wavefront's base, total); two barriers
         // (lane w takes wavefront w's count and the prefix runs over the lanes: a loop over w with "w < wave" is sixteen wave-uniform
@@ -1600,6 +1474,7 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
             *total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kSelWaves - 1);
             return (uint32_t)__builtin_amdgcn_readlane((int)(incl - c), wave);
         };
+        uint32_t p_next = (uint32_t)tid < n ? slot_of((uint32_t)tid) : 0u;
         TRACE_ADD(0, tb0);
         for (uint32_t base = 0; base < n; base += kSelThreads) {
             const int tid = sel_tid(), lane = tid & 63;
@@ -1607,18 +1482,13 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(8, 
             // ---------------- stage 1: the exact predicate, survivors compacted IN ORDER ----------------
             const uint32_t e = base + (uint32_t)tid;
             const bool active = e < n;
-            uint32_t idx = 0, p = 0;
-            const uint32_t run = active ? locate(e, &idx) : 0u;
+            const uint32_t p = p_next;
+            p_next = e + kSelThreads < n ? slot_of(e + kSelThreads) : 0u;
+            const bool in1 = !active || samples_inside((int64_t)p, (int64_t)p + 15, lo, hi);
+            bool ok;
             const LutFull lut{s_lut};
-            // from the scan kernel's window where the run has one for this position, from the stream otherwise (demod_kernel, stage 1)
-            const bool fat = active && idx < P.win_cap;
-            bool ok = false;
-            const uint32_t *my_slots = P.slots + (uint64_t)run * slot_stride(P.slot_cap, P.win_cap);
-            if (fat) ok = preamble_from_window(my_slots + slot_win_off(P.slot_cap) + idx * kWinDwords, lut, &p);
-            if (active && !fat) {                                                // (guarded 2-byte loads for all of them: a second, 16-byte
-                p = my_slots[idx];                                               //  form next to the window's does not fit this kernel's 64
-                ok = preamble_at_guarded(iq, lo, hi, lut, p);                    //  registers; the host keeps these rare: modes_gpu_detect)
-            }
+            if (__all(in1)) ok = active && preamble_at_fast(rsrc, (uint32_t)(2 * ((int64_t)p - gbase)), lut);
+            else            ok = active && preamble_at_guarded(iq, lo, hi, lut, p);
             // (two samples of slack behind the message window: the pre-test's dword-aligned loads read up to four bytes past it)
             const bool whole = samples_inside((int64_t)p - 1, (int64_t)p + 241, lo, hi);
             const uint64_t okb = __ballot(ok);
@@ -2138,7 +2008,6 @@ struct modes_gpu {
 
     // per-detect scratch (grown on demand)
     uint32_t *d_slots = nullptr;      size_t slots_bytes = 0;
-    int64_t win_cap_env = -1;         // MODES_GPU_WINDOW_CAP (measurement / test knob): windows per run; -1 = automatic
     uint32_t *d_surv = nullptr;       size_t surv_bytes = 0;         // select_kernel's survivor lists (same geometry as the candidate lists)
     uint32_t *d_wg_flags = nullptr;                                  // record_kernel: one word per workgroup (<= 512)
     bool split_path = false;          // the detect in flight ran select + record + finalize2 (the list is complete and in order)
@@ -2182,7 +2051,6 @@ struct modes_gpu {
     // demod_variant 0 chooses per call: the one-kernel path on (nearly) record-free input, select + record when the
     // previous call of this context left more than kSplitAbove records per GiB (+4 % there, -4 % on noise)
     double records_per_gib = 0.0;
-    double fwd_per_chunk = 0.0;       // forwarded positions per 512-sample chunk of the previous call (sizes the windows: modes_gpu_detect)
     bool auto_records = false;        // max_records was 0: the record list grows when a call needs more
     bool full_slots = false;          // a run once overflowed the automatic slot_cap: size the lists for the worst case
     modes_gpu_span last_span{};       // what the detect in flight was asked to do (for the overflow retry)
@@ -2285,16 +2153,6 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
         const uint32_t v = ctx->cfg.scan_variant;
         delete ctx;
         return fail(nullptr, MODES_ERR_ARG, "scan_variant %u: there is one scan kernel (the single-pass first version was removed in round 4)", v);
-    }
-    if (const char *v = getenv("MODES_GPU_WINDOW_CAP")) {
-        // Measurement / test knob: how many forwarded positions of a run get a window (0: none - every predicate reads the stream).
-        char *end = nullptr;
-        const unsigned long n = strtoul(v, &end, 10);
-        if (end == v || *end != 0 || n > 262144ul) {
-            delete ctx;
-            return fail(nullptr, MODES_ERR_ARG, "MODES_GPU_WINDOW_CAP='%s': a number of windows per run, 0 .. 262144", v);
-        }
-        ctx->win_cap_env = (int64_t)n;
     }
     if (ctx->cfg.demod_variant == 1 || ctx->cfg.demod_variant > 3) {
         const uint32_t v = ctx->cfg.demod_variant;
@@ -2524,23 +2382,10 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     if (cap == 0) cap = ctx->full_slots ? R * kChunkSamples : std::max<uint32_t>(64, R * 32);   // 1/16 of the run's positions
     if (cap > R * (uint32_t)kChunkSamples) cap = R * kChunkSamples;
 
-    // Windows (ScanParams).  Noise forwards 7e-4 of the positions - 11 per run of 32 chunks, Poisson - and a Mode S frame inside a
-    // run adds a few dozen: two per chunk cover every run of a sparse stream (96 MiB of windows per GiB scanned).  On a dense
-    // stream (the reference's own capture forwards hundreds per run) the count follows the context's previous call - four times
-    // its average per run, up to 1024 - so that the positions the demodulation kernels read from the stream stay the exception.
-    uint32_t win_cap = std::max<uint32_t>(16, 2 * R);
-    if (ctx->win_cap_env >= 0) win_cap = (uint32_t)ctx->win_cap_env;
-    else
-        while ((double)win_cap < 4.0 * ctx->fwd_per_chunk * R && win_cap < 1024) win_cap *= 2;
-    if (win_cap > cap) win_cap = cap;
-#if defined(SCAN_NO_WINDOWS)
-    win_cap = 0;                                                  // A/B build (tools/ab_scan.py): the scan kernel stores none
-#endif
-
     int rc;
     const uint32_t nbatches = (nruns + kDemodGroup - 1) / kDemodGroup;      // demod_kernel's unit of work, of candidate lists and of record order
     size_t want = (size_t)nbatches * kDemodGroup * cap * sizeof(uint32_t);
-    if ((rc = grow(ctx, &ctx->d_slots, &ctx->slots_bytes, (size_t)nbatches * kDemodGroup * slot_stride(cap, win_cap) * sizeof(uint32_t))) != MODES_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_slots, &ctx->slots_bytes, want)) != MODES_OK) return rc;
     const bool split = ctx->cfg.demod_variant == 2 || (ctx->cfg.demod_variant == 0 && ctx->records_per_gib > kSplitAbove);
     if (split && (rc = grow(ctx, &ctx->d_surv, &ctx->surv_bytes, want)) != MODES_OK) return rc;
     if (ctx->cfg.keep_candidates && (rc = grow(ctx, &ctx->d_cand_slots, &ctx->cand_slots_bytes, want)) != MODES_OK) return rc;
@@ -2570,7 +2415,6 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     sp.slots = ctx->d_slots;
     sp.counts = d_counts;
     sp.hdr = ctx->d_hdr;
-    sp.win_cap = win_cap;
 
     DemodParams dp{};
     dp.iq = sp.iq;
@@ -2582,7 +2426,6 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     dp.slot_cap = cap;
     dp.slots = ctx->d_slots;
     dp.counts = d_counts;
-    dp.win_cap = win_cap;
     dp.tab = DeviceTables{ctx->d_lut, ctx->d_esyn};
     dp.maxfix = ctx->maxfix;
     dp.cand_slots = ctx->cfg.keep_candidates ? ctx->d_cand_slots : nullptr;
@@ -2653,7 +2496,6 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
         sel.iq = sp.iq; sel.lo = sp.lo; sel.hi = sp.hi;
         sel.nruns = nruns; sel.run_chunks = R; sel.slot_cap = cap;
         sel.slots = ctx->d_slots; sel.counts = d_counts; sel.lut = ctx->d_lut;
-        sel.win_cap = win_cap;
         sel.cand_slots = dp.cand_slots; sel.cand_counts = d_cand_counts;
         sel.surv = ctx->d_surv; sel.batch_count = d_batch_count; sel.nbatches = nbatches; sel.totals = ctx->d_totals;
         hipExtLaunchKernelGGL(select_kernel, dim3(ctx->demod_grid), dim3(kSelThreads), 0, st2, ev(2), ev(3), 0, sel);
@@ -2821,7 +2663,6 @@ static int finish_detect(modes_gpu *ctx, modes_gpu_result *res, bool to_host) {
     // candidates: the workgroup lists keep no order inside a block of positions
     std::sort(ctx->h_cands.begin(), ctx->h_cands.end());
     ctx->records_per_gib = (double)n_records * 1073741824.0 / (double)std::max<uint64_t>(ctx->last_span.nbytes, 1);
-    ctx->fwd_per_chunk = (double)n_forwarded * kChunkBytes / (double)std::max<uint64_t>(ctx->last_span.nbytes, kChunkBytes);
     res->records = to_host ? ctx->h_records : d_list;
     res->n_records = n_records;
     res->candidates = ctx->h_cands.empty() ? nullptr : ctx->h_cands.data();

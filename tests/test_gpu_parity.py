@@ -165,33 +165,6 @@ def test_records_and_candidates_match_oracle(torch_cuda, streams, case, demod_va
         d.close()
 
 
-@pytest.mark.parametrize("demod_variant", [2, 3])
-@pytest.mark.parametrize("window_cap", ["0", "3", "4096"])
-def test_windows_and_stream_reads_agree(torch_cuda, streams, demod_variant, window_cap, monkeypatch):
-    """Stage 1 of both demodulation paths takes a forwarded position's samples from the window the scan kernel left for it
-    (round 5) or, beyond a run's window capacity, from the stream.  MODES_GPU_WINDOW_CAP forces every position onto the
-    stream path (0), nearly every one (3: the first three of a run come from windows - both sources inside one block of
-    positions) or none (4096); records and preamble positions equal the oracle's either way, on the message-dense capture,
-    on frames whose windows cross the ends of the span and on a stream in which every lane forwards."""
-    from dump1090_amd import Demodulator, ModesError
-    monkeypatch.setenv("MODES_GPU_WINDOW_CAP", window_cap)
-    for case in ("modes1", "edges", "frames", "saturated"):
-        data = streams[case]
-        iq = to_dev(torch_cuda, data)
-        for flags in (orc.FLAGSETS["aggressive"], orc.FLAGSETS["nofix"]):
-            mf = maxfix_of(flags)
-            d = Demodulator(keep_candidates=True, demod_variant=demod_variant, **flags)
-            d.detect(iq)
-            recs, cands, info = d.fetch()
-            want, want_cands = oracle_records(data, mf)
-            assert np.array_equal(cands, want_cands), (case, window_cap, "preamble positions")
-            assert_records_equal(recs, want, ctx=(case, mf, window_cap))
-            d.close()
-    monkeypatch.setenv("MODES_GPU_WINDOW_CAP", "many")
-    with pytest.raises(ModesError, match="MODES_GPU_WINDOW_CAP"):
-        Demodulator()
-
-
 def test_removed_demod_variant_is_refused(torch_cuda):
     from dump1090_amd import Demodulator, ModesError
     with pytest.raises(ModesError, match="demod_variant 1"):      # (an explicit variant is never overridden by the environment)
