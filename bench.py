@@ -99,6 +99,25 @@ def measured_traffic(mib):
         return None, "unreadable"
 
 
+def leg_traffic(kind):
+    """Committed PMC pass of a record-bearing leg (profiles/traffic_latest.json["legs"][kind], written by tools/profile.sh <tag>
+    lowsnr | frames + tools/merge_traffic.py): {kernel: HBM read bytes per launch}, or None when there is none for these kernel
+    sources.  The scan kernel's FETCH_SIZE carries the guide's x 2; the demodulation kernels' the factor measured on their own
+    access pattern (profiles/fetch_size_calibration.json)."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)["legs"][kind]
+        if t.get("kernel_source_sha256_16") != kernel_source_hash():
+            return None
+        # (the kernels of the leg's steady state: those the kernel trace saw in the timed region - the first calls of a context run the
+        #  one-kernel path before the record density is known)
+        return {k: int(v["hbm_read_bytes_per_launch"]) for k, v in t.items()
+                if isinstance(v, dict) and "hbm_read_bytes_per_launch" in v and v.get("trace_avg_us_timed_region")}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def fetch_bytes_per_launch(directory, kernel="scan_kernel"):
     """(HBM read bytes per launch, launches) from the counter_collection CSVs rocprofv3 left under `directory`: FETCH_SIZE is in
     KB and counts the 128-byte requests of 16 B-per-lane streaming reads as 64 bytes on gfx950 (the guide's correction: x 2).
@@ -636,6 +655,25 @@ def main():
             d["cpu_baseline"] = leg["cpu_baseline"]
         ksum = leg["calls_per_step"] * (leg["scan_ms"] + leg["demod_ms"] + leg["order_ms"])
         d["wall_over_kernels"] = round(d["ms_per_step"] / ksum, 3) if ksum > 0 else None
+        # the leg's own roofline: algorithmic bytes = 2 B per sample = this rank's bytes per step; `scan` prices the
+        # scan kernel's launches (HIP events), `step` the whole step (every kernel, the fetch and the resolve behind it: the leg's clock)
+        if leg["scan_ms"] > 0:
+            kind = name.split(":")[0].replace("BASELINE.json ", "")
+            tkind = "lowsnr" if "configs[4]" in kind else "frames"
+            # (the committed counter passes ran the weak legs' launch sizes: none for the strong leg's 7.1 GiB calls - same kernels, same
+            #  stream statistics as `frames`, whose ratio of traffic to algorithmic bytes applies)
+            tr = leg_traffic(tkind) if scaling == "weak" else None
+            per_launch = leg["call_bytes"]
+            a_scan = per_launch / (leg["scan_ms"] * 1e-3) / 1e9
+            a_step = leg["per_gpu"] / (d["ms_per_step"] * 1e-3) / 1e9
+            d["roofline"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "scan_kernel",
+                             "algorithmic_bytes_per_launch": int(per_launch), "algorithmic_bytes_per_step": int(leg["per_gpu"]),
+                             "achieved_scan": round(a_scan, 1), "frac_scan": round(a_scan / HBM_PEAK_GBS, 4),
+                             "achieved_step": round(a_step, 1), "frac_step": round(a_step / HBM_PEAK_GBS, 4),
+                             # HBM bytes per launch of every kernel of a call, from the committed counter pass of THIS workload
+                             "traffic": tr, "traffic_per_launch_total": sum(tr.values()) if tr else None,
+                             "traffic_source": ("profiles/traffic_latest.json legs.%s (rocprofv3 FETCH_SIZE passes of this workload on these "
+                                                "kernel sources; profiles/README.md)" % tkind) if tr else "no committed PMC pass of this workload for these kernel sources"}
         per_rank = gathered({"scan": round(leg["scan_ms"], 4), "demod": round(leg["demod_ms"], 4)})
         if rank == 0:
             d["msgs_per_s"] = round(leg["msgs"] / el, 1)

@@ -39,7 +39,7 @@ cd "$R"
 # launches in front of the timed region: the leg's settle steps (ceil(SETTLE / GiB per step), at least 6) + warmup... bench.py's
 # noise leg adds its warmup to --settle; the other legs settle max(6, ceil(settle / GiB)) steps of `calls` launches each
 case $WL in noise) SKIP=$((SETTLE + 2)) ;; lowsnr) SKIP=$SETTLE ;; frames) SKIP=60 ;; esac
-python tools/summarize_prof.py "$OUT" $SKIP > "$OUT/summary.txt" 2>&1
+python tools/summarize_prof.py "$OUT" $SKIP $WL > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 # keep the merge-back small: raw per-dispatch CSVs of the counter runs can be large
 find "$OUT" -name "*.csv" -size +4M -delete
