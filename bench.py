@@ -355,6 +355,10 @@ def ipc_probe(dist, torch, dev, rank, world, seconds=120.0):
         if time.perf_counter() - t0 > seconds:
             print("bench.py rank %d of %d: the first 64-byte isend/irecv ring did not complete in %.0f s (HSA_ENABLE_IPC_MODE_LEGACY=%s)" % (
                 rank, world, seconds, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset")), file=sys.stderr, flush=True)
+            # one machine-readable line for whoever keeps the log (the driver, tools/first_contact.sh): the failure path says what
+            # the success path's `rccl_start` object says
+            print(json.dumps({"rccl_start": dict(RCCL_START, failed="probe", rank=rank, world=world, probe_s=round(time.perf_counter() - t0, 1))}),
+                  file=sys.stderr, flush=True)
             mark = os.environ.get("MODES_PROBE_MARK")
             if mark:
                 open(mark, "w").close()
@@ -362,6 +366,11 @@ def ipc_probe(dist, torch, dev, rank, world, seconds=120.0):
         time.sleep(0.002)
     torch.cuda.synchronize(dev)
     assert bool((b == 0x5a).all()), "the probe ring delivered other bytes than were sent"
+    return time.perf_counter() - t0
+
+
+# How the process group came up (rank 0's view; in the JSON line as `rccl_start`, and on stderr when the start fails)
+RCCL_START = {"ipc_mode": None, "restarts": 0, "init_s": None, "probe_s": None}
 
 
 def parse_args(argv=None):
@@ -443,7 +452,10 @@ def main():
             other = "1" if os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" else "0"
             print("bench.py: the first transfer between the ranks did not complete with HSA_ENABLE_IPC_MODE_LEGACY=%s; starting over with %s" % (
                 os.environ["HSA_ENABLE_IPC_MODE_LEGACY"], other), file=sys.stderr, flush=True)
-            rc = subprocess.call(launcher_command(sys.argv[1:], args.gpus), env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=other))
+            rc = subprocess.call(launcher_command(sys.argv[1:], args.gpus), env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=other, MODES_IPC_RETRIED="1"))
+        if rc != 0:
+            print(json.dumps({"rccl_start": {"failed": "launcher status %d" % rc, "world": args.gpus,
+                                             "ipc_mode_tried_first": os.environ["HSA_ENABLE_IPC_MODE_LEGACY"]}}), file=sys.stderr, flush=True)
         sys.exit(rc)
 
     # stdout carries ONE line: the JSON.  Libraries write there too (RCCL prints a five-line version banner with printf when a
@@ -478,9 +490,17 @@ def main():
         # holding the node (not three: the first RCCL start on a fresh box has taken 60-100 s by itself)
         import datetime
         limit = datetime.timedelta(seconds=300)
+        RCCL_START.update(ipc_mode=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset"), restarts=1 if os.environ.get("MODES_IPC_RETRIED") else 0)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
-            ipc_probe(dist, torch, dev, rank, world)           # (a group of one sends to itself: the same calls on a one-GPU box)
+            t_init = time.perf_counter()
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
+            except Exception as e:                              # the rendezvous or the communicator: say it in one line, then fail as before
+                print(json.dumps({"rccl_start": dict(RCCL_START, failed="init_process_group: %s" % str(e)[:200], rank=rank, world=world,
+                                                     init_s=round(time.perf_counter() - t_init, 1))}), file=sys.stderr, flush=True)
+                raise
+            RCCL_START["init_s"] = round(time.perf_counter() - t_init, 3)
+            RCCL_START["probe_s"] = round(ipc_probe(dist, torch, dev, rank, world), 3)   # (a group of one sends to itself: the same calls on a one-GPU box)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=limit)
 
@@ -765,6 +785,8 @@ def main():
                      # (profiles/): its events read ~3 % above its own kernel durations (the dispatch's ~5 us lead-in)
                      "committed_trace_avg_ms": TRACE_AVG_MS, "committed_traffic": committed_traffic},
     }
+    if rank == 0 and dist_on:
+        line["rccl_start"] = dict(RCCL_START, backend=args.backend)
     if rank == 0 and world > 1:
         line["kernel_ms_per_rank"] = per_rank_kernels
     if rank == 0 and dist_on and noise is not None:

@@ -100,6 +100,9 @@ void show_help() {
         "--gpu-list <a,b,...>     The same with explicit ordinals; an ordinal may repeat (several contexts on one device).\n"
         "--ranks <n>              One PROCESS per GPU (this one forks n-1 more): rank r takes batches r, r+n, ... of a regular\n"
         "                         file on device r (or --gpu-list), the record lists are gathered to rank 0 over RCCL.\n"
+        "                         A pipe (--ifile -) and --loop have ONE reader: use --gpus <n> for them (one process, the same\n"
+        "                         devices).  --gpus <n> is also the faster of the two for any file below ~96 GB: a communicator\n"
+        "                         takes 1.6 s to start (a minute on a fresh box) before the first byte is read.\n"
         "--gather-records <n>     With --ranks: records per rank and round the gather buffers hold (default: 262144).\n"
         "--gather-candidates <n>  With --ranks --stats: preamble positions per rank and round (default: a batch's positions / 64).\n"
         "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).\n"
@@ -415,6 +418,13 @@ int run_ranks(const Options &opt, double t_start) {
     struct stat sb;
     if (fd == -1 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { perror("Opening data file"); return finish(1); }
     const size_t size = (size_t)sb.st_size;
+    // One process per GPU pays RCCL's start-up - 1.6-1.8 s warm, a minute or more on a fresh box (profiles/r06/rccl_init_time.txt) - before
+    // the first byte; one process driving all the devices (--gpus N) does not, and reads a file at ~50 GB/s (profiles/r06/e2e_cli.json).
+    // N readers at ~40 GB/s each win that time back only beyond kRanksPaysFromBytes (INTEGRATION.md 2b has the arithmetic): say so once.
+    constexpr double kRanksPaysFromBytes = 96e9;
+    if (rank == 0 && (double)size < kRanksPaysFromBytes && !getenv("MODES_RANKS_QUIET"))
+        fprintf(stderr, "--ranks %d: %.1f GiB is below the ~%.0f GB from which one process per GPU is faster than --gpus %d (one process, the same "
+                        "devices, no communicator to start)\n", N, size / 1073741824.0, kRanksPaysFromBytes / 1e9, N);
     const uint8_t *map = size ? static_cast<const uint8_t *>(mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0)) : nullptr;
     if (size && map == MAP_FAILED) { perror("mmap"); return finish(1); }
 

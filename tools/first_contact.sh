@@ -1,33 +1,65 @@
 #!/bin/bash
-# First contact with an N-GPU node (nothing of this has run on more than one device: every piece was proven on one GPU or on
-# CPU with stubs).  The exact sequence for the lease, cheapest and most telling first; every step has its own timeout, its log
-# under gpurun_out/first_contact/, and a line that says what a failure means.
-#   tools/first_contact.sh [N]            (default: every GPU of the box)
+# First contact with an N-GPU node (nothing of this has run on more than one device: every piece was proven on one GPU or on CPU with
+# stubs).  The exact sequence for the lease, cheapest and most telling first.  SELF-VERIFYING: every step has its own timeout, its log
+# under gpurun_out/first_contact/, prints PASS or FAIL (the md5 / listing comparison is part of the step, not left to the reader) and a
+# line that says what a failure means; the script ends with ONE JSON line the driver can keep and exits 0 only when everything passed.
+#   tools/first_contact.sh [N]            (default: every GPU of the box; N = 1 runs the same steps over a group of one)
 N=${1:-$(python -c "import torch; print(torch.cuda.device_count())")}
 R=$PWD
 O=$R/gpurun_out/first_contact
 mkdir -p "$O"
 export TMPDIR=/tmp
 export HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}      # dmabuf IPC (this pool's hosts support nothing else)
-step() { name=$1; limit=$2; shift 2; echo "== $name: $*"; ( time timeout $limit "$@" ) > "$O/$name.log" 2>&1; rc=$?; echo "   rc=$rc  $(grep -m1 '^{' "$O/$name.log" | cut -c1-300)"; return $rc; }
-means() { echo "   -> if this fails: $*"; }
+REF_RAW=4a81758c8bec5e45ffa8541c5622938a        # ./dump1090 --ifile testfiles/modes1.bin --raw (padded capture)
+REF_STATS=bc3d1c04b24f4989f0fc4a2d1f45abdd      # ... --stats
+EXE=dump1090_amd/bin/dump1090_amd
+STEPS=()
+FAILED=0
+record() { STEPS+=("{\"step\": \"$1\", \"pass\": $2, \"seconds\": $3, \"detail\": \"$4\"}"); [ "$2" = true ] && echo "   PASS  $1 ($3 s) $4" || { echo "   FAIL  $1 ($3 s) $4"; FAILED=$((FAILED + 1)); }; }
+means() { echo "         if this fails: $*"; }
+# run <name> <timeout> <command...>: log, wall seconds in $SECS, status in $RC
+run() { name=$1; limit=$2; shift 2; echo "== $name: $*"; t0=$(date +%s.%N); timeout $limit "$@" > "$O/$name.out" 2> "$O/$name.err"; RC=$?; SECS=$(python -c "import time; print('%.1f' % (time.time() - $t0))"); }
+# the JSON line a bench.py run printed (stdout), field by python expression on `d`
+jget() { python -c "
+import json, sys
+try:
+    d = json.loads([l for l in open('$1') if l.startswith('{')][-1])
+    print($2)
+except Exception as e:
+    print('unreadable: %s' % e)"; }
 
-step ranks2_small 400 dump1090_amd/bin/dump1090_amd --ifile tests/golden/modes1.bin --raw --ranks 2 --batch-blocks 1 --timing
-means "two PROCESSES, two devices, 3 batches: the unique id pipe, ncclCommInitRank across processes, the first ncclSend/ncclRecv between two GPUs." \
-      "'hipIpcGetMemHandle: invalid argument' = the IPC mode (try HSA_ENABLE_IPC_MODE_LEGACY=1); a hang that ends after 120 s with 'probe' = the" \
-      "communicator came up but the first transfer did not complete (xGMI / P2P access between the two devices)."
-md5=$(dump1090_amd/bin/dump1090_amd --ifile tests/golden/modes1.bin --raw --ranks 2 --batch-blocks 1 2>/dev/null | md5sum | cut -c1-32)
-echo "   --ranks 2 listing md5 $md5 (the reference's: 4a81758c8bec5e45ffa8541c5622938a)"
+echo "first contact: N = $N, HSA_ENABLE_IPC_MODE_LEGACY=$HSA_ENABLE_IPC_MODE_LEGACY, $(rocm-smi --showcomputepartition 2>/dev/null | grep -m1 'Compute Partition' | sed 's/.*: //') partition"
+NR=$((N < 2 ? N : 2))
 
-step bench2_frames 600 python bench.py --gpus 2 --workload frames --frames-mib 1024 --steps 10
-means "torch.distributed over RCCL with two ranks: init_process_group, the count all_gather, exact-size isend/irecv of device lists;" \
-      "the listing is checked against the analytic expectation inside (an assertion text names what differs)."
+run ranks${NR}_small 400 $EXE --ifile tests/golden/modes1.bin --raw --ranks $NR --batch-blocks 1 --timing
+md5=$(md5sum < "$O/ranks${NR}_small.out" | cut -c1-32)
+record ranks${NR}_small $([ $RC = 0 ] && [ "$md5" = $REF_RAW ] && echo true || echo false) $SECS "status $RC, listing md5 $md5 (reference $REF_RAW)"
+means "$NR PROCESS(ES), one device each, 3 batches: the unique id pipe, ncclCommInitRank across processes, the first ncclSend/ncclRecv between two GPUs." \
+      "'hipIpcGetMemHandle: invalid argument' = the IPC mode (the host restarts itself once with the other one: look for 'starting over' in the .err);" \
+      "'probe' after 120 s = the communicator came up but the first transfer did not complete (xGMI / P2P access between the two devices)."
 
-step bench${N}_frames 900 python bench.py --gpus $N --workload frames --steps 20
-means "the same at N = $N with BASELINE's 8 GiB per GPU (configs[3]): 7 lists per call to rank 0 over 7 links; listing == the committed" \
-      "reference md5.  rank0_resolve_ms_per_step against kernel_ms_per_step_max_rank says whether rank 0's host half bounds the step."
+run ranks${NR}_stats 400 $EXE --ifile tests/golden/modes1.bin --stats --ranks $NR --batch-blocks 1
+md5=$(md5sum < "$O/ranks${NR}_stats.out" | cut -c1-32)
+record ranks${NR}_stats $([ $RC = 0 ] && [ "$md5" = $REF_STATS ] && echo true || echo false) $SECS "status $RC, --stats md5 $md5 (reference $REF_STATS)"
+means "the gather's second list (every rank's preamble positions) - the same transfers as above with a second buffer."
 
-step bench${N}_all 1500 python bench.py --gpus $N --steps 20 --warmup 5
+run bench${NR}_frames 600 python bench.py --gpus $NR --workload frames --frames-mib 1024 --steps 10 $([ $NR = 1 ] && echo --force-gather)
+ok=$(jget "$O/bench${NR}_frames.out" "d['listing_check'].get('equals_reference_md5') in (True, None) and d['n_gpus'] == $NR and d['rccl']['p2p_ops_per_step'] > 0")
+record bench${NR}_frames $([ $RC = 0 ] && [ "$ok" = True ] && echo true || echo false) $SECS "status $RC, $(jget "$O/bench${NR}_frames.out" "'%.0f Msamples/s, %d msgs per step, rccl_start %s' % (d['value'], d['listing_check']['lines'], d.get('rccl_start'))")"
+means "torch.distributed over RCCL: init_process_group, the count all_gather, exact-size isend/irecv of device lists; the listing is checked" \
+      "inside (an assertion text names what differs); a start-up failure leaves a {\"rccl_start\": ...} line in the .err."
+
+if [ $N -gt 2 ]; then
+run bench${N}_frames 900 python bench.py --gpus $N --workload frames --steps 20
+ok=$(jget "$O/bench${N}_frames.out" "d['listing_check'].get('equals_reference_md5') is True and d['n_gpus'] == $N")
+record bench${N}_frames $([ $RC = 0 ] && [ "$ok" = True ] && echo true || echo false) $SECS "status $RC, $(jget "$O/bench${N}_frames.out" "'%.0f Msamples/s, listing == the reference md5: %s, rank0_resolve_ms_per_step %s vs kernels %s' % (d['value'], d['listing_check'].get('equals_reference_md5'), d.get('rank0_resolve_ms_per_step'), d.get('kernel_ms_per_step_max_rank'))")"
+means "the same at N = $N with BASELINE's 8 GiB per GPU (configs[3]): $((N - 1)) lists per call to rank 0 over $((N - 1)) links; rank0_resolve_ms_per_step" \
+      "against kernel_ms_per_step_max_rank says whether rank 0's host half bounds the step."
+fi
+
+run bench${N}_all 1500 python bench.py --gpus $N --steps 20 --warmup 5
+ok=$(jget "$O/bench${N}_all.out" "all(d[k]['listing_check'].get('equals_reference_md5') in (True, None) for k in ('frames', 'lowsnr', 'frames_strong')) and d['n_gpus'] == $N")
+record bench${N}_all $([ $RC = 0 ] && [ "$ok" = True ] && echo true || echo false) $SECS "status $RC, $(jget "$O/bench${N}_all.out" "'value %.0f Msamples/s over %d GPU(s); frames %.0f, low SNR %.0f, 64 GiB strong %.0f' % (d['value'], d['n_gpus'], d['frames']['Msamples_per_s'], d['lowsnr']['Msamples_per_s'], d['frames_strong']['Msamples_per_s'])")"
 means "the driver's command: every leg (noise, frames, low SNR, the 64 GiB stream at every N)."
 
 if [ -w /dev/shm ]; then
@@ -42,14 +74,17 @@ with open("/dev/shm/modes_fc.bin", "wb") as f:       # built on the GPU (the num
         iq, _ = bench.build_frames_shard(torch, dev, total_blocks, lo, lo + (1 << 30), seed=4)
         iq.cpu().numpy().tofile(f)
 PY
-  one=$(dump1090_amd/bin/dump1090_amd --ifile /dev/shm/modes_fc.bin --raw | md5sum | cut -c1-32)
-  step ranks${N}_file 600 dump1090_amd/bin/dump1090_amd --ifile /dev/shm/modes_fc.bin --raw --ranks $N --timing
-  many=$(dump1090_amd/bin/dump1090_amd --ifile /dev/shm/modes_fc.bin --raw --ranks $N 2>/dev/null | md5sum | cut -c1-32)
-  echo "   4 GiB of frames: one process md5 $one, --ranks $N md5 $many  $([ "$one" = "$many" ] && echo SAME || echo DIFFERENT)"
+  one=$($EXE --ifile /dev/shm/modes_fc.bin --raw | md5sum | cut -c1-32)
+  st1=$($EXE --ifile /dev/shm/modes_fc.bin --stats | md5sum | cut -c1-32)
+  run ranks${N}_file 600 $EXE --ifile /dev/shm/modes_fc.bin --raw --ranks $N --timing
+  many=$(md5sum < "$O/ranks${N}_file.out" | cut -c1-32)
+  record ranks${N}_file $([ $RC = 0 ] && [ "$one" = "$many" ] && echo true || echo false) $SECS "status $RC, 4 GiB of frames: one process md5 $one, --ranks $N md5 $many"
   means "the C host's one-process-per-GPU mode at full width: batches dealt round-robin, $N lists per round."
-  st=$(dump1090_amd/bin/dump1090_amd --ifile /dev/shm/modes_fc.bin --stats --ranks $N 2>/dev/null | md5sum | cut -c1-32)
-  st1=$(dump1090_amd/bin/dump1090_amd --ifile /dev/shm/modes_fc.bin --stats | md5sum | cut -c1-32)
-  echo "   --stats: one process $st1, --ranks $N $st  $([ "$st" = "$st1" ] && echo SAME || echo DIFFERENT)"
+  run ranks${N}_file_stats 600 $EXE --ifile /dev/shm/modes_fc.bin --stats --ranks $N
+  st=$(md5sum < "$O/ranks${N}_file_stats.out" | cut -c1-32)
+  record ranks${N}_file_stats $([ $RC = 0 ] && [ "$st" = "$st1" ] && echo true || echo false) $SECS "status $RC, --stats: one process $st1, --ranks $N $st"
   rm -f /dev/shm/modes_fc.bin
 fi
-echo "== done: logs in $O"
+echo "== logs in $O"
+echo "{\"first_contact\": {\"n_gpus\": $N, \"ipc_mode\": \"$HSA_ENABLE_IPC_MODE_LEGACY\", \"failed\": $FAILED, \"all_pass\": $([ $FAILED = 0 ] && echo true || echo false), \"steps\": [$(IFS=,; echo "${STEPS[*]}")]}}" | tee "$O/verdict.json"
+[ $FAILED = 0 ]
