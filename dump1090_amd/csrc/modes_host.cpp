@@ -181,7 +181,10 @@ void modes_host_decode(modes_host *h, const modes_attempt *att, struct modesMess
     static const char ais[] = "?ABCDEFGHIJKLMNOPQRSTUVWXYZ????? ???????????????0123456789??????";
     // The reference leaves the fields a message type does not use uninitialised (mm is a stack
     // variable, :1732); zero them so the struct is a function of the input.
-    if (!h->lean) memset(mm, 0, sizeof *mm);                                      // (lean: every field read afterwards is assigned below)
+    // Lean mode (the --raw sinks of this file, which read msg / msgbits / crcok / the address bytes only) skips the memset AND the
+    // per-type fields: modes_host_resolve zeroes its modesMessage ONCE per call instead, so a sink that does read another field in
+    // lean mode sees zeros or an earlier message's value of that field, never the stack's bytes.
+    if (!h->lean) memset(mm, 0, sizeof *mm);
     memcpy(mm->msg, att->msg, MODES_LONG_MSG_BYTES);
     unsigned char *msg = mm->msg;
 
@@ -321,6 +324,8 @@ uint64_t modes_host_resolve(modes_host *h, const modes_record *recs, uint64_t nr
     uint32_t cur_block = 0xffffffffu;
     uint32_t skip_to = 0;                 // first block-local offset the scan visits again
     if (cands) h->have_candidates = true;
+    struct modesMessage mm;               // one for the whole call, zeroed here: lean decodes (modes_host_decode) leave the fields
+    memset(&mm, 0, sizeof mm);            // they do not compute alone, and no sink may ever see the stack's bytes in them
 
     auto next_is_candidate_only = [&]() -> bool {
         if (!cands || ci >= ncand) return false;
@@ -350,8 +355,8 @@ uint64_t modes_host_resolve(modes_host *h, const modes_record *recs, uint64_t nr
             if (!a.gate_ok) break;                                                // :1723-1726 (no retry)
             bool good = false;
             if (a.errors == 0 || (h->cfg.aggressive && a.errors < 3)) {           // :1731
-                struct modesMessage mm;
                 modes_host_decode(h, &a, &mm);
+                mm.phase_corrected = 0;                                           // (set below for this attempt only; the full decode zeroes it anyway)
                 if (mm.crcok || pass == 1) {                                      // :1738-1753
                     if (a.errors == 0) h->st.demodulated++;
                     if (mm.errorbit == -1) {
@@ -539,7 +544,9 @@ void run_piece(Piece &p) {
     const modes_record *recs = p.recs;
     p.log = IcaoLog{};
     p.text.clear();
-    p.text.reserve((size_t)(p.hi - p.lo) * 31 + 64);                              // a line per record at most: no regrowth while appending
+    // (a hint, not a bound: one line per record is the common case - with check_crc off both attempts of a record reach the sink and a
+    //  record prints two lines; the string grows then)
+    p.text.reserve((size_t)(p.hi - p.lo) * 31 + 64);
     p.host.st = modes_host_stats{};
     p.host.have_candidates = false;
     p.host.log = &p.log;
