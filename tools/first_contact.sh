@@ -28,7 +28,7 @@ try:
 except Exception as e:
     print('unreadable: %s' % e)"; }
 
-echo "first contact: N = $N, HSA_ENABLE_IPC_MODE_LEGACY=$HSA_ENABLE_IPC_MODE_LEGACY, $(rocm-smi --showcomputepartition 2>/dev/null | grep -m1 'Compute Partition' | sed 's/.*: //') partition"
+echo "first contact: N = $N, HSA_ENABLE_IPC_MODE_LEGACY=$HSA_ENABLE_IPC_MODE_LEGACY, $(rocm-smi --showcomputepartition 2>/dev/null | grep -m1 'GPU\[' | sed 's/.*: //') partition"
 NR=$((N < 2 ? N : 2))
 
 run ranks${NR}_small 400 $EXE --ifile tests/golden/modes1.bin --raw --ranks $NR --batch-blocks 1 --timing
