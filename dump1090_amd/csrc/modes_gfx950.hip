@@ -647,10 +647,21 @@ __device__ __forceinline__ int mag_of(const Lut lut, uint32_t iq16) {
     return lut[modes_lut_index(iq16 & 0xff, (iq16 >> 8) & 0xff)];
 }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+// Sum / XOR over the wavefront (every lane active), the result in every lane - in fact in a scalar register.  Four DPP steps leave
+// every lane of a row of 16 with its row's value (quad butterflies, then the mirrored half row and the mirrored row), four
+// v_readlane collect the rows: ~80 cycles.  (__shfl_xor compiles to ds_bpermute_b32, a round trip through the LDS crossbar per
+// step: six of them per reduction, ~24 reductions per record - a quarter of record_kernel's time, which is one dependent chain per
+// wavefront; profiles/r08/ab_record_kernel.txt.)
+__device__ __forceinline__ int wave_rows_sum(int v) {
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);                  // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);                  // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);                 // row_half_mirror
+    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true);                 // row_mirror
     return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+    v = wave_rows_sum(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
 // bits of `mask` below this lane (v_mbcnt: no per-lane mask register to keep alive)
@@ -668,9 +679,12 @@ __device__ __forceinline__ bool m128_bit(modes_m128 m, int k) {      // k may be
 
 // XOR over the wavefront.
 __device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v ^= (uint32_t)__shfl_xor((int)v, off, 64);
-    return v;
+    int x = (int)v;
+    x ^= __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true);
+    x ^= __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true);
+    x ^= __builtin_amdgcn_mov_dpp(x, 0x141, 0xf, 0xf, true);
+    x ^= __builtin_amdgcn_mov_dpp(x, 0x140, 0xf, 0xf, true);
+    return (uint32_t)(__builtin_amdgcn_readlane(x, 0) ^ __builtin_amdgcn_readlane(x, 16) ^ __builtin_amdgcn_readlane(x, 32) ^ __builtin_amdgcn_readlane(x, 48));
 }
 
 // Syndrome and repair lookup of one attempt by the whole wavefront (dump1090.c:1104, 1112-1117, 854-880).
@@ -886,19 +900,34 @@ struct Front {
     modes_m128 bits0;
     uint8_t err0;
 };
-template <bool GUARD, class Lut>
-__device__ __forceinline__ Front demod_front(const DemodParams &P, const Lut lut, int lane, int64_t pc, uint32_t known56,
-                                             uint32_t known112) {
+// The samples of one preamble's message window as the wavefront loads them (raw I | Q << 8): lane L holds bit pairs k1 = L and
+// k2 = L + 64 (samples 16 + 2 k, 17 + 2 k) and, lanes 0 .. 11, sample L - 1 of the preamble.  Loading and evaluating are separate so
+// that record_kernel can have the NEXT record's loads in flight while it demodulates the current one.
+struct FrontRaw {
+    uint32_t lo1, hi1, lo2, hi2, pre;
+};
+template <bool GUARD>
+__device__ __forceinline__ FrontRaw front_load(const DemodParams &P, int lane, int64_t pc) {
     const uint8_t *iq = P.iq;
     const int64_t lo = P.lo, hi = P.hi;
     const bool two = lane < 48;
+    FrontRaw r;
+    r.lo1 = load_sample<GUARD>(iq, pc + 16 + 2 * lane, lo, hi);
+    r.hi1 = load_sample<GUARD>(iq, pc + 17 + 2 * lane, lo, hi);
+    r.lo2 = two ? load_sample<GUARD>(iq, pc + 144 + 2 * lane, lo, hi) : 0x7f7fu;
+    r.hi2 = two ? load_sample<GUARD>(iq, pc + 145 + 2 * lane, lo, hi) : 0x7f7fu;
+    r.pre = (lane < 12) ? load_sample<GUARD>(iq, pc - 1 + lane, lo, hi) : 0x7f7fu;
+    return r;
+}
+template <class Lut>
+__device__ __forceinline__ Front front_eval(const Lut lut, int lane, const FrontRaw &r, uint32_t known56, uint32_t known112) {
+    const bool two = lane < 48;
     Front f;
-    // lane L: pairs k1 = L, k2 = L+64 -> samples 16+2k, 17+2k; lanes 0..11 also m[-1..10]
-    f.lo1 = mag_of(lut, load_sample<GUARD>(iq, pc + 16 + 2 * lane, lo, hi));
-    f.hi1 = mag_of(lut, load_sample<GUARD>(iq, pc + 17 + 2 * lane, lo, hi));
-    f.lo2 = two ? mag_of(lut, load_sample<GUARD>(iq, pc + 144 + 2 * lane, lo, hi)) : 0;
-    f.hi2 = two ? mag_of(lut, load_sample<GUARD>(iq, pc + 145 + 2 * lane, lo, hi)) : 0;
-    f.pre = (lane < 12) ? mag_of(lut, load_sample<GUARD>(iq, pc - 1 + lane, lo, hi)) : 0;
+    f.lo1 = mag_of(lut, r.lo1);
+    f.hi1 = mag_of(lut, r.hi1);
+    f.lo2 = two ? mag_of(lut, r.lo2) : 0;
+    f.hi2 = two ? mag_of(lut, r.hi2) : 0;
+    f.pre = (lane < 12) ? mag_of(lut, r.pre) : 0;
     f.sum56 = (int)known56;
     f.sum112 = (int)known112;
     f.have112 = known112 != kUnknown;
@@ -909,17 +938,22 @@ __device__ __forceinline__ Front demod_front(const DemodParams &P, const Lut lut
     f.gate0 = long0 ? (f.sum112 / 56 >= 2550) : (f.sum56 / 28 >= 2550);     // dump1090.c:1717-1723
     return f;
 }
+template <bool GUARD, class Lut>
+__device__ __forceinline__ Front demod_front(const DemodParams &P, const Lut lut, int lane, int64_t pc, uint32_t known56,
+                                             uint32_t known112) {
+    return front_eval(lut, lane, front_load<GUARD>(P, lane, pc), known56, known112);
+}
 
 // Full demodulation (both attempts) -> the record in staging slot `slot`, keyed `key`.  Returns false when the first
 // noise gate fails after all (then nothing is written; the caller has already ruled that out for its entries).
-template <bool GUARD, bool KEYED = true, class Lut>
-__device__ __forceinline__ bool demod_full(const DemodParams &P, const Lut lut, const uint32_t *s_esyn, int lane, int64_t pc,
-                                           uint32_t known56, uint32_t known112, uint32_t slot, uint64_t key,
+template <bool KEYED = true, class Lut>
+__device__ __forceinline__ bool demod_rest(const DemodParams &P, const Lut lut, const uint32_t *s_esyn, int lane, int64_t pc,
+                                           const FrontRaw &raw, uint32_t known56, uint32_t known112, uint32_t slot, uint64_t key,
                                            modes_record *host_rec = nullptr) {
     const uint64_t g = (uint64_t)pc + P.g0;
     const uint32_t j = (uint32_t)(g & (MODES_BLOCK_STRIDE - 1));
     const bool two = lane < 48;
-    Front f = demod_front<GUARD>(P, lut, lane, pc, known56, known112);
+    Front f = front_eval(lut, lane, raw, known56, known112);
     if (!f.gate0) return false;                                              // dump1090.c:1723-1726: position ends
     const int lo1 = f.lo1, hi1 = f.hi1, lo2 = f.lo2, hi2 = f.hi2, pre = f.pre;
     const modes_m128 bits0 = f.bits0;
@@ -979,6 +1013,12 @@ __device__ __forceinline__ bool demod_full(const DemodParams &P, const Lut lut, 
         if (KEYED && lane == 0) P.keys[slot] = key;
     }
     return true;
+}
+template <bool GUARD, bool KEYED = true, class Lut>
+__device__ __forceinline__ bool demod_full(const DemodParams &P, const Lut lut, const uint32_t *s_esyn, int lane, int64_t pc,
+                                           uint32_t known56, uint32_t known112, uint32_t slot, uint64_t key,
+                                           modes_record *host_rec = nullptr) {
+    return demod_rest<KEYED>(P, lut, s_esyn, lane, pc, front_load<GUARD>(P, lane, pc), known56, known112, slot, key, host_rec);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1648,9 +1688,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(80))) void reco
     const DemodParams &P = R.d;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // sum of batch_count[from, to) over the workgroup (to - from <= 512: the grid never exceeds 512 workgroups)
-    auto count_sum = [&](uint32_t from, uint32_t to) -> uint32_t {
-        uint32_t v = from + (uint32_t)tid < to ? R.batch_count[from + (uint32_t)tid] : 0u;
+#ifdef MODES_TRACE
+    const unsigned long long t_start = wall_clock64();
+    unsigned long long tr_counts = 0, tr_table = 0, tr_records = 0, tr_n = 0, tr_nb = 0;     // (second half of g_trace: select_kernel has the first)
+#endif
+    // sum over the workgroup of one value per thread (batch_count[from + tid], from <= .. < to: to - from <= 512, the grid never exceeds
+    // 512 workgroups)
+    auto count_reduce = [&](uint32_t v) -> uint32_t {
         v = (uint32_t)wave_sum((int)v);
         __syncthreads();                                                     // s_red of the previous call has been read
         if (lane == 0) s_red[wave] = v;
@@ -1660,34 +1704,72 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(80))) void reco
         for (int w = 0; w < 8; w++) all += s_red[w];
         return all;
     };
+    // the samples of the record at buffer sample pc (wave-uniform): plain loads when its window is inside the span
+    auto load_front = [&](int64_t pc) -> FrontRaw {
+        return samples_inside(pc - 1, pc + 239, P.lo, P.hi) ? front_load<false>(P, lane, pc) : front_load<true>(P, lane, pc);
+    };
     if (tid == 0) s_bad = 0;
     bool staged = false;
     uint32_t off = 0, prev = 0;                                              // records in front of batch `prev`
     for (uint32_t batch = blockIdx.x; batch < P.nbatches; batch += gridDim.x) {
-        off += count_sum(prev, batch);
-        prev = batch;
+        // Everything a wavefront needs to start is requested TOGETHER: the batch's count, the counts in front of it, and the positions
+        // of the wavefront's first two records (their slots exist whatever the count is) - one round trip to memory, then the first
+        // record's samples together with the table: two in front of the first demodulation instead of five (round 5).
+        const uint64_t list_base = (uint64_t)batch * kDemodGroup * P.slot_cap;
         const uint32_t nb = R.batch_count[batch];
+        uint32_t r = (uint32_t)wave;
+        uint32_t p0 = R.surv[list_base + r], p1 = R.surv[list_base + r + 8];
+        TRACE_T(tc0);
+        off += count_reduce(prev + (uint32_t)tid < batch ? R.batch_count[prev + (uint32_t)tid] : 0u);
+        prev = batch;
+#ifdef MODES_TRACE
+        tr_counts += wall_clock64() - tc0; tr_nb += nb;
+#endif
         if (nb == 0) continue;                                               // workgroup-uniform: noise ends here, before any table is staged
+        FrontRaw raw0 = FrontRaw{0x7f7fu, 0x7f7fu, 0x7f7fu, 0x7f7fu, 0x7f7fu};
+        if (r < nb) raw0 = load_front((int64_t)p0);
+        TRACE_T(tt0);
         if (!staged) {
             stage_lut<512>(s_lut, P.tab.lut);
             for (int i = tid; i < kSynWords; i += 512) s_esyn[i] = P.tab.esyn[i];
             __syncthreads();
             staged = true;
         }
+#ifdef MODES_TRACE
+        tr_table += wall_clock64() - tt0;
+        const unsigned long long tr0 = wall_clock64();
+#endif
         const LutFull lut{s_lut};
-        const uint64_t list_base = (uint64_t)batch * kDemodGroup * P.slot_cap;
-        for (uint32_t r = (uint32_t)wave; r < nb; r += 8) {
-            const int64_t pc = (int64_t)R.surv[list_base + r];
+        // one wavefront per record, software-pipelined: while record r is demodulated the samples of the wavefront's next record
+        // (r + 8) and the position of the one after (r + 16) are already on their way
+        for (; r < nb; r += 8) {
+            const uint32_t p2 = r + 16 < nb ? R.surv[list_base + r + 16] : 0u;
+            FrontRaw raw1 = raw0;
+            if (r + 8 < nb) raw1 = load_front((int64_t)p1);
             const uint32_t slot = off + r;                                   // its place in the ordered list
-            // demod_full writes P.staging[slot] (here: the ordered list itself) and P.keys[slot]: keys are not used on this path
+            // demod_rest writes P.staging[slot] (here: the ordered list itself); keys are not used on this path.
             // the first direct_cap records also go to the host's pinned copy (a short list needs no copy operation then)
             modes_record *host_rec = (R.host_out && slot < R.direct_cap) ? &R.host_out[slot] : nullptr;
-            bool done;
-            if (samples_inside(pc - 1, pc + 239, P.lo, P.hi)) done = demod_full<false, false>(P, lut, s_esyn, lane, pc, kUnknown, kUnknown, slot, 0, host_rec);
-            else                                              done = demod_full<true, false>(P, lut, s_esyn, lane, pc, kUnknown, kUnknown, slot, 0, host_rec);
+            const bool done = demod_rest<false>(P, lut, s_esyn, lane, (int64_t)p0, raw0, kUnknown, kUnknown, slot, 0, host_rec);
             if (!done && lane == 0) atomicOr(&s_bad, 2u);
+            p0 = p1; p1 = p2; raw0 = raw1;
+#ifdef MODES_TRACE
+            tr_n++;
+#endif
+        }
+#ifdef MODES_TRACE
+        tr_records += wall_clock64() - tr0;
+#endif
+    }
+#ifdef MODES_TRACE
+    if (lane == 0) {
+        const uint32_t w = blockIdx.x * 8 + (uint32_t)wave;
+        if (w < 4096) {
+            unsigned long long *tr = &g_trace[8 * (4096 + w)];
+            tr[0] = t_start; tr[1] = tr_counts; tr[2] = wall_clock64(); tr[3] = tr_n; tr[4] = tr_table; tr[5] = tr_records; tr[6] = tr_nb; tr[7] = 0;
         }
     }
+#endif
     __syncthreads();
     if (tid == 0) R.wg_flags[blockIdx.x] = s_bad;
 }
