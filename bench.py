@@ -422,8 +422,8 @@ def parse_args(argv=None):
                          "all_gather, the list sent to itself through isend / irecv) - exercises the RCCL calls on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
-    ap.add_argument("--leg-streams", type=int, default=1, help="launch streams of the frames / lowsnr / strong legs (their calls that "
-                    "carry timing events run alone either way)")
+    ap.add_argument("--leg-streams", type=int, default=0, help="launch streams of the frames / lowsnr / strong legs; 0 (default): two for legs "
+                    "whose calls are at most 2 GiB, one for bigger calls (the kernels are timed in a one-stream region of their own either way)")
     ap.add_argument("--call-blocks", type=int, default=32767, help="buffers per GPU call of the frames / strong legs (at most 32767 = "
                     "8 GiB - 256 KiB; the same number of calls on every rank)")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC pass only: no child "
@@ -577,7 +577,23 @@ def main():
         # steps of the 1 GiB workload; a leg with G GiB per step and GPU gets ceil(settle / G) of its own steps, at least 6.
         gib_per_step = max((hi - lo) / 2 ** 30, 1e-3)
         settle_steps = max(6, int(-(-args.settle // gib_per_step)))
-        res = leg(iq_f, lo, calls, flags, steps, settle_steps, cap_records, max(1, args.leg_streams), True)
+        # Like the headline leg: the THROUGHPUT region runs on --leg-streams launch streams with no event in them (2 since round 5: the
+        # scan of call i + 1 fills the tail of call i's demodulation kernels - low SNR 0.2448 -> 0.2370 ms per step, frames 1.8475 ->
+        # 1.8335; profiles/r08/leg_streams_ab.txt), and the kernels are timed in a short region of their own on ONE stream (one call in
+        # four carries events: every kernel alone, at sustained clocks) - two regions, one listing check.
+        # (0 = automatic: two for calls of up to 2 GiB - the next scan has a tail to fill - one for bigger calls, whose kernels are long enough
+        #  to leave nothing to fill and whose big record copies only get in each other's way: frames 1.861 / 1.866 ms on one stream, 1.894 / 2.203 on two)
+        # (decided from rank-independent numbers: the launch streams set the order in which a rank issues its collectives)
+        nls = args.leg_streams if args.leg_streams > 0 else (2 if total_bytes // world // len(calls) <= (2 << 30) else 1)
+        res = leg(iq_f, lo, calls, flags, steps, settle_steps, cap_records, nls, nls == 1)
+        if nls > 1:
+            tsteps = max(4, -(-48 // len(calls)))                # ~48 calls, 12 of them timed
+            # (settled like every region: the pause between two regions - the resolver drains, contexts are torn down and made - restarts
+            #  the chip's clock transient)
+            kt = leg(iq_f, lo, calls, flags, tsteps, settle_steps, cap_records, 1, True, time_every=4)
+            res.update(scan_ms=kt["scan_ms"], demod_ms=kt["demod_ms"], order_ms=kt["order_ms"], scan_ms_median=kt["scan_ms_median"],
+                       timed_calls=kt["timed_calls"], kernel_steps=tsteps,
+                       kernel_timing="a region of %d steps of the same workload on ONE launch stream, HIP events on one call in 4" % tsteps)
         res.update(total=total_bytes, span=hi - lo, per_gpu=total_bytes // world, settle_steps=settle_steps)
         if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "strong":     # (strong: the frames leg's stream at another seed)
             # the compiled reference on the first GiB of THIS leg's stream, with this leg's flags ("for >= 8 GiB
@@ -668,7 +684,8 @@ def main():
         d = {"workload": name, "scaling": scaling, "Msamples_per_s": round(samples_per_step * steps / el / 1e6, 1),
              "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "calls_per_step": leg["calls_per_step"],
              "bytes_per_gpu": leg["per_gpu"],
-             "kernel_ms": {"scan": round(leg["scan_ms"], 4), "demod": round(leg["demod_ms"], 4), "order": round(leg["order_ms"], 4)},
+             "kernel_ms": {"scan": round(leg["scan_ms"], 4), "demod": round(leg["demod_ms"], 4), "order": round(leg["order_ms"], 4),
+                           "measured_in": leg.get("kernel_timing", "the timed region")},
              "records_per_step_rank0": int(leg["last"].get("n_records", 0)), "host_ms_per_call": leg.get("host_ms_per_call"),
              "settle_steps": leg.get("settle_steps")}
         if leg.get("cpu_baseline") is not None:
@@ -771,10 +788,10 @@ def main():
         "forwarded_per_step_rank0": int(head["last"].get("n_forwarded", 0)),
         "kernel_ms": {"scan": round(kern["scan_ms"], 4), "demod": round(kern["demod_ms"], 4), "order": round(kern["order_ms"], 4),
                       "scan_median": round(kern["scan_ms_median"], 4),
-                      "timed_calls": kern["timed_calls"], "of_calls": kern["steps"] * kern["calls_per_step"],
+                      "timed_calls": kern["timed_calls"], "of_calls": kern.get("kernel_steps", kern["steps"]) * kern["calls_per_step"],
                       "measured_in": "a region of %d steps of the same workload on ONE launch stream, HIP events on one call in 4 (every "
                                      "kernel alone; averages over the timed calls)" % kern["steps"] if kern is not head
-                      else "the timed region"},
+                      else kern.get("kernel_timing", "the timed region")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": "scan_kernel", "algorithmic_bytes_per_launch": int(kern["call_bytes"]),
