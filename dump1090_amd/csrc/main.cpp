@@ -22,8 +22,9 @@
 //
 // --ranks N is the other way to use N GPUs (north_star's): ONE PROCESS PER GPU - this program forks N - 1 copies of
 // itself - and the record lists travel to rank 0 from device memory over RCCL / xGMI (libmodes_gather.so, loaded on demand):
-// rank r demodulates batches r, r + N, r + 2N, ... of the (regular) file, round g of the gather carries batches
-// gN .. gN + N - 1, so rank order is stream order and rank 0 resolves and prints every round as it arrives (run_ranks).
+// rank r demodulates batches r, r + N, r + 2N, ... of the stream, round g of the gather carries batches
+// gN .. gN + N - 1, so rank order is stream order and rank 0 resolves and prints every round as it arrives (run_ranks).  A regular
+// file is mapped by every rank; a pipe or --loop is read by rank 0 alone, which deals the batches out through shared memory.
 
 #include <atomic>
 #include <cerrno>
@@ -100,9 +101,9 @@ void show_help() {
         "--gpu-list <a,b,...>     The same with explicit ordinals; an ordinal may repeat (several contexts on one device).\n"
         "--ranks <n>              One PROCESS per GPU (this one forks n-1 more): rank r takes batches r, r+n, ... of a regular\n"
         "                         file on device r (or --gpu-list), the record lists are gathered to rank 0 over RCCL.\n"
-        "                         A pipe (--ifile -) and --loop have ONE reader: use --gpus <n> for them (one process, the same\n"
-        "                         devices).  --gpus <n> is also the faster of the two for any file below ~96 GB: a communicator\n"
-        "                         takes 1.6 s to start (a minute on a fresh box) before the first byte is read.\n"
+        "                         A pipe (--ifile -) and --loop have ONE reader: rank 0 reads and hands every rank its batches\n"
+        "                         through shared memory.  --gpus <n> (one process, the same devices) is the faster of the two for\n"
+        "                         any input below ~96 GB: a communicator takes 1.6 s to start (a minute on a fresh box).\n"
         "--gather-records <n>     With --ranks: records per rank and round the gather buffers hold (default: 262144).\n"
         "--gather-candidates <n>  With --ranks --stats: preamble positions per rank and round (default: a batch's positions / 64).\n"
         "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).\n"
@@ -294,13 +295,30 @@ bool read_all(int fd, void *p, size_t n) {
 
 int run_ranks(const Options &opt, double t_start) {
     const int N = opt.ranks;
-    // Every rank maps the file and takes its own batches: a pipe or an endless replay has one reader, and dealing its bytes
-    // out to N processes would put a host-side copy in front of every GPU - that input is what --gpus N (one process, one
-    // reader, N devices) is for.
-    if (opt.loop || opt.filename == "-") {
-        fprintf(stderr, "--ranks reads a regular file (every rank maps its own batches); for %s use --gpus %d: one process, one reader, the same %d GPUs\n",
-                opt.loop ? "--loop" : "--ifile -", N, N);
-        return 1;
+    // A regular file is mapped by every rank, which takes its own batches.  A pipe (--ifile -) or an endless replay (--loop) has ONE reader:
+    // rank 0 reads it on a thread of its own into slots of a shared mapping made before the fork (one slot per rank and batch in flight:
+    // batch b belongs to rank b mod N), and rank r copies its batch from its slot to its pinned buffer exactly as it would copy it out of a
+    // file mapping - one read() more per byte than the file path, in front of N PCIe links (round 5; before: refused, --gpus N named).
+    const bool feed = opt.loop || opt.filename == "-";
+    const int depth = std::max(3, opt.depth);        // three stages are in flight per rank (round q submits, q - 1 exchanges, q - 2 is resolved)
+    const size_t batch_bytes = (size_t)opt.batch_blocks * MODES_DATA_LEN;
+    struct FeedSlot { std::atomic<uint64_t> seq; uint64_t nbytes; };           // seq: 0 = free, b + 1 = holds batch b (carry + nbytes new bytes)
+    struct FeedHead { std::atomic<uint64_t> total; std::atomic<int> failed; };  // total: batches of the stream, ~0 until the reader has seen the end
+    const size_t slot_bytes = (MODES_CARRY_BYTES + batch_bytes + 4095) & ~(size_t)4095;
+    const size_t nslots = (size_t)N * (size_t)depth;
+    uint8_t *feed_mem = nullptr;
+    FeedHead *feed_head = nullptr;
+    FeedSlot *feed_slots = nullptr;
+    if (feed) {
+        const size_t ctl = (sizeof(FeedHead) + nslots * sizeof(FeedSlot) + 4095) & ~(size_t)4095;
+        void *m = mmap(nullptr, ctl + nslots * slot_bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) { perror("--ranks: shared buffers"); return 1; }
+        feed_head = new (m) FeedHead;
+        feed_head->total.store(~0ull);
+        feed_head->failed.store(0);
+        feed_slots = reinterpret_cast<FeedSlot *>(static_cast<uint8_t *>(m) + sizeof(FeedHead));
+        for (size_t i = 0; i < nslots; i++) { new (&feed_slots[i]) FeedSlot; feed_slots[i].seq.store(0); feed_slots[i].nbytes = 0; }
+        feed_mem = static_cast<uint8_t *>(m) + ctl;
     }
     if (!opt.devices.empty() && (int)opt.devices.size() != N) { fprintf(stderr, "--ranks %d with a --gpu-list of %zu devices\n", N, opt.devices.size()); return 1; }
     // this pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffers fail (hipIpcGetMemHandle:
@@ -414,22 +432,29 @@ int run_ranks(const Options &opt, double t_start) {
         close(rd[(size_t)rank]);
     }
     const int device = opt.devices.empty() ? rank : opt.devices[(size_t)rank];
-    const int fd = open(opt.filename.c_str(), O_RDONLY);
-    struct stat sb;
-    if (fd == -1 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { perror("Opening data file"); return finish(1); }
-    const size_t size = (size_t)sb.st_size;
-    // One process per GPU pays RCCL's start-up - 1.6-1.8 s warm, a minute or more on a fresh box (profiles/r06/rccl_init_time.txt) - before
-    // the first byte; one process driving all the devices (--gpus N) does not, and reads a file at ~50 GB/s (profiles/r06/e2e_cli.json).
-    // N readers at ~40 GB/s each win that time back only beyond kRanksPaysFromBytes (INTEGRATION.md 2b has the arithmetic): say so once.
-    constexpr double kRanksPaysFromBytes = 96e9;
-    if (rank == 0 && (double)size < kRanksPaysFromBytes && !getenv("MODES_RANKS_QUIET"))
-        fprintf(stderr, "--ranks %d: %.1f GiB is below the ~%.0f GB from which one process per GPU is faster than --gpus %d (one process, the same "
-                        "devices, no communicator to start)\n", N, size / 1073741824.0, kRanksPaysFromBytes / 1e9, N);
-    const uint8_t *map = size ? static_cast<const uint8_t *>(mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0)) : nullptr;
-    if (size && map == MAP_FAILED) { perror("mmap"); return finish(1); }
+    int fd = -1;
+    size_t size = 0;
+    const uint8_t *map = nullptr;
+    if (!feed) {
+        fd = open(opt.filename.c_str(), O_RDONLY);
+        struct stat sb;
+        if (fd == -1 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { perror("Opening data file"); return finish(1); }
+        size = (size_t)sb.st_size;
+        // One process per GPU pays RCCL's start-up - 1.6-1.8 s warm, a minute or more on a fresh box (profiles/r06/rccl_init_time.txt) -
+        // before the first byte; one process driving all the devices (--gpus N) does not, and reads a file at ~50 GB/s
+        // (profiles/r06/e2e_cli.json).  N readers at ~40 GB/s each win that time back only beyond kRanksPaysFromBytes (INTEGRATION.md 2b has
+        // the arithmetic): say so once.
+        constexpr double kRanksPaysFromBytes = 96e9;
+        if (rank == 0 && (double)size < kRanksPaysFromBytes && !getenv("MODES_RANKS_QUIET"))
+            fprintf(stderr, "--ranks %d: %.1f GiB is below the ~%.0f GB from which one process per GPU is faster than --gpus %d (one process, the "
+                            "same devices, no communicator to start)\n", N, size / 1073741824.0, kRanksPaysFromBytes / 1e9, N);
+        map = size ? static_cast<const uint8_t *>(mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0)) : nullptr;
+        if (size && map == MAP_FAILED) { perror("mmap"); return finish(1); }
+    } else if (rank == 0) {
+        fd = opt.filename == "-" ? 0 : open(opt.filename.c_str(), O_RDONLY);
+        if (fd == -1) { perror("Opening data file"); return finish(1); }
+    }
 
-    // three stages are in flight per rank (round q submits, q - 1 exchanges, q - 2 is resolved): at least three sets of buffers
-    const int depth = std::max(3, opt.depth);
     // --stats: the preamble positions of every batch travel to rank 0 with its records (the second list of the gather)
     const uint64_t batch_positions = opt.batch_blocks * (uint64_t)MODES_BLOCK_STRIDE;
     const uint32_t cap_cands = !opt.stats ? 0u : opt.gather_cands ? opt.gather_cands : (uint32_t)std::max<uint64_t>(4096, batch_positions / 64);
@@ -448,7 +473,6 @@ int run_ranks(const Options &opt, double t_start) {
         return finish(1);
     }
     const double t_comm = now_s();
-    const size_t batch_bytes = (size_t)opt.batch_blocks * MODES_DATA_LEN;
     std::vector<Lane> lanes((size_t)depth);
     for (int l = 0; l < depth; l++) {
         modes_gpu_config cfg{};
@@ -477,24 +501,85 @@ int run_ranks(const Options &opt, double t_start) {
 
     // Batch b of the stream (the single-process host's geometry: a short - possibly empty - batch ends the stream and
     // carries the EOF buffer, dump1090.c:484-510); round q of the gather = batches qN .. qN + N - 1, rank r takes batch qN + r.
-    const uint64_t nbatches = size / batch_bytes + 1;
-    const uint64_t nrounds = (nbatches + (uint64_t)N - 1) / (uint64_t)N;
+    // A file's batches are known from its size; a fed stream's (pipe, --loop) when the reader sees the end (never with --loop).
+    uint64_t nbatches = feed ? ~0ull : size / batch_bytes + 1;
+    auto rounds_of = [&](uint64_t nb) { return nb == ~0ull ? ~0ull : (nb + (uint64_t)N - 1) / (uint64_t)N; };
+    uint64_t nrounds = rounds_of(nbatches);
+    uint64_t fed_bytes = 0;                                                  // rank 0's reader: bytes of the stream so far (--timing)
+    std::thread reader;
+    if (feed && rank == 0)
+        reader = std::thread([&] {
+            // dump1090.c:460-512 for N consumers: batch b = the previous batch's last 476 bytes + the next batch_bytes of the stream;
+            // --loop seeks back and keeps filling the same batch (:488-494); a short batch ends the stream
+            std::vector<uint8_t> tail(MODES_CARRY_BYTES, 127);
+            for (uint64_t b = 0;; b++) {
+                FeedSlot &sl = feed_slots[b % nslots];
+                while (sl.seq.load(std::memory_order_acquire) != 0) {
+                    if (feed_head->failed.load()) return;
+                    usleep(50);
+                }
+                uint8_t *dst = feed_mem + (b % nslots) * slot_bytes;
+                if (b) memcpy(dst, tail.data(), MODES_CARRY_BYTES);
+                uint8_t *data = dst + (b ? MODES_CARRY_BYTES : 0);
+                size_t got = 0;
+                if (!read_full(fd, data, batch_bytes, &got)) { perror("read"); feed_head->failed.store(1); return; }
+                while (got < batch_bytes && opt.loop && fd != 0) {
+                    if (lseek(fd, 0, SEEK_SET) == -1) break;
+                    size_t more = 0;
+                    if (!read_full(fd, data + got, batch_bytes - got, &more)) { perror("read"); feed_head->failed.store(1); return; }
+                    if (more == 0) break;                                    // empty file
+                    got += more;
+                }
+                if (got >= MODES_CARRY_BYTES) memcpy(tail.data(), data + got - MODES_CARRY_BYTES, MODES_CARRY_BYTES);
+                fed_bytes += got;
+                sl.nbytes = got;
+                if (got < batch_bytes) feed_head->total.store(b + 1, std::memory_order_release);      // this batch carries the EOF buffer
+                sl.seq.store(b + 1, std::memory_order_release);
+                if (got < batch_bytes) return;
+            }
+        });
     Pool pool(std::max(1, opt.read_threads / N));
     std::vector<char> has((size_t)depth, 0);
     int rc = 0;
     auto fail_rank = [&](const char *what, const char *text) { fprintf(stderr, "rank %d: %s: %s\n", rank, what, text); rc = 1; };
-    for (uint64_t q = 0; q < nrounds + 2 && !rc; q++) {
-        if (q < nrounds) {                                                   // submit this rank's batch of round q
+    for (uint64_t q = 0; (nrounds == ~0ull || q < nrounds + 2) && !rc; q++) {
+        if (nrounds == ~0ull || q < nrounds) {                               // submit this rank's batch of round q
             const int l = (int)(q % (uint64_t)depth);
             const uint64_t b = q * (uint64_t)N + (uint64_t)rank;
-            has[(size_t)l] = b < nbatches;
+            const uint8_t *src = nullptr;
+            size_t got = 0;
+            FeedSlot *slot = nullptr;
+            if (feed) {
+                // wait for the reader: either batch b is there, or the stream has ended in front of it (then the round may not exist at all)
+                slot = &feed_slots[b % nslots];
+                for (;;) {
+                    if (slot->seq.load(std::memory_order_acquire) == b + 1) break;
+                    const uint64_t total = feed_head->total.load(std::memory_order_acquire);
+                    if (total != ~0ull && total <= b) { slot = nullptr; break; }
+                    if (feed_head->failed.load()) { fail_rank("input", "the reader failed"); break; }
+                    usleep(50);
+                }
+                if (rc) break;
+                const uint64_t total = feed_head->total.load(std::memory_order_acquire);
+                if (total != ~0ull && nbatches == ~0ull) { nbatches = total; nrounds = rounds_of(nbatches); }
+                if (nrounds != ~0ull && q >= nrounds) { q--; continue; }     // the stream ended before this round: drain (the loop's header takes over)
+                has[(size_t)l] = slot != nullptr;
+                if (slot) { src = feed_mem + (b % nslots) * slot_bytes; got = (size_t)slot->nbytes; }
+            } else {
+                has[(size_t)l] = b < nbatches;
+                if (has[(size_t)l]) {
+                    const size_t lo = (size_t)b * batch_bytes;
+                    got = std::min(batch_bytes, size - std::min(size, lo));
+                    src = map + lo - (b ? MODES_CARRY_BYTES : 0);
+                }
+            }
             if (has[(size_t)l]) {
-                const size_t lo = (size_t)b * batch_bytes, got = std::min(batch_bytes, size - std::min(size, lo));
+                const size_t lo = (size_t)b * batch_bytes;
                 const size_t carry = b ? MODES_CARRY_BYTES : 0;
-                const uint8_t *src = map + lo - carry;
                 const size_t n = carry + got, sl = (n / (size_t)pool.size() + 4095) & ~(size_t)4095;
                 uint8_t *dst = lanes[(size_t)l].buf;
                 pool.run(pool.size(), [&](int t) { const size_t o = (size_t)t * sl; if (o < n) memcpy(dst + o, src + o, std::min(sl, n - o)); });
+                if (slot) slot->seq.store(0, std::memory_order_release);     // the reader may fill it again
                 uint64_t nblocks = got / MODES_DATA_LEN;
                 if (got < batch_bytes) nblocks += 1;                         // the EOF buffer
                 if (modes_gpu_submit_host(lanes[(size_t)l].gpu, dst, n, (uint64_t)lo - carry, b * opt.batch_blocks, nblocks) != MODES_OK)
@@ -518,6 +603,7 @@ int run_ranks(const Options &opt, double t_start) {
             uint64_t nrec = 0;
             if (G.wait(g, (uint32_t)l, &recs, &nrec, nullptr) != MODES_OK) { fail_rank("gather", G.last_error(g)); break; }
             if (rank != 0) continue;
+            if (feed) modes_host_set_time(host, (int64_t)time(nullptr));       // a live stream: the whitelist's 60 s run on the wall clock (dump1090.c:913,924)
             const uint64_t *cands = nullptr;
             uint64_t ncand = 0;
             if (opt.stats && G.candidates(g, (uint32_t)l, &cands, &ncand) != MODES_OK) { fail_rank("gather", G.last_error(g)); break; }
@@ -537,6 +623,9 @@ int run_ranks(const Options &opt, double t_start) {
         }
     }
     const double t_end = now_s();
+    if (feed && rc) feed_head->failed.store(1);                              // (the reader and the other ranks stop waiting for slots)
+    if (reader.joinable()) { if (rc) reader.detach(); else reader.join(); }
+    if (feed) size = (size_t)fed_bytes;                                      // what --timing reports (rank 0 knows it)
     if (rc) {
         // A rank that leaves the round loop with an error has peers that wait inside a collective it will never issue; they never
         // reach their own teardown, and RCCL's communicator destroy may wait for them (it synchronises the ranks of a node).  So
@@ -573,7 +662,7 @@ int run_ranks(const Options &opt, double t_start) {
     for (auto &ln : lanes) { modes_gpu_host_free(ln.gpu, ln.buf); modes_gpu_destroy(ln.gpu); }
     G.destroy(g);
     if (map) munmap(const_cast<uint8_t *>(map), size);
-    close(fd);
+    if (fd > 0) close(fd);
     return finish(rc);
 }
 

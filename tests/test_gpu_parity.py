@@ -357,6 +357,34 @@ def test_cli_one_process_per_gpu_prints_the_reference_stats(torch_cuda, streams,
     assert small.returncode == 1 and b"preamble positions" in small.stderr and small.stdout == b""
 
 
+def test_cli_one_process_per_gpu_reads_a_pipe_and_replays_a_file(torch_cuda, streams, tmp_path):
+    """dump1090_amd --ranks 1 with --ifile - and with --loop (round 5: rank 0 reads, the ranks take their batches from shared memory):
+    the pipe's listing is the file's, the replay's first 2.5 laps are the one-process host's (which are the reference's:
+    test_cli_loop_and_clean_exit) - through real RCCL on the GPU at hand."""
+    exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
+    pad = tmp_path / "pad.bin"
+    synth.modes1_padded(os.path.join(ROOT, "tests", "golden", "modes1.bin")).tofile(pad)
+    one = subprocess.run([exe, "--ifile", str(pad), "--raw"], capture_output=True, check=True).stdout
+    assert hashlib.md5(one).hexdigest() == "4a81758c8bec5e45ffa8541c5622938a"
+    with open(pad, "rb") as f:
+        p = subprocess.run([exe, "--ifile", "-", "--raw", "--ranks", "1", "--batch-blocks", "1"], stdin=f, capture_output=True)
+    assert p.returncode == 0 and p.stdout == one, p.stderr[-600:]
+    n = len(one) * 5 // 2
+    outs = []
+    for extra in ([], ["--ranks", "1"]):
+        q = subprocess.Popen([exe, "--ifile", str(pad), "--raw", "--loop", "--batch-blocks", "1"] + extra, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        got = b""
+        while len(got) < n:
+            chunk = q.stdout.read(n - len(got))
+            if not chunk:
+                break
+            got += chunk
+        q.kill()
+        q.wait()
+        outs.append(got)
+    assert outs[0] == outs[1] and len(outs[0]) == n and outs[0][:len(one)] == one
+
+
 def test_cli_more_ranks_than_gpus_fails_instead_of_hanging(torch_cuda, streams, tmp_path):
     """dump1090_amd --ranks 2 on a box with one GPU: rank 1 has no device, rank 0 already waits in the communicator's
     rendezvous.  Rank 0's watchdog ends the job: status 1 and a message, not a hang."""

@@ -86,6 +86,7 @@ run_tsan_host() {
 # the libmodes_gather.so the host dlopens) - fork, id pipes, round-robin batches, gather rounds, ranks without a batch, the EOF
 # batch; stdout must be the reference's for every N and batch size.
 run_ranks_host() {
+    export MODES_RANKS_QUIET=1                    # (the '--gpus N is faster below 96 GB' line: once per run is enough for a log)
     echo "== ranks-host =="
     D=/tmp/modes_ranks_host
     mkdir -p $D
@@ -121,13 +122,32 @@ run_ranks_host() {
     set -e
     echo "   --stats with 8 positions of room: exit status $rc"
     [ "$rc" = 1 ] && grep -q "exceeds the gather buffers\|gather" $D/fail.err || { cat $D/fail.err; exit 1; }
-    # a pipe or --loop has one reader: --ranks says so and names the alternative
+    # a pipe or --loop has ONE reader: rank 0 reads and hands every rank its batches through shared memory (round 5; refused before)
+    for n in 1 2 3; do for bb in 1 2; do
+        got=$($D/dump1090_amd_stub --ifile - --raw --ranks $n --batch-blocks $bb < tests/golden/modes1.bin | md5sum | cut -c1-32)
+        echo "   --ifile - --ranks $n --batch-blocks $bb: md5 $got"
+        [ "$got" = 4a81758c8bec5e45ffa8541c5622938a ] || { echo "   expected 4a81758c8bec5e45ffa8541c5622938a"; exit 1; }
+    done; done
+    got=$(cat tests/golden/modes1.bin | $D/dump1090_amd_stub --ifile - --stats --ranks 2 --batch-blocks 1 | md5sum | cut -c1-32)
+    [ "$got" = bc3d1c04b24f4989f0fc4a2d1f45abdd ] || { echo "   --ifile - --stats --ranks 2: $got"; exit 1; }
+    echo "   --ifile - --stats --ranks 2: md5 $got"
+    # --loop: the first 2.5 laps are the single-process host's (which are the reference's: loop-host below)
+    python - <<'PY'
+import sys
+sys.path[:0] = [".", "tests", "oracle"]
+import synth
+synth.modes1_padded("tests/golden/modes1.bin").tofile("/tmp/modes_ranks_host/pad.bin")
+PY
+    one=$($D/dump1090_amd_stub --ifile $D/pad.bin --raw | wc -c)
+    n=$(( one * 5 / 2 ))
     set +e
-    $D/dump1090_amd_stub --ifile - --raw --ranks 2 < tests/golden/modes1.bin > /dev/null 2> $D/fail.err; rc1=$?
-    $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --loop --raw --ranks 2 > /dev/null 2>> $D/fail.err; rc2=$?
+    timeout 60 $D/dump1090_amd_stub --ifile $D/pad.bin --raw --loop --batch-blocks 1 2> /dev/null | head -c $n > $D/loop_1proc.txt
+    for r in 2 3; do
+        timeout 60 $D/dump1090_amd_stub --ifile $D/pad.bin --raw --loop --ranks $r --batch-blocks 1 2> /dev/null | head -c $n > $D/loop_ranks$r.txt
+    done
     set -e
-    [ "$rc1" = 1 ] && [ "$rc2" = 1 ] && [ "$(grep -c 'use --gpus 2' $D/fail.err)" = 2 ] || { cat $D/fail.err; exit 1; }
-    echo "   --ifile - / --loop with --ranks: refused, --gpus named"
+    cmp $D/loop_1proc.txt $D/loop_ranks2.txt && cmp $D/loop_1proc.txt $D/loop_ranks3.txt || { echo "   --loop --ranks differs from the one-process replay"; exit 1; }
+    echo "   --loop --ranks 2 / 3: the first $n bytes (2.5 laps) equal the one-process host's"
     # a rank whose GPU does not come up while its peers already wait in the gather: the job ends with status 1, it does not hang
     # (rank 0's watchdog kills the other ranks; a rank never outlives rank 0)
     for bad in 0 1 2; do
