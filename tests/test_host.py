@@ -315,8 +315,9 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS")}
     p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "ranks-host"], capture_output=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout[-800:], p.stderr[-800:])
-    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 13 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
-    # (three of the twelve: the start-up probe of the communicator fails - on every rank, on a peer, on rank 0 - and rank 0 starts the
+    # the reference's listing: 9 files x (N, batch size), N = 8, 6 pipes (--ifile -, round 5) and 3 restarts
+    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 19 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
+    # (three of them: the start-up probe of the communicator fails - on every rank, on a peer, on rank 0 - and rank 0 starts the
     # job over once with the other IPC mode; that second run prints the listing)
     assert p.stdout.count(b", 1 restart") == 3
     # a rank that fails to start while its peers wait in the gather ends the job (status 1), whichever rank it is
@@ -325,10 +326,13 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     # the communicator on that path: ADVICE round 3)
     assert p.stdout.count(b"fails in GPU call") == 2 and p.stdout.count(b": exit status 1") == 6
     # --stats through the gather's second list (every rank's preamble positions on rank 0): the reference's nine lines for N = 1, 2, 3;
-    # a list that outgrows its buffers fails the job; a pipe / --loop is refused with the alternative named
-    assert p.stdout.count(b"md5 bc3d1c04b24f4989f0fc4a2d1f45abdd") == 7        # N = 1, 2, 3 x two batch sizes, and N = 8
+    # a list that outgrows its buffers fails the job
+    assert p.stdout.count(b"md5 bc3d1c04b24f4989f0fc4a2d1f45abdd") == 8        # N = 1, 2, 3 x two batch sizes, N = 8, and a pipe with N = 2
     assert b"--raw --ranks 8 --batch-blocks 1: md5 4a81758c" in p.stdout              # eight processes, five of them without a batch
-    assert b"--stats with 8 positions of room: exit status 1" in p.stdout and b"refused, --gpus named" in p.stdout
+    assert b"--stats with 8 positions of room: exit status 1" in p.stdout
+    # round 5: a pipe and --loop through --ranks (rank 0 reads, shared-memory slots): the pipe's listing for N = 1, 2, 3 x two batch sizes
+    # is counted above; the replay's first 2.5 laps equal the one-process host's
+    assert p.stdout.count(b"--ifile - --ranks") == 6 and b"--loop --ranks 2 / 3: the first" in p.stdout
 
 
 def test_c_host_loop_replays_the_file_like_the_reference():
