@@ -138,4 +138,4 @@ if total_valu:
                                                   per_chunk - always - push))
 print("\nthe instructions behind each construct (both halves):")
 for c in cats:
-    print("  %s\n      %s" % (c, ", ".join("%s x%d" % (o, n) for o, n in kinds[c].most_common(14))))
+    print("  %s\n      %s" % (c, ", ".join("%s x%d" % (o, n) for o, n in kinds[c].most_common(40))))
