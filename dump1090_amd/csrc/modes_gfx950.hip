@@ -1774,328 +1774,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(80))) void reco
     if (tid == 0) R.wg_flags[blockIdx.x] = s_bad;
 }
 
-// ------------------------------------------------------------------------------------
-// record4_kernel - stage 3 with FOUR records per wavefront (round 5; MODES_GPU_RECORD4).  record_kernel gives a record a whole
-// wavefront and is bound by its ~400 vector instructions per record (profiles/r08/ab_record_kernel.txt): every scalar step of the
-// reference's per-message logic costs a wave-instruction.  Here a record has a ROW of 16 lanes, lane t owning the seven bit pairs
-// 7 t .. 7 t + 6 (16 x 7 = 112), so one instruction stream serves four records:
-//   * the 224 + 224 sample bytes of the row's record come in as dword-aligned 16-byte loads + v_alignbit (select_kernel's loads,
-//     16 lanes instead of 8), the twelve preamble samples one per lane;
-//   * the bit-slicing recurrence and both phase-correction chains (modes_core.h: r_k = G_k | (P_k & r_(k-1))) are a carry chain over
-//     the row: 7-bit additions inside a lane, a four-step carry-lookahead over the 16 lanes with DPP row shifts (row_chain_up; the
-//     downward chain is the same on the mirrored row);
-//   * sums, syndromes (XOR of the single-bit syndromes of the lane's set bits), repair positions: row reductions (four DPP steps);
-//     values one lane owns (the DF in lane 0, the preamble samples) reach the row through row_newbcast;
-//   * the record leaves as ONE 4-byte store per lane: lane t writes dword t of the 64-byte record.
-// The rare shapes stay with the proven code: a record whose first pair has lo == hi (the `bits == 2` quirk of dump1090.c:1677-1706) or
-// whose window touches an end of the span is handed to demod_rest - a wavefront each - by the same workgroup afterwards.
-// record_kernel remains the second implementation the parity tests cross-check this one with.
-// ------------------------------------------------------------------------------------
-namespace r4 {
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp(uint32_t v) {                        // lanes without a source lane read 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
-}
-constexpr int kShr = 0x110, kShl = 0x100, kMirror = 0x140, kBcast = 0x150;   // row_shr:n, row_shl:n, row_mirror, row_newbcast:n
-#define R4_ROW_REDUCE(name, OP)                                                                        \
-    __device__ __forceinline__ uint32_t name(uint32_t v) {                                             \
-        v = v OP (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);                     \
-        v = v OP (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);                     \
-        v = v OP (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);                    \
-        v = v OP (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true);                    \
-        return v;                                                                                      \
-    }
-R4_ROW_REDUCE(row_sum, +)
-R4_ROW_REDUCE(row_xor, ^)
-R4_ROW_REDUCE(row_or, |)
-#undef R4_ROW_REDUCE
-__device__ __forceinline__ uint32_t row_max(uint32_t v) {
-    v = max(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));
-    return v;
-}
-__device__ __forceinline__ uint32_t rev7(uint32_t x) { return __builtin_bitreverse32(x) >> 25; }
-// pair 7 t + j <-> pair 111 - (7 t + j) = 7 (15 - t) + (6 - j): the row mirrored
-__device__ __forceinline__ uint32_t mirror(uint32_t x) { return dpp<kMirror>(rev7(x)); }
-// r_k = g_k | (p_k & r_(k-1)), r_(-1) = 0, over the 112 pairs of the row; bit j of lane t = pair 7 t + j; g & p == 0.
-// (modes_chain: the carry chain of (g | p) + g; here 7 bits per lane and a Kogge-Stone carry-lookahead over the 16 lanes)
-__device__ __forceinline__ uint32_t row_chain_up(uint32_t g, uint32_t p) {
-    const uint32_t a = g | p;
-    uint32_t G = ((a + g) >> 7) & 1u;                                        // the lane's carry out without a carry in
-    uint32_t Pl = p == 0x7fu ? 1u : 0u;                                      // ... and whether a carry in passes through
-#define R4_STEP(d) { const uint32_t Gs = dpp<kShr + d>(G), Ps = dpp<kShr + d>(Pl); G |= Pl & Gs; Pl &= Ps; }
-    R4_STEP(1) R4_STEP(2) R4_STEP(4) R4_STEP(8)
-#undef R4_STEP
-    const uint32_t cin = dpp<kShr + 1>(G);                                   // carry into lane t = carry out of lanes 0 .. t - 1
-    return (((a + g + cin) ^ p) >> 1) & 0x7fu;
-}
-struct Fix {
-    uint32_t syndrome, nfix, pos0, pos1;
-};
-// syndrome + repair positions of one attempt for the four rows at once (wave_finish_attempt, dump1090.c:1104, 1112-1117, 854-880)
-__device__ __forceinline__ Fix finish_attempt(uint32_t bits, bool gate, uint32_t df, bool is_long, int maxfix, uint32_t t, const uint32_t *s_esyn) {
-    Fix f{0u, 0u, 0xffu, 0xffu};
-    const uint32_t nbits = is_long ? 112u : 56u, shift = 112u - nbits, kbase = 7u * t;
-    uint32_t e[7], c = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 7; j++) {
-        const uint32_t k = kbase + j;                                        // message bit k sits at frame position k + shift
-        e[j] = s_esyn[min(k + shift, 111u)];
-        if (k < nbits && ((bits >> j) & 1u)) c ^= e[j];
-    }
-    const uint32_t syn = gate ? row_xor(c) : 0u;
-    f.syndrome = syn;
-    const bool fixable = gate && syn != 0u && maxfix >= 1 && (df == 11u || df == 17u || df == 18u);
-    const uint32_t first = is_long ? 5u : 56u;                               // frame bits this length may repair
-    uint32_t code = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 7; j++) {
-        const uint32_t k = kbase + j;
-        if (fixable && k < nbits && k + shift >= first && e[j] == syn) code = k + 1u;
-    }
-    const uint32_t one = row_max(code);
-    if (one) { f.nfix = 1u; f.pos0 = one - 1u; }
-    const bool need2 = fixable && one == 0u && maxfix >= 2;
-    if (__any(need2)) {                                                      // wave-uniform: the hash lookups are the expensive part
-        uint32_t code2 = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < 7; j++) {
-            const uint32_t k = kbase + j, pfr = k + shift;
-            if (need2 && k < nbits && pfr >= first) {
-                const uint32_t q = syn_lookup(s_esyn + 112, syn ^ e[j]);     // frame position of the second flipped bit, if any
-                if (q < 112u && q > pfr) code2 = ((k + 1u) << 8) | (q - shift);
-            }
-        }
-        const uint32_t two = row_max(code2);                                 // (at most one pair answers: all 1- and 2-bit syndromes are distinct)
-        if (two) { f.nfix = 2u; f.pos0 = (two >> 8) - 1u; f.pos1 = two & 0xffu; }
-    }
-    return f;
-}
-// The seven bits of every lane -> the message's four mask dwords in every lane of the row (bit k of the 128-bit mask = message bit k),
-// then the message bytes of dword i (msg[4 i .. 4 i + 3]; bit 8 b + u of the mask is bit 7 - u of byte b: modes_bits_to_msg).
-__device__ __forceinline__ void row_msg_dwords(uint32_t bits, uint32_t t, uint32_t (&m)[4]) {
-    const uint32_t off = 7u * t, w = off >> 5, sh = off & 31u;
-    const uint32_t lo = bits << sh, hi = sh > 25u ? bits >> (32u - sh) : 0u;
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++) {
-        const uint32_t mine = (w == i ? lo : 0u) | (w + 1u == i ? hi : 0u);
-        m[i] = __builtin_bswap32(__builtin_bitreverse32(row_or(mine)));      // every byte bit-reversed in place
-    }
-}
-}  // namespace r4
-
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(80))) void record4_kernel(RecordParams R) {
-    __shared__ __attribute__((aligned(16))) uint16_t s_lut[MODES_LUT_ENTRIES];
-    __shared__ uint32_t s_esyn[kSynWords];
-    __shared__ uint32_t s_red[8];
-    __shared__ uint32_t s_bad;
-    const DemodParams &P = R.d;
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t t = (uint32_t)lane & 15u, row = (uint32_t)lane >> 4;
-#ifdef MODES_TRACE
-    const unsigned long long t_start = wall_clock64();
-    unsigned long long tr_counts = 0, tr_table = 0, tr_records = 0, tr_n = 0, tr_nb = 0, tr_slow = 0;
-#endif
-    auto count_reduce = [&](uint32_t v) -> uint32_t {
-        v = (uint32_t)wave_sum((int)v);
-        __syncthreads();
-        if (lane == 0) s_red[wave] = v;
-        __syncthreads();
-        uint32_t all = 0;
-#pragma unroll
-        for (int w = 0; w < 8; w++) all += s_red[w];
-        return all;
-    };
-    if (tid == 0) s_bad = 0;
-    bool staged = false;
-    uint32_t off = 0, prev = 0;
-    const uint32_t lut_adj = (uint32_t)reinterpret_cast<uintptr_t>(s_lut) + 0x10000u;     // sel_pair: LDS byte address of the table, adjusted
-    for (uint32_t batch = blockIdx.x; batch < P.nbatches; batch += gridDim.x) {
-        const uint64_t list_base = (uint64_t)batch * kDemodGroup * P.slot_cap;
-        const uint32_t nb = R.batch_count[batch];
-        TRACE_T(tc0);
-        off += count_reduce(prev + (uint32_t)tid < batch ? R.batch_count[prev + (uint32_t)tid] : 0u);
-        prev = batch;
-#ifdef MODES_TRACE
-        tr_counts += wall_clock64() - tc0; tr_nb += nb;
-#endif
-        if (nb == 0) continue;                                               // workgroup-uniform
-        TRACE_T(tt0);
-        if (!staged) {
-            stage_lut<512>(s_lut, P.tab.lut);
-            for (int i = tid; i < kSynWords; i += 512) s_esyn[i] = P.tab.esyn[i];
-            __syncthreads();
-            staged = true;
-        }
-#ifdef MODES_TRACE
-        tr_table += wall_clock64() - tt0;
-        const unsigned long long tr0 = wall_clock64();
-#endif
-        const LutFull lut{s_lut};
-        // every position of the batch is >= gbase: 32-bit byte offsets from there through a raw buffer descriptor
-        const int64_t gbase = (int64_t)batch * kDemodGroup * P.run_chunks * kChunkSamples - 64;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.iq) + 2 * gbase, 0, 0x7fffffff, 0x00020000);
-        for (uint32_t r0 = 0; r0 < nb; r0 += 32) {                           // 8 wavefronts x 4 rows
-            const uint32_t r = r0 + 4u * (uint32_t)wave + row;
-            const bool valid = r < nb;
-            const uint32_t pcu = valid ? R.surv[list_base + r] : 0u;
-            const int64_t pc = (int64_t)pcu;
-            const uint32_t slot = off + r;
-            // the row's record takes the fast path when its whole window (and the four bytes of slack the dword-aligned loads may
-            // touch) lies inside the span
-            const bool fast = valid && samples_inside(pc - 1, pc + 241, P.lo, P.hi);
-            // ---- loads: lane t's seven pairs of both halves are 28 consecutive bytes from sample pc + 16 + 14 t ----
-            uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            const uint32_t voff = (uint32_t)(2 * (pc - gbase)) + 32u;
-            if (fast) sel_load(rsrc, voff, (int)t, d);
-            const uint32_t sh16 = ((voff + 28u * t) & 2u) << 3;
-            uint32_t pre_raw = 0x7f7fu;
-            if (fast && t < 12u) pre_raw = load_sample<false>(P.iq, pc - 1 + (int64_t)t, P.lo, P.hi);
-            uint32_t a[7], b[7];
-#pragma unroll
-            for (int j = 0; j < 7; j++) sel_pair(sel_dword(d, j, sh16), lut_adj, a[j], b[j]);
-            const uint32_t pre = t < 12u ? (uint32_t)mag_of(lut, pre_raw) : 0u;
-            // ---- first slicing pass (dump1090.c:1669-1689) and the delta sums of the noise gate (:1713-1717) ----
-            uint32_t wk = 0, st = 0, sall = 0;
-#pragma unroll
-            for (int j = 0; j < 7; j++) {
-                const uint32_t dd = __builtin_amdgcn_sad_u16(a[j], b[j], 0u);
-                wk |= (dd < 256u ? 1u : 0u) << j;
-                st |= (a[j] > b[j] ? 1u : 0u) << j;
-                sall += dd;
-            }
-            if (t == 0u) wk &= ~1u;                                          // pair 0 never repeats (:1675)
-            const uint32_t sum112 = r4::row_sum(sall), sum56 = r4::row_sum(t < 8u ? sall : 0u);
-            const uint32_t bits0 = r4::row_chain_up(st & ~wk, wk);
-            const bool feq0 = r4::dpp<r4::kBcast + 0>((t == 0u && a[0] == b[0]) ? 1u : 0u) != 0u;
-            const uint32_t df0 = r4::dpp<r4::kBcast + 0>(__builtin_bitreverse32(bits0 & 31u) >> 27);      // msg[0] >> 3: message bits 0 .. 4, lane 0
-            const bool long0 = df0 >= 16u && df0 <= 21u;
-            const bool gate0 = long0 ? sum112 >= 2550u * 56u : sum56 >= 2550u * 28u;                       // :1717-1723
-            // ---- phase-corrected retry (dump1090.c:1498-1558), rows whose block-local offset is not 0 (:1660) ----
-            const uint64_t g = (uint64_t)pc + P.g0;
-            const uint32_t jblk = (uint32_t)(g & (MODES_BLOCK_STRIDE - 1));
-            const bool with_phase = jblk != 0u;
-            uint32_t up, dn;
-            const bool backward = modes_phase_factors(r4::dpp<r4::kBcast + 0>(pre), r4::dpp<r4::kBcast + 1>(pre), r4::dpp<r4::kBcast + 3>(pre),
-                                                      r4::dpp<r4::kBcast + 4>(pre), r4::dpp<r4::kBcast + 7>(pre), r4::dpp<r4::kBcast + 8>(pre),
-                                                      r4::dpp<r4::kBcast + 10>(pre), r4::dpp<r4::kBcast + 11>(pre), &up, &dn);
-            uint32_t su[7], sd[7], upm = 0, dnm = 0;
-#pragma unroll
-            for (int j = 0; j < 7; j++) {
-                // backward: the hi sample of the pair is rescaled and lo compared with it; forward: lo is rescaled and compared with hi
-                const uint32_t x = backward ? b[j] : a[j], y = backward ? a[j] : b[j];
-                su[j] = modes_scale(x, up);
-                sd[j] = modes_scale(x, dn);
-                upm |= ((backward ? y > su[j] : su[j] > y) ? 1u : 0u) << j;
-                dnm |= ((backward ? y > sd[j] : sd[j] > y) ? 1u : 0u) << j;
-            }
-            uint32_t G, Pm;
-            if (backward) {                                                  // c_k = Up_k | (Dn_k & ~Up_k & c_(k+1)), c_111 = Up_111
-                G = upm;
-                Pm = dnm & ~upm;
-                if (t == 15u) Pm &= ~0x40u;
-            } else {                                                         // c_k = Dn_k | (Up_k & ~Dn_k & c_(k-1)), c_0 = Up_0
-                G = dnm;
-                Pm = upm & ~dnm;
-                if (t == 0u) { G = (G & ~1u) | (upm & 1u); Pm &= ~1u; }
-            }
-            // one upward chain serves both directions: the downward one runs on the mirrored row
-            const uint32_t cm = r4::row_chain_up(backward ? r4::mirror(G) : G, backward ? r4::mirror(Pm) : Pm);
-            const uint32_t c = backward ? r4::mirror(cm) : cm;
-            // backward: pair k uses c_(k+1) (pair 111: the up factor); forward: pair k uses c_(k-1) (pair 0: the up factor)
-            const uint32_t cnext = (c >> 1) | ((r4::dpp<r4::kShl + 1>(c) & 1u) << 6);
-            uint32_t cprev = ((c << 1) | ((r4::dpp<r4::kShr + 1>(c) >> 6) & 1u)) & 0x7fu;
-            if (t == 0u) cprev |= 1u;
-            uint32_t wk1 = 0, st1 = 0;
-            uint32_t na0 = 0, nb0 = 0;
-#pragma unroll
-            for (int j = 0; j < 7; j++) {
-                const uint32_t na = backward ? a[j] : (((cprev >> j) & 1u) ? su[j] : sd[j]);
-                const uint32_t nh = backward ? (((cnext >> j) & 1u) ? sd[j] : su[j]) : b[j];
-                const uint32_t dd = na > nh ? na - nh : nh - na;
-                wk1 |= (dd < 256u ? 1u : 0u) << j;
-                st1 |= (na > nh ? 1u : 0u) << j;
-                if (j == 0) { na0 = na; nb0 = nh; }
-            }
-            if (t == 0u) wk1 &= ~1u;
-            uint32_t bits1 = r4::row_chain_up(st1 & ~wk1, wk1);
-            bool feq1 = r4::dpp<r4::kBcast + 0>((t == 0u && na0 == nb0) ? 1u : 0u) != 0u;
-            uint32_t df1 = r4::dpp<r4::kBcast + 0>(__builtin_bitreverse32(bits1 & 31u) >> 27);
-            bool long1 = df1 >= 16u && df1 <= 21u;
-            bool gate1 = long1 ? sum112 >= 2550u * 56u : sum56 >= 2550u * 28u;  // the retry's own length, the uncorrected deltas (:1708-1723)
-            if (!with_phase) { bits1 = bits0; feq1 = false; df1 = df0; long1 = long0; gate1 = true; }
-            // ---- who stays on this path ----
-            const bool mine = fast && !feq0 && !feq1;                        // the others go to demod_rest below
-            if (mine && !gate0 && t == 0u) atomicOr(&s_bad, 2u);            // cannot happen: the pre-test IS the first gate
-            // ---- syndromes and repair positions ----
-            const r4::Fix f0 = r4::finish_attempt(bits0, mine && gate0, df0, long0, P.maxfix, t, s_esyn);
-            const r4::Fix f1 = r4::finish_attempt(bits1, mine && gate0 && gate1, df1, long1, P.maxfix, t, s_esyn);
-            // ---- the record: lane t writes dword t ----
-            uint32_t m0[4], m1[4];
-            r4::row_msg_dwords(bits0, t, m0);
-            r4::row_msg_dwords(bits1, t, m1);
-            const uint32_t g1 = gate1 ? 1u : 0u;
-            uint32_t v;
-            switch (t) {
-                case 0: v = (uint32_t)(g / MODES_BLOCK_STRIDE); break;
-                case 1: v = jblk; break;
-                case 2: v = m0[0]; break;
-                case 3: v = m0[1]; break;
-                case 4: v = m0[2]; break;
-                case 5: v = (m0[3] & 0xffffu) | (1u << 24); break;           // errors 0, gate_ok 1
-                case 6: v = f0.nfix | (f0.pos0 << 8) | (f0.pos1 << 16); break;
-                case 7: v = 0u; break;
-                case 8: v = f0.syndrome; break;
-                case 9: v = m1[0]; break;
-                case 10: v = m1[1]; break;
-                case 11: v = m1[2]; break;
-                case 12: v = (m1[3] & 0xffffu) | (g1 << 24); break;
-                case 13: v = f1.nfix | (f1.pos0 << 8) | (f1.pos1 << 16); break;
-                case 14: v = 0u; break;
-                default: v = f1.syndrome; break;
-            }
-            if (mine && gate0 && slot < P.max_records) {
-                reinterpret_cast<uint32_t *>(&P.staging[slot])[t] = v;
-                if (R.host_out && slot < R.direct_cap) reinterpret_cast<uint32_t *>(&R.host_out[slot])[t] = v;
-            }
-            // ---- the rows this path leaves alone: a wavefront each, the proven way ----
-            uint64_t todo = __ballot(valid && !mine && t == 0u);
-#ifdef MODES_TRACE
-            tr_n += (unsigned long long)__builtin_popcountll(__ballot(valid && t == 0u));
-            tr_slow += (unsigned long long)__builtin_popcountll(todo);
-#endif
-            while (todo) {
-                const int src = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const int64_t pcs = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)pcu, src);
-                const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slot, src);
-                modes_record *host_rec = (R.host_out && sl < R.direct_cap) ? &R.host_out[sl] : nullptr;
-                bool done;
-                if (samples_inside(pcs - 1, pcs + 239, P.lo, P.hi)) done = demod_full<false, false>(P, lut, s_esyn, lane, pcs, kUnknown, kUnknown, sl, 0, host_rec);
-                else                                                done = demod_full<true, false>(P, lut, s_esyn, lane, pcs, kUnknown, kUnknown, sl, 0, host_rec);
-                if (!done && lane == 0) atomicOr(&s_bad, 2u);
-            }
-        }
-#ifdef MODES_TRACE
-        tr_records += wall_clock64() - tr0;
-#endif
-    }
-#ifdef MODES_TRACE
-    if (lane == 0) {
-        const uint32_t w = blockIdx.x * 8 + (uint32_t)wave;
-        if (w < 4096) {
-            unsigned long long *tr = &g_trace[8 * (4096 + w)];
-            tr[0] = t_start; tr[1] = tr_counts; tr[2] = wall_clock64(); tr[3] = tr_n; tr[4] = tr_table; tr[5] = tr_records; tr[6] = tr_nb; tr[7] = tr_slow;
-        }
-    }
-#endif
-    __syncthreads();
-    if (tid == 0) R.wg_flags[blockIdx.x] = s_bad;
-}
-
 // finalize of the two-kernel path: totals, the number of records, the verdict for the host.  Nothing to put in order.
 struct Finalize2Params {
     ResultHeader *hdr;
@@ -2415,7 +2093,6 @@ struct modes_gpu {
     uint32_t *d_surv = nullptr;       size_t surv_bytes = 0;         // select_kernel's survivor lists (same geometry as the candidate lists)
     uint32_t *d_wg_flags = nullptr;                                  // record_kernel: one word per workgroup (<= 512)
     bool split_path = false;          // the detect in flight ran select + record + finalize2 (the list is complete and in order)
-    bool record4 = false;             // ... with record4_kernel (four records per wavefront) instead of record_kernel: MODES_GPU_RECORD4
     uint32_t *d_cand_slots = nullptr; size_t cand_slots_bytes = 0;
     uint32_t *d_counts = nullptr;     size_t counts_elems = 0;       // counts | cand_counts | batch_count | batch_off
     uint64_t *d_cand_offsets = nullptr;
@@ -2553,14 +2230,6 @@ int modes_gpu_create(const modes_gpu_config *cfg, modes_gpu **out) {
             return fail(nullptr, MODES_ERR_ARG, "MODES_GPU_DEMOD_VARIANT='%s': 0 (automatic), 2 (two kernels) or 3 (one kernel)", v);
         }
         if (ctx->cfg.demod_variant == 0) ctx->cfg.demod_variant = (uint32_t)n;
-    }
-    if (const char *v = getenv("MODES_GPU_RECORD4")) {
-        // Measurement / test knob: which of the two stage-3 kernels of the two-kernel path runs (1: four records per wavefront, 0: one).
-        if (!(v[0] == '0' || v[0] == '1') || v[1] != 0) {
-            delete ctx;
-            return fail(nullptr, MODES_ERR_ARG, "MODES_GPU_RECORD4='%s': 0 (a wavefront per record) or 1 (four records per wavefront)", v);
-        }
-        ctx->record4 = v[0] == '1';
     }
     if (ctx->cfg.scan_variant != 0) {
         const uint32_t v = ctx->cfg.scan_variant;
@@ -2919,8 +2588,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
         rp.surv = ctx->d_surv; rp.batch_count = d_batch_count;
         rp.host_out = ctx->h_records_dev; rp.direct_cap = fp.inline_cap; rp.wg_flags = ctx->d_wg_flags;
         const uint32_t rec_grid = std::min<uint32_t>(nbatches, 512);
-        if (ctx->record4) hipExtLaunchKernelGGL(record4_kernel, dim3(rec_grid), dim3(512), 0, st2, ev(4), ev(5), 0, rp);
-        else              hipExtLaunchKernelGGL(record_kernel, dim3(rec_grid), dim3(512), 0, st2, ev(4), ev(5), 0, rp);
+        hipExtLaunchKernelGGL(record_kernel, dim3(rec_grid), dim3(512), 0, st2, ev(4), ev(5), 0, rp);
         Finalize2Params f2{};
         f2.hdr = ctx->d_hdr; f2.totals = ctx->d_totals; f2.ntotals = ctx->demod_grid; f2.wg_flags = ctx->d_wg_flags; f2.nwg = rec_grid;
         f2.batch_count = d_batch_count; f2.nbatches = nbatches; f2.d_count = ctx->d_user_count; f2.host_hdr = ctx->h_hdr_dev; f2.seq = fp.seq;
