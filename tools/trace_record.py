@@ -27,7 +27,6 @@ for name, v in (("start", us(t[:, 0] - t0)), ("end", us(t[:, 2] - t0)), ("life",
     print("%-26s min %8.2f p10 %8.2f p50 %8.2f p90 %8.2f max %8.2f" % (name, v.min(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
 has = t[:, 3] > 0
 print("us per record (wavefronts with records): p50 %.2f  mean %.2f" % (np.median(us(t[has, 5]) / t[has, 3]), (us(t[has, 5]) / t[has, 3]).mean()))
-print("records handed to the wavefront-per-record path (record4_kernel only): %d of %d" % (t[:, 7].sum(), t[:, 3].sum()))
 for k in range(1, int(t[:, 3].max()) + 1):
     sel = t[:, 3] == k
     if sel.any():
