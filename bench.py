@@ -795,6 +795,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": "scan_kernel", "algorithmic_bytes_per_launch": int(kern["call_bytes"]),
+                     # the same bytes over the WHOLE step (every kernel, the fetch and the resolve behind it: the clock `value` is on)
+                     "achieved_step": round(head["per_gpu"] / (head["elapsed"] / head_steps) / 1e9, 1),
+                     "frac_step": round(head["per_gpu"] / (head["elapsed"] / head_steps) / 1e9 / HBM_PEAK_GBS, 4),
                      # the box's own read-only streaming rate next to the specification
                      "measured_ceiling": ceiling,
                      "frac_of_measured_ceiling": round(achieved / ceiling["GB_per_s"], 4) if ceiling else None,
