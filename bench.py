@@ -417,6 +417,10 @@ def parse_args(argv=None):
                          "where every kernel runs alone (`one_launch_stream`).  1: one region, one stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                                                       "the N > 1 control flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--resolve-on", default="root", choices=("root", "ranks"),
+                    help="N > 1 (or --force-gather): root (default) = the record lists travel to rank 0, which resolves them all; ranks = "
+                         "every rank resolves its own records from a guessed whitelist, the ranks confirm each other and only the TEXT "
+                         "travels (dump1090_amd/distributed.py RankResolve; DESIGN.md 5.4)")
     ap.add_argument("--force-gather", action="store_true",
                     help="with one rank: run the N > 1 code path anyway (process group of one, device output buffers, count "
                          "all_gather, the list sent to itself through isend / irecv) - exercises the RCCL calls on a one-GPU box")
@@ -503,6 +507,9 @@ def main():
             RCCL_START["probe_s"] = round(ipc_probe(dist, torch, dev, rank, world), 3)   # (a group of one sends to itself: the same calls on a one-GPU box)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=limit)
+    ranks_resolve = dist_on and args.resolve_on == "ranks"
+    # host memory for the ranks' whitelist exchanges (three small all_gathers a step), whatever the records' backend is
+    ctl_group = dist.new_group(backend="gloo", timeout=limit) if ranks_resolve else None
 
     def shard(total_bytes):
         """this rank's contiguous buffer range of the whole stream, and the bytes it needs (476-byte carry in front)"""
@@ -531,12 +538,15 @@ def main():
 
         def make():
             d = Demodulator(device=local, run_chunks=args.run_chunks, overlap=args.overlap,
-                            demod_variant=args.demod_variant, max_records=cap_records if dist_on else 0, **flags)
+                            demod_variant=args.demod_variant, max_records=cap_records if dist_on and not ranks_resolve else 0, **flags)
             return d if timing else NoTiming(d)
         return run_steps(make, iq, lo, calls, flags, steps, warm, args.depth, world=world, rank=rank, dist=dist,
                          coll_device=coll_dev, cap_records=cap_records, streams=works,
                          device_sync=lambda: torch.cuda.synchronize(dev), time_every=max(1, time_every or args.time_every),
-                         resolve_threads=args.resolve_threads or max(1, min(32, (os.cpu_count() or 4) // 4)), gather=dist_on)
+                         # (root: rank 0 resolves every rank's records on up to 32 threads; ranks: every rank its own, all at the same
+                         #  time - half the hardware threads shared out among them)
+                         resolve_threads=args.resolve_threads or max(1, min(32, (os.cpu_count() or 4) // (2 * world if ranks_resolve else 4))),
+                         gather=dist_on, resolve_on=args.resolve_on, ctl_group=ctl_group)
 
     def gathered(obj):
         """[obj of rank 0, of rank 1, ...] on rank 0 (None elsewhere)"""
@@ -723,6 +733,8 @@ def main():
                 d["kernel_ms_per_step_max_rank"] = round(max(per_step(r) for r in per_rank), 4)
                 d["kernel_ms_per_step_min_rank"] = round(min(per_step(r) for r in per_rank), 4)
                 d["rank0_resolve_ms_per_step"] = (leg.get("host_ms_per_call") or {}).get("resolve_per_step")
+            if leg.get("rank_resolve"):
+                d["rank_resolve"] = leg["rank_resolve"]     # rank 0's view: its own share of the resolve, the protocol's exchanges
             if dist_on:
                 d["rccl"] = comm_facts(leg, steps)
                 # a leg with records to gather whose gather moved nothing did not measure the N > 1 path
@@ -772,11 +784,13 @@ def main():
         "config": {"workload": head_name, "bytes_per_gpu": head["per_gpu"],
                    "flags": {"noise": "--raw --no-fix", "lowsnr": "--raw --aggressive"}.get(head_kind, "--raw"),
                    "sharding": "buffers over %d rank(s)" % world, "settle_steps": args.settle if noise is not None else head.get("settle_steps"),
-                   "demod_variant": args.demod_variant,
+                   "demod_variant": args.demod_variant, "resolve_on": args.resolve_on if dist_on else None,
                    "step": "scan + demod + order kernels, record fetch%s, host resolve + --raw formatting on a second thread; "
                            "%d detect(s) in flight; overlap=%d; completion by a host-visible word (no event in the stream), kernel timing events on "
                            "one call in %d of the kernel-timing region only; %d launch stream(s) in the throughput region" % (
-                               ", device-resident lists gathered to rank 0 over %s (counts all_gather + exact-size send/recv)" % (
+                               (", every rank resolves its own list (whitelist guesses and confirmations: three host all_gathers a step), the "
+                                "texts travel to rank 0 over %s" if ranks_resolve else
+                                ", device-resident lists gathered to rank 0 over %s (counts all_gather + exact-size send/recv)") % (
                                    "RCCL" if args.backend == "nccl" else args.backend) if world > 1 else "",
                                head["depth"], args.overlap, 4 if (noise is not None and args.streams > 1) else args.time_every,
                                max(1, args.streams))},
@@ -824,6 +838,8 @@ def main():
         line["listing_check"] = only["listing_check"]
         if "rccl" in only:
             line["rccl"] = only["rccl"]
+        if "rank_resolve" in only:
+            line["rank_resolve"] = only["rank_resolve"]
 
     if rank == 0 and world == 1 and noise is not None and not args.no_end_to_end:
         line["end_to_end"] = end_to_end(torch, dev, iq_noise, args)

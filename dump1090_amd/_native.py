@@ -112,6 +112,10 @@ class Aircraft(C.Structure):
                 ("odd_cprtime", C.c_int64), ("even_cprtime", C.c_int64), ("seen_ms", C.c_int64), ("messages", C.c_long)]
 
 
+ICAO_SLOTS = 1024                  # MODES_ICAO_SLOTS
+ICAO_NONE = 0xFFFFFFFF             # MODES_ICAO_NONE
+LOOKUP_DTYPE = np.dtype([("addr", np.uint32), ("known", np.uint32)])      # modes_icao_lookup
+
 SINK_FN = C.CFUNCTYPE(None, C.POINTER(ModesMessage), C.c_uint32, C.c_uint32, C.c_void_p)
 
 # every symbol include/*.h declares (tests/test_abi.py checks the libraries export them)
@@ -125,6 +129,8 @@ HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_set_time"
                 "modes_host_get_stats", "modes_host_decode", "modes_host_decode_frame", "modes_format_raw", "modes_format_raw_net",
                 "modes_format_onlyaddr", "modes_format_verbose", "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
                 "modes_block_count",
+                "modes_host_get_whitelist", "modes_host_set_whitelist", "modes_host_whitelist_guess", "modes_host_resolve_raw_spec",
+                "modes_host_whitelist_check",
                 "modes_tracker_create", "modes_tracker_destroy", "modes_tracker_receive", "modes_tracker_expire",
                 "modes_tracker_count", "modes_tracker_get", "modes_tracker_reference", "modes_tracker_json", "modes_format_sbs")
 
@@ -246,6 +252,18 @@ def host_lib():
         L.modes_host_resolve_raw_mtv.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_uint64,
                                                  C.POINTER(C.c_uint64), C.c_int]
         L.modes_host_resolve_raw_mtv.restype = C.c_uint64
+        # resolve on the ranks that demodulated (include/modes_host.h)
+        L.modes_host_get_whitelist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.modes_host_get_whitelist.restype = None
+        L.modes_host_set_whitelist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.modes_host_set_whitelist.restype = None
+        L.modes_host_whitelist_guess.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_int]
+        L.modes_host_whitelist_guess.restype = None
+        L.modes_host_resolve_raw_spec.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_uint64,
+                                                  C.POINTER(C.c_uint64), C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.modes_host_resolve_raw_spec.restype = C.c_uint64
+        L.modes_host_whitelist_check.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.modes_host_whitelist_check.restype = C.c_int
         L.modes_host_wants.argtypes = [C.c_void_p, C.POINTER(ModesMessage)]
         L.modes_host_get_stats.argtypes = [C.c_void_p, C.POINTER(HostStats)]
         L.modes_host_get_stats.restype = None

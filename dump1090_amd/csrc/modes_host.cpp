@@ -559,13 +559,10 @@ void run_piece(Piece &p) {
 }
 }  // namespace
 
-uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint64_t nrecs, char *out, uint64_t cap,
-                                   uint64_t *nbytes, int threads) {
-    return modes_host_resolve_raw_mtv(h, &recs, &nrecs, 1, out, cap, nbytes, threads);
-}
-
-uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
-                                    char *out, uint64_t cap, uint64_t *nbytes, int threads) {
+// `outer` (modes_host_resolve_raw_spec; else null): the log of the CALL as a whole - the slots it wrote, and the lookups
+// that were answered from the state `h` had on entry.
+static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
+                                     char *out, uint64_t cap, uint64_t *nbytes, int threads, IcaoLog *outer) {
     uint64_t nrecs = 0;
     for (uint32_t g = 0; g < nsegs; g++) nrecs += seg_nrecs[g];
     // threads < 0: exactly -threads pieces however short the list (tests); otherwise at least 2048 records per thread
@@ -575,6 +572,8 @@ uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *se
     if ((uint64_t)T > nrecs / kMinPiece) T = (int)(nrecs / kMinPiece);
     if (T <= 1) {                                                                 // one thread: segment after segment
         uint64_t msgs = 0, total = 0;
+        struct Log { modes_host *h; IcaoLog *was; ~Log() { h->log = was; } } keep{h, h->log};
+        if (outer) h->log = outer;                                                // (the log's `written` carries over from segment to segment)
         for (uint32_t g = 0; g < nsegs; g++) {
             uint64_t nb = 0;
             msgs += modes_host_resolve_raw(h, segs[g], seg_nrecs[g], nullptr, 0, out ? out + total : nullptr, cap > total ? cap - total : 0, &nb);
@@ -608,7 +607,7 @@ uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *se
         uint64_t msgs = 0, total = 0;
         for (uint32_t g = 0; g < nsegs; g++) {
             uint64_t nb = 0;
-            msgs += modes_host_resolve_raw_mt(h, segs[g], seg_nrecs[g], out ? out + total : nullptr, cap > total ? cap - total : 0, &nb, threads);
+            msgs += resolve_raw_mtv_impl(h, &segs[g], &seg_nrecs[g], 1, out ? out + total : nullptr, cap > total ? cap - total : 0, &nb, threads, outer);
             total += nb;
         }
         if (nbytes) *nbytes = total;
@@ -654,6 +653,14 @@ uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *se
         // true state after the piece: its writes over the true state before it
         for (uint32_t s2 = 0; s2 < kIcaoSlots; s2++)
             if (p.log.written[s2]) { truth.icao[s2] = p.host.icao[s2]; truth.icao_seen[s2] = p.host.icao_seen[s2]; }
+        if (outer) {
+            // the piece's answers now ARE the sequential run's: those it took from a slot no piece of this call had written
+            // before it came from the state the call started with
+            for (const IcaoLog::Lookup &q : p.log.lookups)
+                if (!outer->written[icao_slot(q.addr)]) outer->lookups.push_back(q);
+            for (uint32_t s2 = 0; s2 < kIcaoSlots; s2++)
+                if (p.log.written[s2]) outer->written[s2] = true;
+        }
     }
     const double t3 = now();
     // merge: whitelist, counters, text
@@ -696,6 +703,80 @@ uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *se
         fprintf(stderr, "resolve_raw_mt: %zu pieces in %u segment(s), %llu records: guess %.2f ms, speculative %.2f ms, confirm %.2f ms (%d re-run), merge %.2f ms\n",
                 P, nsegs, (unsigned long long)nrecs, t1 - t0, t2 - t1, t3 - t2, reruns, now() - t3);
     return msgs;
+}
+
+uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint64_t nrecs, char *out, uint64_t cap,
+                                   uint64_t *nbytes, int threads) {
+    return resolve_raw_mtv_impl(h, &recs, &nrecs, 1, out, cap, nbytes, threads, nullptr);
+}
+
+uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
+                                    char *out, uint64_t cap, uint64_t *nbytes, int threads) {
+    return resolve_raw_mtv_impl(h, segs, seg_nrecs, nsegs, out, cap, nbytes, threads, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resolve on the ranks that demodulated (include/modes_host.h; dump1090_amd/distributed.py RankResolve is the
+// protocol): the speculation of modes_host_resolve_raw_mt one level up - a rank is a piece, its guess and its log
+// travel instead of its records.
+// ---------------------------------------------------------------------------------------------
+static_assert(MODES_ICAO_SLOTS == kIcaoSlots, "the header's table size is the whitelist's");
+
+void modes_host_get_whitelist(const modes_host *h, uint32_t *addr, int64_t *seen) {
+    memcpy(addr, h->icao, sizeof h->icao);
+    memcpy(seen, h->icao_seen, sizeof h->icao_seen);
+}
+
+void modes_host_set_whitelist(modes_host *h, const uint32_t *addr, const int64_t *seen) {
+    memcpy(h->icao, addr, sizeof h->icao);
+    memcpy(h->icao_seen, seen, sizeof h->icao_seen);
+}
+
+void modes_host_whitelist_guess(const modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
+                                uint32_t *guess, int threads) {
+    for (uint32_t s = 0; s < kIcaoSlots; s++) guess[s] = MODES_ICAO_NONE;
+    uint64_t nrecs = 0;
+    for (uint32_t g = 0; g < nsegs; g++) nrecs += seg_nrecs[g];
+    if (nrecs == 0) return;
+    // pieces in stream order (any cut will do: the lists are only read); a later piece's address wins its slot
+    int T = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+    if ((uint64_t)T > nrecs / 4096 + 1) T = (int)(nrecs / 4096 + 1);
+    const uint64_t share = (nrecs + (uint64_t)T - 1) / (uint64_t)T;
+    std::vector<Piece> pieces;
+    for (uint32_t g = 0; g < nsegs; g++)
+        for (uint64_t lo = 0; lo < seg_nrecs[g]; lo += share) {
+            pieces.emplace_back();
+            pieces.back().recs = segs[g];
+            pieces.back().lo = lo;
+            pieces.back().hi = lo + share < seg_nrecs[g] ? lo + share : seg_nrecs[g];
+        }
+    const bool aggressive = h->cfg.aggressive != 0;
+    WorkerPool::instance().run(pieces.size(), [&](size_t t) { guess_piece(pieces[t], aggressive); });
+    for (const Piece &p : pieces)
+        for (uint32_t s = 0; s < kIcaoSlots; s++)
+            if (p.guess_set[s]) guess[s] = p.guess_addr[s];
+}
+
+uint64_t modes_host_resolve_raw_spec(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
+                                     char *out, uint64_t cap, uint64_t *nbytes, int threads,
+                                     uint8_t *written, modes_icao_lookup *lookups, uint64_t lookup_cap, uint64_t *nlookups) {
+    IcaoLog log;
+    const uint64_t msgs = resolve_raw_mtv_impl(h, segs, seg_nrecs, nsegs, out, cap, nbytes, threads, &log);
+    if (written)
+        for (uint32_t s = 0; s < kIcaoSlots; s++) written[s] = log.written[s] ? 1 : 0;
+    const uint64_t n = log.lookups.size();
+    if (lookups)
+        for (uint64_t i = 0; i < n && i < lookup_cap; i++) lookups[i] = modes_icao_lookup{log.lookups[i].addr, log.lookups[i].known ? 1u : 0u};
+    if (nlookups) *nlookups = n;
+    return msgs;
+}
+
+int modes_host_whitelist_check(const modes_host *h, const modes_icao_lookup *lookups, uint64_t n) {
+    modes_host probe = *h;                                                        // (no log: a check is not a lookup of the run)
+    probe.log = nullptr;
+    for (uint64_t i = 0; i < n; i++)
+        if (icao_known(&probe, lookups[i].addr) != (lookups[i].known != 0)) return 0;
+    return 1;
 }
 
 // '*' + two hex digits per byte + ";\n".  A byte -> its two digits through a 256-entry table (one 2-byte store per message

@@ -176,6 +176,58 @@ class HostResolver:
         n = self._lib.modes_host_resolve_raw_mtv(self._h, ptrs, lens, len(segs), buf, len(buf), C.byref(nbytes), max(1, threads))
         return int(n), (C.string_at(buf, nbytes.value) if text else None)
 
+    # ---- resolve on the ranks that demodulated (include/modes_host.h; distributed.RankResolve is the protocol) ----
+    @staticmethod
+    def _segments(segments):
+        segs = [np.ascontiguousarray(a, dtype=N.RECORD_DTYPE) for a in segments if len(a)]
+        ptrs = (C.c_void_p * max(1, len(segs)))(*[a.ctypes.data for a in segs])
+        lens = (C.c_uint64 * max(1, len(segs)))(*[a.size for a in segs])
+        return segs, ptrs, lens
+
+    def whitelist(self):
+        """(addr uint32[ICAO_SLOTS], seen int64[ICAO_SLOTS]): the ICAO whitelist as it stands (copies)."""
+        addr = np.empty(N.ICAO_SLOTS, dtype=np.uint32)
+        seen = np.empty(N.ICAO_SLOTS, dtype=np.int64)
+        self._lib.modes_host_get_whitelist(self._h, addr.ctypes.data, seen.ctypes.data)
+        return addr, seen
+
+    def set_whitelist(self, addr, seen):
+        addr = np.ascontiguousarray(addr, dtype=np.uint32)
+        seen = np.ascontiguousarray(seen, dtype=np.int64)
+        assert addr.size == N.ICAO_SLOTS and seen.size == N.ICAO_SLOTS
+        self._lib.modes_host_set_whitelist(self._h, addr.ctypes.data, seen.ctypes.data)
+
+    def whitelist_guess(self, segments, threads: int = 1) -> np.ndarray:
+        """uint32[ICAO_SLOTS]: what the clean DF11/17/18 frames of these records would leave on the whitelist (ICAO_NONE: nothing)."""
+        segs, ptrs, lens = self._segments(segments)
+        guess = np.empty(N.ICAO_SLOTS, dtype=np.uint32)
+        self._lib.modes_host_whitelist_guess(self._h, ptrs, lens, len(segs), guess.ctypes.data, max(1, threads))
+        return guess
+
+    def raw_listing_spec(self, segments, threads: int = 1):
+        """raw_listing_segments from the whitelist this resolver holds NOW (a guess the caller has set), with the log a
+        later confirmation needs: -> (lines, nbytes, written uint8[ICAO_SLOTS], lookups LOOKUP_DTYPE[]).  The listing
+        stays in the resolver's buffer (text_view(nbytes))."""
+        segs, ptrs, lens = self._segments(segments)
+        total = sum(a.size for a in segs)
+        buf = self._text_buffer(62 * total + 64)
+        nbytes, nlook = C.c_uint64(), C.c_uint64()
+        written = np.zeros(N.ICAO_SLOTS, dtype=np.uint8)
+        lookups = np.empty(2 * total + 16, dtype=N.LOOKUP_DTYPE)
+        n = self._lib.modes_host_resolve_raw_spec(self._h, ptrs, lens, len(segs), buf, len(buf), C.byref(nbytes), max(1, threads),
+                                                  written.ctypes.data, lookups.ctypes.data, lookups.size, C.byref(nlook))
+        assert nlook.value <= lookups.size and nbytes.value < len(buf)
+        return int(n), int(nbytes.value), written, lookups[: nlook.value]
+
+    def text_view(self, nbytes: int) -> np.ndarray:
+        """The first nbytes of the listing buffer as uint8 (a view: valid until the next listing call of this resolver)."""
+        return np.frombuffer(self._rawbuf, dtype=np.uint8, count=nbytes) if nbytes else np.zeros(0, dtype=np.uint8)
+
+    def whitelist_check(self, lookups) -> bool:
+        """Does this resolver's whitelist (at its clock) give every one of the logged answers?"""
+        lookups = np.ascontiguousarray(lookups, dtype=N.LOOKUP_DTYPE)
+        return bool(self._lib.modes_host_whitelist_check(self._h, lookups.ctypes.data, lookups.size))
+
     def stats(self) -> dict:
         st = N.HostStats()
         self._lib.modes_host_get_stats(self._h, C.byref(st))

@@ -219,3 +219,289 @@ def gather_records(records: np.ndarray, candidates, dst: int = 0, group=None, de
     if candidates is not None:
         cands = gather_arrays(np.ascontiguousarray(candidates, dtype=np.uint64), dst, group, device)
     return recs, cands
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Resolve on the ranks that demodulated.
+#
+# The gather above brings every rank's records to rank 0, whose host then runs the one sequential piece of the path for
+# all N GPUs (the ICAO whitelist, dump1090.c:896-925, :1183-1210).  RankResolve leaves the records where they are: the
+# speculation of modes_host_resolve_raw_mt (modes_host.cpp) one level up, a rank = a piece of the step.
+#
+#   1  every rank lists what its clean DF11/17/18 frames would write to the whitelist (whitelist_guess: 4 KiB);
+#      one all_gather (host memory) - with rank 0's clock, which all ranks use for the step;
+#   2  rank r resolves its own records - in stream order they follow those of ranks 0 .. r-1 - from the state the step
+#      started with, overlaid with the guesses of the ranks before it, logging the slots it wrote and every whitelist
+#      question it answered from that start state (raw_listing_spec);
+#   3  one all_gather of what every rank wrote (8 KiB) and its line / byte / counter totals; every rank rebuilds the
+#      state that REALLY preceded it from the tables of the ranks before it and checks its logged answers against it;
+#   4  one all_gather of the verdicts.  All good (the rule): the texts are final.  Else the first rank with a wrong
+#      answer - the ranks before it are final, so the state it has just rebuilt is the true one - resolves again from
+#      that state, and 3 - 4 repeat for the ranks behind it; every round settles at least one more rank;
+#   5  the texts travel to rank 0 (31 bytes a line instead of 64 a record), which concatenates them in rank order.
+#
+# Same answers -> same control flow -> same output: the listing is byte-identical to the sequential resolve of the
+# gathered records (tests/test_host.py: every stream, 2 .. 8 ranks, spoiled guesses; tests/test_distributed.py over gloo).
+#
+# The protocol is a generator (rank_resolve_step) that yields what it wants exchanged: LocalRanks runs N of them in one
+# process (tests), RankResolve runs one per process over torch.distributed.
+# ---------------------------------------------------------------------------------------------------------------------
+_HDR = 2 + len(N.STAT_NAMES)          # lines, bytes, the --stats counters; then one word per whitelist slot
+
+
+def _pack_writes(written, addr, seen):
+    """int64[ICAO_SLOTS]: -1 = slot untouched, else seen << 24 | addr (24-bit addresses, a non-negative clock)."""
+    assert int(seen.min()) >= 0 and int(seen.max()) < (1 << 38)
+    return np.where(written != 0, (seen.astype(np.int64) << 24) | addr.astype(np.int64), np.int64(-1))
+
+
+def _apply_writes(addr, seen, w):
+    m = w >= 0
+    addr[m] = (w[m] & 0xFFFFFF).astype(np.uint32)
+    seen[m] = w[m] >> 24
+
+
+def rank_resolve_step(make_resolver, rank, world, start, segments, threads=1, now=0, spoil=False, text_buffer=None):
+    """One step of the protocol on one rank, as a generator.
+    yields ("gather", int64 array)            -> send() it the list of every rank's array, in rank order
+           ("text", uint8 view, [nbytes ...]) -> send() rank 0 the list of every rank's text (its own first), the others None
+    returns (StopIteration.value) a dict: lines / nbytes / stats of the whole step, texts (rank 0), the whitelist the
+    step leaves (identical on every rank), reruns of this rank, rounds, the resolver (for its listing buffer).
+    start = (addr, seen): the true whitelist the step starts from, the same on every rank.
+    spoil: make this rank's guess of its start state wrong on purpose (tests: the re-run path)."""
+    addr0, seen0 = start
+    res = make_resolver(text_buffer)
+    guess = res.whitelist_guess(segments, threads)
+    gs = yield ("gather", np.concatenate([np.array([now], dtype=np.int64), guess.astype(np.int64)]))
+    now = int(gs[0][0])                                  # one clock for the step: rank 0's
+    res.set_time(now)
+    addr, seen = addr0.copy(), seen0.copy()
+    for r in range(rank):
+        g = gs[r][1:]
+        m = g != N.ICAO_NONE
+        addr[m] = g[m].astype(np.uint32)
+        seen[m] = now
+    if spoil:                                            # forget everything: every "known" answer of the true run comes out wrong
+        addr[:] = 0
+        seen[:] = 0
+    res.set_whitelist(addr, seen)
+    lines, nbytes, written, lookups = res.raw_listing_spec(segments, threads)
+    reruns = rounds = 0
+    while True:
+        rounds += 1
+        a, s = res.whitelist()
+        st = res.stats()
+        head = np.array([lines, nbytes] + [st[k] for k in N.STAT_NAMES], dtype=np.int64)
+        ws = yield ("gather", np.concatenate([head, _pack_writes(written, a, s)]))
+        addr, seen = addr0.copy(), seen0.copy()
+        for r in range(rank):
+            _apply_writes(addr, seen, ws[r][_HDR:])
+        probe = make_resolver(None)
+        probe.set_time(now)
+        probe.set_whitelist(addr, seen)
+        ok = probe.whitelist_check(lookups)
+        probe.close()
+        oks = yield ("gather", np.array([1 if ok else 0], dtype=np.int64))
+        bad = [r for r in range(world) if not int(oks[r][0])]
+        if not bad:
+            break
+        if bad[0] == rank:                               # the ranks before this one are final: `addr, seen` is the true start
+            buf = res.take_text_buffer()
+            res.close()
+            res = make_resolver(buf)
+            res.set_time(now)
+            res.set_whitelist(addr, seen)
+            lines, nbytes, written, lookups = res.raw_listing_spec(segments, threads)
+            reruns += 1
+    for r in range(rank, world):                         # the whitelist the step leaves: every rank's writes, in order
+        _apply_writes(addr, seen, ws[r][_HDR:])
+    sizes = [int(w[1]) for w in ws]
+    texts = yield ("text", res.text_view(nbytes), sizes)
+    stats = {k: int(sum(int(w[2 + i]) for w in ws)) for i, k in enumerate(N.STAT_NAMES)}
+    stats["valid_preamble"] = -1                         # (records only: like modes_host_get_stats without candidates)
+    return {"lines": int(sum(int(w[0]) for w in ws)), "nbytes": int(sum(sizes)), "stats": stats, "texts": texts,
+            "whitelist": (addr, seen), "reruns": reruns, "rounds": rounds, "resolver": res, "own_lines": lines}
+
+
+class LocalRanks:
+    """N ranks' protocol generators run in lockstep in ONE process (tests, and a host that holds several GPUs' lists):
+    step(segments_per_rank) -> (listing bytes, the per-rank result dicts)."""
+
+    def __init__(self, world, flags, threads=1):
+        from .demod import HostResolver
+        self.world, self.threads = world, threads
+        self.make = lambda buf=None: HostResolver(text_buffer=buf, **flags)
+        self.state = (np.zeros(N.ICAO_SLOTS, dtype=np.uint32), np.zeros(N.ICAO_SLOTS, dtype=np.int64))
+
+    def step(self, segments_per_rank, now=0, spoil=()):
+        gens = [rank_resolve_step(self.make, r, self.world, self.state, segments_per_rank[r], self.threads, now, r in spoil)
+                for r in range(self.world)]
+        asks = [next(g) for g in gens]
+        results = [None] * self.world
+        while any(r is None for r in results):
+            kind = asks[0][0]
+            assert all(a[0] == kind for a in asks)          # every rank is at the same exchange
+            if kind == "gather":
+                reply = [[a[1].copy() for a in asks]] * self.world
+            else:
+                texts = [a[1].copy() for a in asks]
+                assert [t.size for t in texts] == asks[0][2]
+                reply = [texts] + [None] * (self.world - 1)
+            nxt = []
+            for r, g in enumerate(gens):
+                try:
+                    nxt.append(g.send(reply[r]))
+                except StopIteration as e:
+                    results[r] = e.value
+            asks = nxt
+        for r in results:
+            r["resolver"].close()
+        self.state = results[0]["whitelist"]
+        for r in results[1:]:                               # every rank ends the step with the same whitelist
+            assert np.array_equal(r["whitelist"][0], self.state[0]) and np.array_equal(r["whitelist"][1], self.state[1])
+        return b"".join(t.tobytes() for t in results[0]["texts"]), results
+
+
+class RankResolve:
+    """The protocol of one rank of a torch.distributed job.  ctl: a process group over HOST memory (gloo) for the three small
+    all_gathers, used by the calling thread only; the texts travel through it too (CPU tensors), or - device given - over the
+    default group from device memory (RCCL: host -> device on the sender, exact-size point-to-point transfers into one buffer on
+    rank 0, one copy back).  fresh=True: every step starts from an empty whitelist (a bench step replays its stream from the
+    beginning); False: from the one the step before left."""
+
+    def __init__(self, flags, threads, ctl, device=None, fresh=True, cap_bytes=1 << 22):
+        import torch
+        import torch.distributed as dist
+        from .demod import HostResolver
+        self.dist, self.torch = dist, torch
+        self.ctl = ctl
+        self.world = dist.get_world_size(ctl)
+        self.rank = dist.get_rank(ctl)
+        self.threads = threads
+        self.fresh = fresh
+        self.make = lambda buf=None: HostResolver(text_buffer=buf, **flags)
+        self.state = self._empty()
+        self.device = torch.device(device) if device is not None else None
+        self.on_gpu = self.device is not None and self.device.type == "cuda"
+        self._prev = None                                   # the resolver of the step before (its listing buffer is handed on)
+        self._dev = self._pin = None
+        self._cap = 0
+        if self.on_gpu:
+            self.stream = torch.cuda.Stream(device=self.device)
+            self._grow(cap_bytes)
+        self.work_s = self.exchange_s = 0.0                 # seconds in the C calls / inside the exchanges (waiting for peers included)
+        self.steps = self.reruns = self.rounds = 0
+        self.bytes_moved = self.p2p_ops = 0
+
+    @staticmethod
+    def _empty():
+        return np.zeros(N.ICAO_SLOTS, dtype=np.uint32), np.zeros(N.ICAO_SLOTS, dtype=np.int64)
+
+    def _grow(self, nbytes):
+        torch = self.torch
+        if nbytes > self._cap:
+            self._cap = int(nbytes * 5 // 4)
+            self._dev = torch.empty(self._cap, dtype=torch.uint8, device=self.device)
+            self._pin = torch.empty(self._cap, dtype=torch.uint8).pin_memory()
+
+    def _gather(self, arr):
+        torch, dist = self.torch, self.dist
+        mine = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64))
+        out = torch.empty(self.world * mine.numel(), dtype=torch.int64)
+        dist.all_gather_into_tensor(out, mine, group=self.ctl)
+        return list(out.numpy().reshape(self.world, -1))
+
+    def _texts(self, view, sizes):
+        """-> rank 0: [uint8 array per rank] (views of buffers that live until the next step), others None"""
+        torch, dist = self.torch, self.dist
+        me, n = self.rank, int(view.size)
+        assert sizes[me] == n
+        peers = [r for r in range(self.world) if r != 0 and sizes[r]]
+        moved = sum(sizes[r] for r in peers)
+        if not self.on_gpu:
+            if me == 0:
+                self.bytes_moved += moved
+                self.p2p_ops += len(peers)
+                parts = {r: torch.empty(sizes[r], dtype=torch.uint8) for r in peers}
+                works = [dist.irecv(parts[r], dist.get_global_rank(self.ctl, r), group=self.ctl) for r in peers]
+                for w in works:
+                    w.wait()
+                return [view] + [parts[r].numpy() if r in parts else np.zeros(0, dtype=np.uint8) for r in range(1, self.world)]
+            if n:
+                dist.send(torch.from_numpy(view), dist.get_global_rank(self.ctl, 0), group=self.ctl)
+                self.p2p_ops += 1
+            return None
+        # device memory: the default group is RCCL
+        with torch.cuda.stream(self.stream):
+            if me == 0:
+                self._grow(moved + (n if self.world == 1 else 0))
+                ops, offs, where = [], 0, {}
+                for r in peers:
+                    where[r] = (offs, sizes[r])
+                    ops.append(dist.P2POp(dist.irecv, self._dev[offs: offs + sizes[r]], r))
+                    offs += sizes[r]
+                if self.world == 1 and n:                   # a group of one: the text goes through isend / irecv to itself (the calls of
+                    src = torch.from_numpy(view).to(self.device, non_blocking=False)        # the N > 1 path on the hardware at hand)
+                    ops += [dist.P2POp(dist.irecv, self._dev[:n], 0), dist.P2POp(dist.isend, src, 0)]
+                    offs = n
+                if ops:
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                    self._pin[:offs].copy_(self._dev[:offs], non_blocking=True)
+                self.stream.synchronize()
+                self.bytes_moved += offs
+                self.p2p_ops += len(ops)
+                if self.world == 1:
+                    if n and not np.array_equal(self._pin[:n].numpy(), view):
+                        raise N.ModesError(-2, "loopback: the text that went through isend / irecv differs from the one sent")
+                    return [view]
+                host = self._pin.numpy()
+                return [view] + [host[where[r][0]: where[r][0] + where[r][1]] if r in where else np.zeros(0, dtype=np.uint8)
+                                 for r in range(1, self.world)]
+            if n:
+                self._grow(n)
+                self._pin[:n].copy_(torch.from_numpy(view))
+                self._dev[:n].copy_(self._pin[:n], non_blocking=True)
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, self._dev[:n], 0)]):
+                    w.wait()
+                self.p2p_ops += 1
+            self.stream.synchronize()
+            return None
+
+    def step(self, segments, now=0, spoil=False):
+        """Resolve this rank's records of one step (arrays in stream order, whole buffers each).  -> the result dict of
+        rank_resolve_step; on rank 0 `texts` holds every rank's listing in rank order (views: valid until the next step)."""
+        import time
+        if self.fresh:
+            self.state = self._empty()
+        buf = None
+        if self._prev is not None:                          # the step before is consumed: its listing buffer serves again
+            buf = self._prev.take_text_buffer()
+            self._prev.close()
+            self._prev = None
+        gen = rank_resolve_step(self.make, self.rank, self.world, self.state, segments, self.threads, now, spoil, buf)
+        t = time.perf_counter()
+        ask = next(gen)
+        while True:
+            t1 = time.perf_counter()
+            self.work_s += t1 - t
+            reply = self._gather(ask[1]) if ask[0] == "gather" else self._texts(ask[1], ask[2])
+            t = time.perf_counter()
+            self.exchange_s += t - t1
+            try:
+                ask = gen.send(reply)
+            except StopIteration as e:
+                out = e.value
+                break
+        self.work_s += time.perf_counter() - t
+        self.state = out["whitelist"]
+        self._prev = out.pop("resolver")                    # rank 0's own text is a view of its buffer: alive until the next step
+        self.steps += 1
+        self.reruns += out["reruns"]
+        self.rounds += out["rounds"]
+        return out
+
+    def close(self):
+        if self._prev is not None:
+            self._prev.close()
+            self._prev = None

@@ -16,8 +16,11 @@ class Resolver(threading.Thread):
     A fresh whitelist per step: every step demodulates the same stream from its beginning; the calls of one step
     share it (like the batches of one file)."""
 
-    def __init__(self, flags, threads=1, hold_views=True):
+    def __init__(self, flags, threads=1, hold_views=True, rank_resolve=None, root=True):
         super().__init__(daemon=True)
+        self.rr = rank_resolve          # distributed.RankResolve: every rank runs a Resolver and resolves its OWN records; the ranks
+        self.root = root                # confirm each other and the texts travel to rank 0 (root) - no record leaves its rank
+        self.exchange_s = 0.0           # seconds of the timed steps inside that protocol's exchanges (waiting for the peers included)
         self.flags = flags
         self.hold_views = hold_views    # keep the gather buffers of a step's calls until the step is resolved (else: copy)
         self.threads = threads          # modes_host_resolve_raw_mt: pieces of a long list resolved in parallel (exact)
@@ -63,6 +66,9 @@ class Resolver(threading.Thread):
                 continue
             recs, counts, first_call, last_call, timed, done, keep = item
             try:
+                if self.rr is not None:
+                    self._rank_step(recs, first_call, last_call, timed, done, keep)
+                    continue
                 if first_call:
                     # a fresh whitelist, the old listing buffer (a new one per step would be zero-filled and faulted in
                     # under the GIL: 7 ms for the 34 MB of an 8-GPU step - the launching thread stalls, the GPU runs dry)
@@ -118,6 +124,34 @@ class Resolver(threading.Thread):
             finally:
                 self.completed += 1
 
+    def _rank_step(self, recs, first_call, last_call, timed, done, keep):
+        """A call's records on a rank that resolves its own: kept (views of the context's list, or copies when there are fewer
+        contexts than a step has calls) until the step's last call is here - the protocol runs once per step, over the rank's
+        records of the step in stream order."""
+        if first_call:
+            self._parts = []
+        if self.hold_views:
+            self._parts.append((recs, done))
+        else:
+            self._parts.append((recs.copy(), None))
+            done.set()
+        if not last_call:
+            return
+        rr = self.rr
+        w0, x0 = rr.work_s, rr.exchange_s
+        out = rr.step([p for p, _ in self._parts])
+        if timed:
+            self.resolve_s += rr.work_s - w0
+            self.exchange_s += rr.exchange_s - x0
+            self.msgs += out["lines"]
+        self.step_lines = self.last_lines = out["lines"]
+        if keep and self.root:
+            self.last_text = b"".join(t.tobytes() for t in out["texts"])
+        for _, ev in self._parts:
+            if ev is not None:
+                ev.set()
+        self._parts = []
+
     def drain(self):
         """Block until everything submitted so far is resolved (a released buffer only says its records were taken over).
         Normally the resolver is a few microseconds from done when this is called (the caller has just seen its last
@@ -150,7 +184,7 @@ def split_calls(first_block, nblocks, ncalls, lo, total_bytes):
 
 def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, rank=0, dist=None, coll_device=None,
               cap_records=1 << 16, streams=(None,), device_sync=lambda: None, time_every=8, resolve_threads=1,
-              gather=None, oplog=None, lag=None):
+              gather=None, oplog=None, lag=None, resolve_on="root", ctl_group=None):
     """`warm` untimed + `steps` timed steps of the hot path over this rank's shard `iq` (stream bytes from `lo`;
     a CUDA uint8 tensor - anything sliceable that make_demod()'s detect accepts); a step is the sequence `calls`
     of GPU calls (split_calls).  `depth` contexts (make_demod() each) are used in rotation, so that the GPU always
@@ -175,6 +209,11 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     device with RCCL; "cpu" with gloo: the lists are fetched to the host first).  Returns a dict of measurements
     (rank 0: also the --raw listing of the last step).
 
+    resolve_on="ranks" (world > 1, or gather=True on one rank): no record leaves its rank - every rank fetches its own list
+    like a single GPU's host does and resolves it on its own resolver thread; the ranks exchange whitelist guesses, confirm each
+    other and send their TEXT to rank 0 (distributed.RankResolve; ctl_group: a gloo group for its host-memory all_gathers, made
+    here when not given).  The launching threads then issue no communication call at all between the barriers.
+
     Every rank issues its communication calls in the SAME order - per call n: detect(n), count all_gather(n - 1), list
     transfers(n - 2); at a flush: what is left of the newest calls - whatever its resolver thread is doing: RCCL
     executes a communicator's operations in issue order, so a rank that queued "transfers(n - 1), all_gather(n)" against
@@ -185,6 +224,10 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     from .distributed import RecordGather
 
     dist_on = world > 1 if gather is None else bool(gather)          # records travel through RecordGather
+    ranks_mode = resolve_on == "ranks" and dist_on
+    if ranks_mode:
+        dist_on = False                                              # ... unless every rank resolves its own (RankResolve)
+    sync_ranks = world > 1 or ranks_mode or dist_on
     demods = [make_demod() for _ in range(depth)]
     works = list(streams)
     slots = None
@@ -210,15 +253,23 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     # (the resolver may keep a step's gather buffers until the step's last call arrives only if that call's transfers are
     # queued before the buffers are needed again: see the wait below)
     lag = max(1, len(works) if lag is None else int(lag))
+    rr = None
+    if ranks_mode:
+        from .distributed import RankResolve
+        if ctl_group is None:
+            ctl_group = dist.new_group(backend="gloo")
+        rr = RankResolve(dict(fix=flags["fix"], aggressive=flags["aggressive"], check_crc=True), resolve_threads, ctl_group,
+                         device=coll_device if on_gpu else None, fresh=True)
     resolver = Resolver(dict(fix=flags["fix"], aggressive=flags["aggressive"], check_crc=True), resolve_threads,
-                        hold_views=depth >= len(calls) + (1 + lag if dist_on else 1)) if rank == 0 else None
+                        hold_views=depth >= len(calls) + (1 + lag if dist_on else 1), rank_resolve=rr,
+                        root=rank == 0) if (rank == 0 or ranks_mode) else None
     free = [threading.Event() for _ in range(depth)]          # the resolver is done with context k's record buffer
     for e in free:
         e.set()
 
     def sync_all():
         device_sync()
-        if dist_on:
+        if sync_ranks:
             dist.barrier()
             device_sync()
 
@@ -294,7 +345,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             recs, _, info = demods[k].fetch(copy=False)         # a view of the context's pinned list
             host["fetch"] += time.perf_counter() - t_a
             note(info, timed)
-        if rank == 0:
+        if resolver is not None:
             free[k].clear()
             resolver.submit(recs, counts, tag[0], tag[1], timed, free[k], keep_text=tag[2])
 
@@ -333,6 +384,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                 resolver.drain()
             sync_all()
             prof0 = [d.host_profile() for d in demods if hasattr(d, "host_profile")]
+            if rr is not None:                                  # (its thread is idle: drained above)
+                rr0 = dict(steps=rr.steps, rounds=rr.rounds, reruns=rr.reruns, p2p_ops=rr.p2p_ops, bytes=rr.bytes_moved)
             for key in host:                                    # host time by phase: of the timed calls only (the warm-up
                 host[key] = 0.0                                 # holds one-off costs: list growth, RCCL's connection set-up)
             t0 = time.perf_counter()
@@ -407,7 +460,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     # where the region's last moments go (ms): the calls still in flight when the loop ends, the resolver, the final sync
     tail_ms = {"in_flight": round((t_adv - t_loop) * 1e3, 4), "resolver": round((t_drain - t_adv) * 1e3, 4),
                "sync": round((t0 + elapsed - t_drain) * 1e3, 4)}
-    if dist_on:
+    if sync_ranks:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -424,6 +477,22 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             prof = [{k: p[k] - q[k] for k in p} for p, q in zip(prof, prof0)]
         ncalls_p = max(1, sum(p["calls"] for p in prof))
         out["detect_us_per_call"] = {k: round(sum(p[k] for p in prof) / ncalls_p * 1e6, 2) for k in prof[0] if k != "calls"}
+    if rr is not None:
+        # the protocol's facts over the timed steps (this rank's view; `comm` in the shape the record gather reports it in:
+        # three host-memory all_gathers a step, the texts as point-to-point transfers)
+        nst = max(1, rr.steps - rr0["steps"])
+        out["rank_resolve"] = {"steps": rr.steps - rr0["steps"], "rounds_per_step": round((rr.rounds - rr0["rounds"]) / nst, 3),
+                               "reruns": rr.reruns - rr0["reruns"], "threads": resolve_threads,
+                               "work_ms_per_step": round(resolver.resolve_s / max(1, steps) * 1e3, 4),
+                               "exchange_ms_per_step": round(resolver.exchange_s / max(1, steps) * 1e3, 4),
+                               "text_bytes_per_step": int((rr.bytes_moved - rr0["bytes"]) / nst)}
+        comm.update(calls=(rr.rounds - rr0["rounds"]) * 2 + (rr.steps - rr0["steps"]), p2p_ops=rr.p2p_ops - rr0["p2p_ops"], bytes=rr.bytes_moved - rr0["bytes"])
+        if rank != 0:
+            err = resolver.error
+            resolver.stop()
+            rr.close()
+            if err is not None:
+                raise err
     if rank == 0:
         if resolver.error is not None:
             raise resolver.error
@@ -432,6 +501,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         # step gathered - what bounds an N-GPU step when it exceeds the kernels' time per rank
         out["host_ms_per_call"]["resolve_per_step"] = round(resolver.resolve_s / max(1, steps) * 1e3, 4)
         resolver.stop()
+        if rr is not None:
+            rr.close()
     for d in demods:
         d.close()
     return out

@@ -175,6 +175,42 @@ uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint
 uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
                                     char *out, uint64_t cap, uint64_t *nbytes, int threads);
 
+/* ---- resolve on the ranks that demodulated ------------------------------------------------------
+ * An N-GPU host whose rank 0 would otherwise resolve every rank's records (dump1090.c:896-925, :1183-1210: the
+ * whitelist is the one piece of state that crosses buffers) can leave each list where it is: a rank resolves its
+ * own records from a GUESSED whitelist - the state the batch started from plus what the ranks before it would
+ * write (modes_host_whitelist_guess, exchanged) -, reports what it wrote and which answers it took from the guess
+ * (modes_host_resolve_raw_spec), and the ranks confirm each other in stream order (modes_host_whitelist_check
+ * against the state the ranks before really left); a rank with a wrong answer resolves again from that state.
+ * The listing is the concatenation of the ranks' texts - byte-identical to the sequential resolve, by the argument
+ * of modes_host_resolve_raw_mt.  dump1090_amd/distributed.py (RankResolve) is the protocol around these calls. */
+#define MODES_ICAO_SLOTS 1024u          /* MODES_ICAO_CACHE_LEN, dump1090.c:65 */
+#define MODES_ICAO_NONE 0xFFFFFFFFu     /* "no address" in a guess table (0 is an address a frame can carry) */
+typedef struct {
+    uint32_t addr;                      /* the address asked for (never 0: dump1090.c:920 answers that without the table) */
+    uint32_t known;                     /* 1: the whitelist said yes */
+} modes_icao_lookup;
+
+/* The whitelist itself: addr[s] / seen[s] for the MODES_ICAO_SLOTS slots (dump1090.c:896-925). */
+void modes_host_get_whitelist(const modes_host *h, uint32_t *addr, int64_t *seen);
+void modes_host_set_whitelist(modes_host *h, const uint32_t *addr, const int64_t *seen);
+
+/* guess[s] = the address the records' clean DF11/17/18 frames would leave in slot s (the last one in stream order),
+ * MODES_ICAO_NONE where none would write.  A guess: whether such a frame is decoded at all depends on skip windows.
+ * Uses up to `threads` threads (the lists are only read). */
+void modes_host_whitelist_guess(const modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
+                                uint32_t *guess, int threads);
+
+/* modes_host_resolve_raw_mtv, and besides: written[s] = 1 for every slot the resolve wrote, and lookups[0 .. *nlookups)
+ * = every whitelist question that was answered from the state `h` had on entry (not from a slot written since), in
+ * order.  *nlookups may exceed lookup_cap (then only lookup_cap are stored; 2 per record + 16 always suffice). */
+uint64_t modes_host_resolve_raw_spec(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
+                                     char *out, uint64_t cap, uint64_t *nbytes, int threads,
+                                     uint8_t *written, modes_icao_lookup *lookups, uint64_t lookup_cap, uint64_t *nlookups);
+
+/* 1 when h's whitelist (at h's clock) gives every one of the logged answers, else 0. */
+int modes_host_whitelist_check(const modes_host *h, const modes_icao_lookup *lookups, uint64_t n);
+
 /* dump1090.c:1803: would useModesMessage() display/forward this message? */
 int modes_host_wants(const modes_host *h, const struct modesMessage *mm);
 

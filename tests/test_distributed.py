@@ -101,3 +101,60 @@ def _ragged_worker(rank, world, port, outdir):
         np.save(os.path.join(outdir, "g.npy"), out)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _rank_resolve_worker(rank, world, port, case, fs, outdir):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import oracle as orc
+    import synth
+    from dump1090_amd import HostResolver, block_count, shard_blocks
+    from dump1090_amd.distributed import RankResolve, gather_records
+    from helpers import maxfix_of, oracle_records
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    ctl = dist.new_group(backend="gloo")                  # host memory: the protocol's small all_gathers (and, on CPU, the texts)
+    makers = {"frames": synth.case_frames, "edges_smear": lambda: synth.case_edges(seed=23, smear16=6),
+              "modes1": lambda: synth.modes1_padded(os.path.join(ROOT, "tests", "golden", "modes1.bin"))}
+    data = makers[case]()
+    flags = orc.FLAGSETS[fs]
+    first, n = shard_blocks(block_count(data.size), world, rank)
+    recs, _ = oracle_records(data, maxfix_of(flags), blocks=range(first, first + n))
+    # the rank's records as its GPU calls leave them: two arrays of whole buffers
+    cut = int(np.searchsorted(recs["block"], first + n // 2))
+    segs = [recs[:cut].copy(), recs[cut:].copy()]
+    rr = RankResolve(flags, threads=1, ctl=ctl, fresh=False)
+    out1 = rr.step(segs)
+    text1 = b"".join(t.tobytes() for t in out1["texts"]) if rank == 0 else None
+    out2 = rr.step(segs, spoil=rank > 0)                  # the same records again from the whitelist the first step left; bad starts
+    text2 = b"".join(t.tobytes() for t in out2["texts"]) if rank == 0 else None
+    assert (out1["texts"] is None) == (rank != 0)
+    everything, _ = gather_records(recs, None, dst=0)
+    if rank == 0:
+        seq = HostResolver(**flags)
+        want1 = seq.raw_listing(everything, None)
+        want2 = seq.raw_listing(everything, None)
+        st = seq.stats()
+        assert (out1["lines"], text1) == want1 and (out2["lines"], text2) == want2
+        assert {k: out1["stats"][k] + out2["stats"][k] for k in st if k != "valid_preamble"} == {k: v for k, v in st.items() if k != "valid_preamble"}
+        wl = seq.whitelist()
+        assert np.array_equal(rr.state[0], wl[0]) and np.array_equal(rr.state[1], wl[1])
+        with open(os.path.join(outdir, "out.txt"), "wb") as f:
+            f.write(text1)
+        with open(os.path.join(outdir, "facts.txt"), "w") as f:
+            f.write("%d %d %d" % (rr.steps, rr.rounds, rr.p2p_ops))
+    rr.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case,fs", [(2, "frames", "default"), (3, "edges_smear", "aggressive_nocrc"), (3, "modes1", "default")])
+def test_resolve_on_the_ranks_over_gloo(tmp_path, golden, world, case, fs):
+    """RankResolve: every rank resolves the records of its own buffers, three small all_gathers and the texts travel - the
+    listing rank 0 ends up with is the reference's, over two steps that share the whitelist, the second from spoiled starts."""
+    mp.spawn(_rank_resolve_worker, args=(world, _free_port(), case, fs, str(tmp_path)), nprocs=world, join=True)
+    assert open(tmp_path / "out.txt").read() == golden[case]["raw"][fs]["text"]
+    steps, rounds, p2p = [int(v) for v in open(tmp_path / "facts.txt").read().split()]
+    assert steps == 2 and rounds >= 2 and p2p >= 1

@@ -252,6 +252,101 @@ def test_multithreaded_resolve_rejects_wrong_guesses():
     mt.close()
 
 
+def _rank_pieces(recs, world, rng, calls=2):
+    """recs cut at buffer boundaries into `world` contiguous pieces (stream order = rank order; empty ones are legal), each
+    handed over as up to `calls` arrays of whole buffers - how a rank's GPU calls leave its records."""
+    blocks = np.unique(recs["block"])
+    edges = np.concatenate([blocks, blocks[-1:] + 1]) if blocks.size else np.zeros(1, dtype=np.uint32)
+    cuts = sorted(rng.choice(edges, size=world - 1, replace=True))
+    bounds = [0] + [int(np.searchsorted(recs["block"], c)) for c in cuts] + [recs.size]
+    out = []
+    for r in range(world):
+        piece = recs[bounds[r]: bounds[r + 1]]
+        inner = sorted(rng.choice(edges, size=calls - 1, replace=True))
+        ib = [0] + [int(np.searchsorted(piece["block"], c)) for c in inner] + [piece.size]
+        out.append([piece[ib[i]: ib[i + 1]].copy() for i in range(len(ib) - 1)])
+    return out
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_resolve_on_the_ranks_equals_the_sequential_one(streams, golden, case):
+    """distributed.rank_resolve_step (N ranks' generators in lockstep, LocalRanks): every rank resolves its own records from a
+    guessed whitelist, the ranks confirm each other in stream order - the concatenated texts, the counters and the whitelist
+    the step leaves are those of the sequential resolve of all the records, for any number of ranks, however the buffers
+    fall on them, with every guess spoiled on purpose, and over two steps that share the whitelist."""
+    from dump1090_amd.distributed import LocalRanks
+    data = streams[case]
+    rng = np.random.default_rng(11)
+    for fs in ("default", "aggressive", "nofix"):
+        flags = orc.FLAGSETS[fs]
+        recs, _ = oracle_records(data, maxfix_of(flags))
+        seq = HostResolver(**flags)
+        n0, text0 = seq.raw_listing(recs, None)
+        assert text0.decode() == golden[case]["raw"][fs]["text"]
+        st0 = seq.stats()
+        wl0 = seq.whitelist()
+        n1, text1 = seq.raw_listing(recs, None)                    # a second batch from the whitelist the first left
+        wl1 = seq.whitelist()
+        seq.close()
+        for world, threads, spoil in ((2, 1, ()), (3, -2, ()), (8, 1, ()), (3, 1, (1, 2)), (8, -3, (1, 2, 3, 4, 5, 6, 7))):
+            segs = _rank_pieces(recs, world, rng)
+            lr = LocalRanks(world, flags, threads)
+            text, res = lr.step(segs, spoil=spoil)
+            assert text == text0 and res[0]["lines"] == n0, (case, fs, world, spoil)
+            assert {k: v for k, v in res[0]["stats"].items() if k != "valid_preamble"} == \
+                   {k: v for k, v in st0.items() if k != "valid_preamble"}, (case, fs, world)
+            assert all(r["stats"] == res[0]["stats"] and r["lines"] == n0 for r in res)
+            assert np.array_equal(lr.state[0], wl0[0]) and np.array_equal(lr.state[1], wl0[1]), "the whitelist after the step"
+            text, res = lr.step(_rank_pieces(recs, world, rng), spoil=spoil)
+            assert text == text1 and res[0]["lines"] == n1, (case, fs, world, "second step")
+            assert np.array_equal(lr.state[0], wl1[0]) and np.array_equal(lr.state[1], wl1[1])
+
+
+def test_resolve_on_the_ranks_rejects_wrong_guesses():
+    """The ranks' form of test_multithreaded_resolve_rejects_wrong_guesses: rank 0's clean frame B sits inside A's skip window,
+    so rank 0 never remembers B; rank 1's DF4 validates against B under the guess and must come out unvalidated - rank 1 sees
+    a wrong answer in its log, resolves again from the true state, and the step takes a second round."""
+    from dump1090_amd import RECORD_DTYPE
+    from dump1090_amd.distributed import LocalRanks
+    import synth as sy
+
+    def rec(block, j, frame, syndrome=0):
+        r = np.zeros(1, dtype=RECORD_DTYPE)
+        r["block"], r["j"] = block, j
+        for a in (0, 1):
+            r["att"]["msg"][0, a, :len(frame)] = np.frombuffer(frame, dtype=np.uint8)
+            r["att"]["gate_ok"][0, a] = 1
+            r["att"]["syndrome"][0, a] = syndrome
+            r["att"]["fixpos"][0, a] = (0xFF, 0xFF)
+        return r
+
+    a17 = sy.make_frame(17, sy._payload(1, 14, 1))
+    b17 = sy.make_frame(17, sy._payload(1, 14, 2))
+    addr_b = b17[1:4]
+    data4 = bytes([4 << 3, 0x12, 0x34, 0x56])
+    lib = N.host_lib()
+    crc = lib.modes_compute_crc(data4 + bytes(3), 56)
+    df4 = data4 + bytes([((crc >> 16) & 0xFF) ^ addr_b[0], ((crc >> 8) & 0xFF) ^ addr_b[1], (crc & 0xFF) ^ addr_b[2]])
+    syn4 = lib.modes_checksum(df4, 56)
+    r0 = np.concatenate([rec(0, 100, a17), rec(0, 150, b17)])
+    r1 = rec(1, 100, df4, syndrome=syn4)
+    seq = HostResolver()
+    want = seq.raw_listing(np.concatenate([r0, r1]), None)
+    seq.close()
+    assert want[0] == 1
+    lr = LocalRanks(2, dict(fix=True, aggressive=False, check_crc=True))
+    text, res = lr.step([[r0], [r1]])
+    assert text == want[1] and res[0]["lines"] == 1
+    assert res[1]["reruns"] == 1 and res[0]["reruns"] == 0 and res[0]["rounds"] == 2
+    # the other way round: the guess is right, nothing runs twice
+    text, res = lr.step([[np.concatenate([rec(2, 100, b17)])], [rec(3, 100, df4, syndrome=syn4)]])
+    assert text.count(b"\n") == 2 and [r["reruns"] for r in res] == [0, 0] and res[0]["rounds"] == 1
+    # a rank that starts from a wrong state although the guess was right (spoiled): same text, that rank runs twice
+    lr = LocalRanks(3, dict(fix=True, aggressive=False, check_crc=True))
+    text2, res = lr.step([[rec(2, 100, b17)], [rec(3, 100, df4, syndrome=syn4)], [rec(4, 7, df4, syndrome=syn4), rec(5, 9, a17)]], spoil=(1, 2))
+    assert text2 == text + text[text.index(b"\n") + 1:] + want[1] and [r["reruns"] for r in res] == [0, 1, 1] and res[0]["rounds"] == 3
+
+
 def test_a_listing_that_outgrows_its_buffer_is_cut_at_a_line(streams):
     """include/modes_host.h: when the listing is longer than `cap`, *nbytes still reports the whole length and out holds
     whole lines only, as many as fit - the same for the one-thread and the multi-threaded resolve (which used to copy

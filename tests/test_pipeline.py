@@ -67,7 +67,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_resolver=0.0, lag=None):
+def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_resolver=0.0, lag=None, resolve_on="root"):
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -94,14 +94,23 @@ def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_res
     if slow_resolver:                                            # rank 0's sequential half falls behind its GPU
         import time
         from dump1090_amd import demod
-        fast1, fastv = demod.HostResolver.raw_listing, demod.HostResolver.raw_listing_segments
+        fast1, fastv, fasts = demod.HostResolver.raw_listing, demod.HostResolver.raw_listing_segments, demod.HostResolver.raw_listing_spec
         demod.HostResolver.raw_listing = lambda self, *a, **k: (time.sleep(slow_resolver), fast1(self, *a, **k))[1]
         demod.HostResolver.raw_listing_segments = lambda self, *a, **k: (time.sleep(2 * slow_resolver), fastv(self, *a, **k))[1]
+        # (resolve on the ranks: one rank's resolver slower than the other's - the ranks wait for each other in the exchanges only)
+        demod.HostResolver.raw_listing_spec = lambda self, *a, **k: (time.sleep(slow_resolver * (1 + rank)), fasts(self, *a, **k))[1]
     oplog = []
     out = run_steps(make, data[lo:hi], lo, calls, dict(fix=True, aggressive=False), steps=2, warm=1, depth=depth,
-                    world=world, rank=rank, dist=dist, coll_device="cpu", cap_records=4096, oplog=oplog, lag=lag)
+                    world=world, rank=rank, dist=dist, coll_device="cpu", cap_records=4096, oplog=oplog, lag=lag, resolve_on=resolve_on)
     assert sum(d.calls for d in made) == 3 * ncalls and out["calls_per_step"] == ncalls
-    if world > 1:
+    if resolve_on == "ranks":
+        # no record left its rank: the launching threads issued no communication call at all; three all_gathers a step and the texts
+        assert [op for op, _ in oplog] == ["detect"] * (3 * ncalls)
+        rr = out["rank_resolve"]
+        assert rr["steps"] == 2 and rr["rounds_per_step"] == 1.0 and rr["reruns"] == 0
+        if rank == 0:
+            assert out["comm"]["bytes"] > 0 and out["comm"]["p2p_ops"] >= 2 and rr["text_bytes_per_step"] > 0
+    elif world > 1:
         # every rank issued its communication calls in the same order (RCCL executes them in issue order: a rank that
         # deviates deadlocks the job) - per call n: detect(n), counts(n - 1), records(n - 2)
         logs = [None] * world
@@ -119,10 +128,10 @@ def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_res
         dist.destroy_process_group()
 
 
-def _spawn2(args, deadline=180.0):
+def _spawn2(args, deadline=180.0, nprocs=2):
     """Two ranks; a hang (ranks waiting for each other) is a failure, not a stuck test run."""
     import time
-    ctx = mp.spawn(_run, args=args, nprocs=2, join=False)
+    ctx = mp.spawn(_run, args=args, nprocs=nprocs, join=False)
     t0 = time.time()
     while not ctx.join(timeout=2.0):
         if time.time() - t0 > deadline:
@@ -152,6 +161,16 @@ def test_two_ranks_same_communication_order(tmp_path, golden, case, ncalls, dept
     on gloo, with rank 0's resolver slower than its detector, buffers held by the resolver (depth >= calls + 1 + lag) or
     copied: the ranks' sequences of communication calls must not diverge."""
     _spawn2((2, _free_port(), case, ncalls, depth, str(tmp_path), True, slow, lag))
+    assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
+
+
+@pytest.mark.parametrize("world,case,ncalls,depth,slow", [(2, "frames", 1, 3, 0.0), (2, "edges", 2, 3, 0.03), (2, "edges", 3, 2, 0.0),
+                                                          (3, "edges", 2, 4, 0.02), (2, "frames", 2, 1, 0.0)])
+def test_ranks_resolve_their_own_records(tmp_path, golden, world, case, ncalls, depth, slow):
+    """run_steps(resolve_on="ranks"): every rank fetches its own list and resolves it on its own resolver thread
+    (distributed.RankResolve); rank 0 ends up with the reference's listing, whatever the split into ranks and calls, with
+    buffers held until a step is resolved (depth > calls) or copied, and with resolvers of different speed."""
+    _spawn2((world, _free_port(), case, ncalls, depth, str(tmp_path), False, slow, None, "ranks"), nprocs=world)
     assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
 
 
