@@ -390,6 +390,7 @@ class RankResolve:
             self.stream = torch.cuda.Stream(device=self.device)
             self._grow(cap_bytes)
         self.work_s = self.exchange_s = 0.0                 # seconds in the C calls / inside the exchanges (waiting for peers included)
+        self.phase_s = [0.0] * 8                            # work_s by stretch between exchanges: guess, resolve, check, totals, end (+ re-runs)
         self.steps = self.reruns = self.rounds = 0
         self.bytes_moved = self.p2p_ops = 0
 
@@ -482,9 +483,12 @@ class RankResolve:
         gen = rank_resolve_step(self.make, self.rank, self.world, self.state, segments, self.threads, now, spoil, buf)
         t = time.perf_counter()
         ask = next(gen)
+        ph = 0
         while True:
             t1 = time.perf_counter()
             self.work_s += t1 - t
+            self.phase_s[min(ph, 7)] += t1 - t
+            ph += 1
             reply = self._gather(ask[1]) if ask[0] == "gather" else self._texts(ask[1], ask[2])
             t = time.perf_counter()
             self.exchange_s += t - t1
@@ -494,6 +498,7 @@ class RankResolve:
                 out = e.value
                 break
         self.work_s += time.perf_counter() - t
+        self.phase_s[min(ph, 7)] += time.perf_counter() - t
         self.state = out["whitelist"]
         self._prev = out.pop("resolver")                    # rank 0's own text is a view of its buffer: alive until the next step
         self.steps += 1

@@ -385,7 +385,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             sync_all()
             prof0 = [d.host_profile() for d in demods if hasattr(d, "host_profile")]
             if rr is not None:                                  # (its thread is idle: drained above)
-                rr0 = dict(steps=rr.steps, rounds=rr.rounds, reruns=rr.reruns, p2p_ops=rr.p2p_ops, bytes=rr.bytes_moved)
+                rr0 = dict(steps=rr.steps, rounds=rr.rounds, reruns=rr.reruns, p2p_ops=rr.p2p_ops, bytes=rr.bytes_moved, phase=list(rr.phase_s))
             for key in host:                                    # host time by phase: of the timed calls only (the warm-up
                 host[key] = 0.0                                 # holds one-off costs: list growth, RCCL's connection set-up)
             t0 = time.perf_counter()
@@ -485,7 +485,9 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                                "reruns": rr.reruns - rr0["reruns"], "threads": resolve_threads,
                                "work_ms_per_step": round(resolver.resolve_s / max(1, steps) * 1e3, 4),
                                "exchange_ms_per_step": round(resolver.exchange_s / max(1, steps) * 1e3, 4),
-                               "text_bytes_per_step": int((rr.bytes_moved - rr0["bytes"]) / nst)}
+                               "text_bytes_per_step": int((rr.bytes_moved - rr0["bytes"]) / nst),
+                               # the work by stretch between the exchanges: [guess, resolve, check, totals, end] (+ re-run rounds)
+                               "work_ms_by_phase": [round((a - b) / nst * 1e3, 4) for a, b in zip(rr.phase_s, rr0["phase"])]}
         comm.update(calls=(rr.rounds - rr0["rounds"]) * 2 + (rr.steps - rr0["steps"]), p2p_ops=rr.p2p_ops - rr0["p2p_ops"], bytes=rr.bytes_moved - rr0["bytes"])
         if rank != 0:
             err = resolver.error
