@@ -75,6 +75,7 @@ struct Options {
     uint32_t gather_cap = 1u << 18;        // --gather-records: records per rank and round the gather buffers hold
     char **argv = nullptr;                 // for the one restart --ranks may need (the other IPC mode)
     uint32_t gather_cands = 0;             // --gather-candidates: preamble positions per rank and round (--stats); 0 = positions of a batch / 64
+    bool resolve_on_ranks = false;         // --resolve-on-ranks: with --ranks and --raw, every rank resolves its own batch; only text reaches rank 0
 };
 
 struct Sink {
@@ -104,6 +105,9 @@ void show_help() {
         "                         A pipe (--ifile -) and --loop have ONE reader: rank 0 reads and hands every rank its batches\n"
         "                         through shared memory.  --gpus <n> (one process, the same devices) is the faster of the two for\n"
         "                         any input below ~96 GB: a communicator takes 1.6 s to start (a minute on a fresh box).\n"
+        "--resolve-on-ranks       With --ranks and --raw: every rank resolves its own batches from a guessed whitelist, the ranks\n"
+        "                         confirm each other in stream order through shared memory and rank 0 prints their texts - no\n"
+        "                         record leaves its rank, no communicator is made (the listing is the same).\n"
         "--gather-records <n>     With --ranks: records per rank and round the gather buffers hold (default: 262144).\n"
         "--gather-candidates <n>  With --ranks --stats: preamble positions per rank and round (default: a batch's positions / 64).\n"
         "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).\n"
@@ -320,13 +324,44 @@ int run_ranks(const Options &opt, double t_start) {
         for (size_t i = 0; i < nslots; i++) { new (&feed_slots[i]) FeedSlot; feed_slots[i].seq.store(0); feed_slots[i].nbytes = 0; }
         feed_mem = static_cast<uint8_t *>(m) + ctl;
     }
+    // --resolve-on-ranks (include/modes_host.h "resolve on the ranks that demodulated"; dump1090_amd/distributed.py has the same protocol over
+    // torch.distributed): every rank resolves its own batch of a round from a guessed whitelist; what the ranks tell each other - guesses,
+    // what they wrote, their texts - lies in a mapping made before the fork, a sequence number per (round slot, rank) and table says when
+    // it is there.  The ranks of a round confirm each other IN ORDER: rank r waits for rank r - 1 to be final, so the state it rebuilds from
+    // the tables of the ranks before it is the true one; it checks its logged answers against it (and resolves again if one is wrong) and
+    // is final itself.  Rank 0 prints the texts of a round in rank order.  No record leaves its rank, no communicator exists.
+    const bool rr = opt.resolve_on_ranks;
+    struct RrRank {                                                           // one per (round slot, rank)
+        std::atomic<uint64_t> guess_seq, final_seq;                           // round + 1 once `guess` / everything else is published
+        uint64_t lines, nbytes;
+        uint32_t guess[MODES_ICAO_SLOTS];
+        uint32_t w_addr[MODES_ICAO_SLOTS];
+        int64_t w_seen[MODES_ICAO_SLOTS];
+        uint8_t written[MODES_ICAO_SLOTS];
+    };
+    struct RrHead { std::atomic<uint64_t> printed; std::atomic<int> failed; std::atomic<uint64_t> reruns; int64_t now[16]; };   // printed: rounds rank 0 has written out
+    RrHead *rr_head = nullptr;
+    RrRank *rr_ranks = nullptr;
+    char *rr_text = nullptr;
+    const size_t rr_text_cap = ((size_t)opt.gather_cap * 62 + 64 + 4095) & ~(size_t)4095;     // two 31-byte lines per record at most
+    if (rr) {
+        if (depth > 16) { fprintf(stderr, "--resolve-on-ranks: --depth %d (at most 16)\n", depth); return 1; }
+        const size_t ctl = (sizeof(RrHead) + (size_t)depth * (size_t)N * sizeof(RrRank) + 4095) & ~(size_t)4095;
+        void *m = mmap(nullptr, ctl + (size_t)depth * (size_t)N * rr_text_cap, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (m == MAP_FAILED) { perror("--resolve-on-ranks: shared buffers"); return 1; }
+        rr_head = new (m) RrHead;
+        rr_head->printed.store(0); rr_head->failed.store(0); rr_head->reruns.store(0);
+        rr_ranks = reinterpret_cast<RrRank *>(static_cast<uint8_t *>(m) + sizeof(RrHead));
+        for (size_t i = 0; i < (size_t)depth * (size_t)N; i++) { new (&rr_ranks[i]) RrRank; rr_ranks[i].guess_seq.store(0); rr_ranks[i].final_seq.store(0); }
+        rr_text = static_cast<char *>(m) + ctl;
+    }
     if (!opt.devices.empty() && (int)opt.devices.size() != N) { fprintf(stderr, "--ranks %d with a --gpu-list of %zu devices\n", N, opt.devices.size()); return 1; }
     // this pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffers fail (hipIpcGetMemHandle:
     // invalid argument).  Kept if the caller has set it.
     setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     // the unique id travels from rank 0 to rank r through a pipe made before the fork; no HIP / RCCL call precedes the fork
     std::vector<int> rd((size_t)N, -1), wr((size_t)N, -1);
-    for (int r = 1; r < N; r++) {
+    for (int r = 1; r < N && !rr; r++) {
         int fds[2];
         if (pipe(fds) != 0) { perror("pipe"); return 1; }
         rd[(size_t)r] = fds[0];
@@ -396,7 +431,7 @@ int run_ranks(const Options &opt, double t_start) {
                 usleep(50 * 1000);
             }
         });
-    for (int r = 1; r < N; r++) {                                            // keep only this rank's end(s)
+    for (int r = 1; r < N && !rr; r++) {                                     // keep only this rank's end(s)
         if (rank == 0) close(rd[(size_t)r]);
         else { close(wr[(size_t)r]); if (r != rank) close(rd[(size_t)r]); }
     }
@@ -421,10 +456,11 @@ int run_ranks(const Options &opt, double t_start) {
     FILE *out = saved_stdout >= 0 ? fdopen(saved_stdout, "w") : nullptr;
     if (!out || dup2(2, 1) < 0) { perror("--ranks: stdout"); return finish(1); }
     GatherApi G;
-    if (!G.load()) return finish(1);
+    if (!rr && !G.load()) return finish(1);
     const double t_loaded = now_s();
     unsigned char id[MODES_GATHER_ID_BYTES];
-    if (rank == 0) {
+    if (rr) {
+    } else if (rank == 0) {
         if (G.unique_id(id) != MODES_OK) { fprintf(stderr, "--ranks: %s\n", G.last_error(nullptr)); return finish(1); }
         for (int r = 1; r < N; r++) { if (!write_all(wr[(size_t)r], id, sizeof id)) { perror("--ranks: id pipe"); return finish(1); } close(wr[(size_t)r]); }
     } else {
@@ -461,7 +497,8 @@ int run_ranks(const Options &opt, double t_start) {
     modes_gather_config gc{device, rank, N, opt.gather_cap, (uint32_t)depth, cap_cands};
     modes_gather *g = nullptr;
     const double t_id = now_s();
-    if (const int crc = G.create(&gc, id, &g); crc != MODES_OK) {
+    if (rr) {
+    } else if (const int crc = G.create(&gc, id, &g); crc != MODES_OK) {
         fprintf(stderr, "--ranks: rank %d: %s\n", rank, G.last_error(nullptr));
         if (crc == MODES_GATHER_ERR_PROBE) {
             if (rank != 0) { fflush(stderr); _exit(kProbeStatus); }              // rank 0's watchdog takes it from here
@@ -484,7 +521,12 @@ int run_ranks(const Options &opt, double t_start) {
         uint64_t cap = 0;
         if (modes_gpu_create(&cfg, &lanes[(size_t)l].gpu) != MODES_OK) { fprintf(stderr, "rank %d: GPU init failed: %s\n", rank, modes_gpu_last_error(nullptr)); return finish(1); }
         modes_gpu_set_timing(lanes[(size_t)l].gpu, 0);
-        if (G.output(g, (uint32_t)l, &d_rec, &cap, &d_cnt) != MODES_OK || modes_gpu_set_output(lanes[(size_t)l].gpu, d_rec, cap, d_cnt) != MODES_OK ||
+        if (rr) {                                                            // the list stays on this rank: the context's own pinned list (modes_gpu_fetch)
+            if (modes_gpu_host_alloc(lanes[(size_t)l].gpu, MODES_CARRY_BYTES + batch_bytes, &p) != MODES_OK) {
+                fprintf(stderr, "rank %d: %s\n", rank, modes_gpu_last_error(lanes[(size_t)l].gpu));
+                return finish(1);
+            }
+        } else if (G.output(g, (uint32_t)l, &d_rec, &cap, &d_cnt) != MODES_OK || modes_gpu_set_output(lanes[(size_t)l].gpu, d_rec, cap, d_cnt) != MODES_OK ||
             modes_gpu_host_alloc(lanes[(size_t)l].gpu, MODES_CARRY_BYTES + batch_bytes, &p) != MODES_OK) {
             fprintf(stderr, "rank %d: %s / %s\n", rank, G.last_error(g), modes_gpu_last_error(lanes[(size_t)l].gpu));
             return finish(1);
@@ -492,7 +534,8 @@ int run_ranks(const Options &opt, double t_start) {
         lanes[(size_t)l].buf = static_cast<uint8_t *>(p);
     }
     modes_host_config hcfg{opt.fix_errors, opt.aggressive ? 1 : 0, opt.check_crc, 0};
-    modes_host *host = rank == 0 ? modes_host_create(&hcfg) : nullptr;
+    modes_host *host = (rank == 0 || rr) ? modes_host_create(&hcfg) : nullptr;
+    modes_host *probe = rr ? modes_host_create(&hcfg) : nullptr;              // (--resolve-on-ranks: checks logged answers against a rebuilt state)
     Sink sink{&opt, host, {}, (rank == 0 && opt.sbs) ? modes_tracker_create() : nullptr};
     const bool raw_fast = opt.raw && !opt.stats && !opt.sbs && !opt.raw_net && !opt.onlyaddr;
     std::vector<char> rawbuf;
@@ -542,6 +585,98 @@ int run_ranks(const Options &opt, double t_start) {
     std::vector<char> has((size_t)depth, 0);
     int rc = 0;
     auto fail_rank = [&](const char *what, const char *text) { fprintf(stderr, "rank %d: %s: %s\n", rank, what, text); rc = 1; };
+    // ---- --resolve-on-ranks: round qq of this rank (its batch's kernels are queued; the next batch's already run) ----
+    std::vector<uint32_t> truth_addr(MODES_ICAO_SLOTS, 0), st_addr(MODES_ICAO_SLOTS);       // the whitelist every round < qq left (the same on every rank)
+    std::vector<int64_t> truth_seen(MODES_ICAO_SLOTS, 0), st_seen(MODES_ICAO_SLOTS);
+    std::vector<modes_icao_lookup> lookups;
+    uint64_t rr_applied = 0;                                                 // rounds whose writes are in `truth`
+    auto rr_at = [&](uint64_t round, int r) -> RrRank & { return rr_ranks[(size_t)(round % (uint64_t)depth) * (size_t)N + (size_t)r]; };
+    auto rr_wait = [&](const std::atomic<uint64_t> &a, uint64_t v) {         // false: another rank failed (or this one's peers are gone)
+        for (int spin = 0; a.load(std::memory_order_acquire) < v; spin++) {
+            if (rr_head->failed.load()) return false;
+            if (spin > 200) usleep(20);
+        }
+        return true;
+    };
+    auto rr_apply = [&](std::vector<uint32_t> &addr, std::vector<int64_t> &seen, const RrRank &w) {
+        for (uint32_t sidx = 0; sidx < MODES_ICAO_SLOTS; sidx++)
+            if (w.written[sidx]) { addr[sidx] = w.w_addr[sidx]; seen[sidx] = w.w_seen[sidx]; }
+    };
+    auto rr_round = [&](uint64_t qq, bool have) -> bool {
+        const int l = (int)(qq % (uint64_t)depth);
+        RrRank &me = rr_at(qq, rank);
+        // the slot's previous tenant: round qq - depth, printed?
+        if (qq >= (uint64_t)depth && !rr_wait(rr_head->printed, qq - (uint64_t)depth + 1)) return false;
+        const modes_record *recs = nullptr;
+        uint64_t nrec = 0;
+        if (have) {
+            modes_gpu_result res{};
+            if (modes_gpu_fetch(lanes[(size_t)l].gpu, &res) != MODES_OK) { fail_rank("GPU demodulation failed", modes_gpu_last_error(lanes[(size_t)l].gpu)); return false; }
+            recs = res.records;
+            nrec = res.n_records;
+            if (nrec > opt.gather_cap) { fail_rank("resolve", "a batch's records exceed --gather-records (the text buffers are sized by it)"); return false; }
+        }
+        modes_host_whitelist_guess(host, &recs, &nrec, 1, me.guess, opt.resolve_threads);
+        if (rank == 0) rr_head->now[l] = feed ? (int64_t)time(nullptr) : 0;   // one clock per round: rank 0's (a live stream: dump1090.c:913,924)
+        me.guess_seq.store(qq + 1, std::memory_order_release);
+        // the state the round starts from: every earlier round, final on every rank
+        for (; rr_applied < qq; rr_applied++)
+            for (int r = 0; r < N; r++) {
+                if (!rr_wait(rr_at(rr_applied, r).final_seq, rr_applied + 1)) return false;
+                rr_apply(truth_addr, truth_seen, rr_at(rr_applied, r));
+            }
+        st_addr = truth_addr;
+        st_seen = truth_seen;
+        if (!rr_wait(rr_at(qq, 0).guess_seq, qq + 1)) return false;
+        const int64_t now = rr_head->now[l];
+        for (int r = 0; r < rank; r++) {                                     // ... overlaid with what the ranks before this one expect to write
+            const RrRank &o = rr_at(qq, r);
+            if (!rr_wait(o.guess_seq, qq + 1)) return false;
+            for (uint32_t sidx = 0; sidx < MODES_ICAO_SLOTS; sidx++)
+                if (o.guess[sidx] != MODES_ICAO_NONE) { st_addr[sidx] = o.guess[sidx]; st_seen[sidx] = now; }
+        }
+        if (const char *sp = getenv("MODES_RR_SPOIL"); sp && *sp && rank > 0) { std::fill(st_addr.begin(), st_addr.end(), 0u); std::fill(st_seen.begin(), st_seen.end(), (int64_t)0); }   // tests: a wrong start
+        char *text = rr_text + ((size_t)l * (size_t)N + (size_t)rank) * rr_text_cap;
+        lookups.resize((size_t)nrec * 2 + 16);
+        uint64_t nb = 0, nl = 0, lines = 0;
+        auto resolve_from = [&](const std::vector<uint32_t> &addr, const std::vector<int64_t> &seen) {
+            modes_host_set_time(host, now);
+            modes_host_set_whitelist(host, addr.data(), seen.data());
+            lines = modes_host_resolve_raw_spec(host, &recs, &nrec, 1, text, rr_text_cap, &nb, opt.resolve_threads, me.written, lookups.data(), lookups.size(), &nl);
+        };
+        resolve_from(st_addr, st_seen);
+        // confirmation, in rank order: the ranks before this one are final -> their tables give the true start
+        if (rank > 0) {
+            if (!rr_wait(rr_at(qq, rank - 1).final_seq, qq + 1)) return false;
+            st_addr = truth_addr;
+            st_seen = truth_seen;
+            for (int r = 0; r < rank; r++) rr_apply(st_addr, st_seen, rr_at(qq, r));
+            modes_host_set_time(probe, now);
+            modes_host_set_whitelist(probe, st_addr.data(), st_seen.data());
+            if (nl > lookups.size() || !modes_host_whitelist_check(probe, lookups.data(), nl)) {
+                resolve_from(st_addr, st_seen);                              // rare: an answer taken from the guess was wrong
+                rr_head->reruns.fetch_add(1);
+            }
+        }
+        if (nb >= rr_text_cap) { fail_rank("resolve", "the text of a batch outgrew its buffer"); return false; }
+        modes_host_get_whitelist(host, me.w_addr, me.w_seen);
+        me.lines = lines;
+        me.nbytes = nb;
+        me.final_seq.store(qq + 1, std::memory_order_release);
+        if (rank == 0) {                                                     // the round's listing, rank after rank
+            for (int r = 0; r < N; r++) {
+                const RrRank &o = rr_at(qq, r);
+                if (!rr_wait(o.final_seq, qq + 1)) return false;
+                if (o.nbytes) fwrite(rr_text + ((size_t)l * (size_t)N + (size_t)r) * rr_text_cap, 1, (size_t)o.nbytes, out);
+                n_messages_out += o.lines;
+            }
+            fflush(out);
+            // (every rank reads a round's tables when it starts the NEXT round; the slot is written again depth rounds later, by ranks that
+            //  have been through the round after this one - which needs every rank final there, i.e. past its reading of these)
+            rr_head->printed.store(qq + 1, std::memory_order_release);
+        }
+        return true;
+    };
     for (uint64_t q = 0; (nrounds == ~0ull || q < nrounds + 2) && !rc; q++) {
         if (nrounds == ~0ull || q < nrounds) {                               // submit this rank's batch of round q
             const int l = (int)(q % (uint64_t)depth);
@@ -586,6 +721,10 @@ int run_ranks(const Options &opt, double t_start) {
                     fail_rank("GPU demodulation failed", modes_gpu_last_error(lanes[(size_t)l].gpu));
             }
         }
+        if (rr) {
+            if (q >= 1 && q - 1 < nrounds && !rc && !rr_round(q - 1, has[(size_t)((q - 1) % (uint64_t)depth)] != 0) && !rc) fail_rank("resolve", "another rank failed");
+            continue;
+        }
         if (q >= 1 && q - 1 < nrounds && !rc) {                              // round q - 1: kernels done -> lengths -> transfers
             const int l = (int)((q - 1) % (uint64_t)depth);
             if (has[(size_t)l]) {
@@ -624,6 +763,7 @@ int run_ranks(const Options &opt, double t_start) {
     }
     const double t_end = now_s();
     if (feed && rc) feed_head->failed.store(1);                              // (the reader and the other ranks stop waiting for slots)
+    if (rr && rc) rr_head->failed.store(1);
     if (reader.joinable()) { if (rc) reader.detach(); else reader.join(); }
     if (feed) size = (size_t)fed_bytes;                                      // what --timing reports (rank 0 knows it)
     if (rc) {
@@ -644,7 +784,13 @@ int run_ranks(const Options &opt, double t_start) {
         fputs(text, out);
         fflush(out);
     }
-    if (rank == 0 && opt.timing) {
+    if (rank == 0 && opt.timing && rr) {
+        const double stream_s = t_end - t_ready;
+        fprintf(stderr, "{\"bytes\": %zu, \"ranks\": %d, \"rounds\": %llu, \"init_s\": %.4f, \"stream_s\": %.4f, \"total_s\": %.4f, \"stream_GBps\": %.2f, "
+                        "\"sink_calls\": %llu, \"resolve_on\": \"ranks\", \"reruns\": %llu}\n",
+                size, N, (unsigned long long)nrounds, t_ready - t_start, stream_s, t_end - t_start, stream_s > 0 ? size / stream_s / 1e9 : 0.0,
+                (unsigned long long)n_messages_out, (unsigned long long)rr_head->reruns.load());
+    } else if (rank == 0 && opt.timing) {
         modes_gather_stats st{};
         G.get_stats(g, &st);
         const double stream_s = t_end - t_ready;
@@ -658,9 +804,10 @@ int run_ranks(const Options &opt, double t_start) {
                 (unsigned long long)st.bytes_received, st.gather_ms);
     }
     if (host) modes_host_destroy(host);
+    if (probe) modes_host_destroy(probe);
     modes_tracker_destroy(sink.tracker);
     for (auto &ln : lanes) { modes_gpu_host_free(ln.gpu, ln.buf); modes_gpu_destroy(ln.gpu); }
-    G.destroy(g);
+    if (!rr) G.destroy(g);
     if (map) munmap(const_cast<uint8_t *>(map), size);
     if (fd > 0) close(fd);
     return finish(rc);
@@ -700,6 +847,7 @@ int main(int argc, char **argv) {
             }
         }
         else if (!strcmp(a, "--ranks") && more) opt.ranks = atoi(argv[++j]);
+        else if (!strcmp(a, "--resolve-on-ranks")) opt.resolve_on_ranks = true;
         else if (!strcmp(a, "--gather-records") && more) opt.gather_cap = (uint32_t)strtoul(argv[++j], nullptr, 10);
         else if (!strcmp(a, "--gather-candidates") && more) opt.gather_cands = (uint32_t)strtoul(argv[++j], nullptr, 10);
         else if (!strcmp(a, "--batch-blocks") && more) opt.batch_blocks = strtoull(argv[++j], nullptr, 10);
@@ -728,8 +876,14 @@ int main(int argc, char **argv) {
             if (in_file < opt.batch_blocks) opt.batch_blocks = in_file;
         }
         if (ngpus > 0) { fprintf(stderr, "--ranks and --gpus are two ways to use N GPUs: give one of them\n"); return 1; }
+        if (opt.resolve_on_ranks && !(opt.raw && !opt.stats && !opt.sbs && !opt.raw_net && !opt.onlyaddr)) {
+            // (--stats needs every preamble position in one place, --sbs the aircraft table in stream order: rank 0's business)
+            fprintf(stderr, "--resolve-on-ranks serves the --raw listing only (no --stats, --sbs, --raw-net, --onlyaddr): leave it out for those\n");
+            return 1;
+        }
         return run_ranks(opt, t_start);
     }
+    if (opt.resolve_on_ranks) { fprintf(stderr, "--resolve-on-ranks goes with --ranks <n>\n"); return 1; }
     if (opt.devices.empty()) {
         if (ngpus > 0) for (int d = 0; d < ngpus; d++) opt.devices.push_back(d);
         else opt.devices.push_back(single_device);

@@ -385,6 +385,45 @@ def test_cli_one_process_per_gpu_reads_a_pipe_and_replays_a_file(torch_cuda, str
     assert outs[0] == outs[1] and len(outs[0]) == n and outs[0][:len(one)] == one
 
 
+@pytest.mark.parametrize("nranks", [1, 2, 3])
+def test_cli_ranks_resolve_their_own_batches(torch_cuda, golden, streams, tmp_path, nranks):
+    """dump1090_amd --ranks N --resolve-on-ranks: N real PROCESSES, each with its own contexts on the GPU at hand (--gpu-list 0,0,...:
+    no communicator exists in this mode, so the ranks may share a device), every rank resolving its own batches from a guessed
+    whitelist, the confirmation in rank order and the texts through shared memory - stdout is the reference's listing, for a file,
+    a pipe and a replay; the low-SNR stream under --aggressive (retries, two-bit repairs) included."""
+    exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
+    ranks = ["--ranks", str(nranks), "--gpu-list", ",".join(["0"] * nranks), "--resolve-on-ranks"]
+    for case, batch, flags, name in (("modes1", 1, [], "default"), ("frames", 2, [], "default"), ("edges_smear", 1, ["--aggressive"], "aggressive"),
+                                     ("lowsnr", 1, ["--aggressive"], "aggressive"), ("frames", 1, ["--no-fix"], "nofix")):
+        path = tmp_path / (case + ".bin")
+        streams[case].tofile(path)
+        p = subprocess.run([exe, "--ifile", str(path), "--raw", "--batch-blocks", str(batch), "--timing"] + flags + ranks, capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-600:]
+        assert p.stdout.decode() == golden[case]["raw"][name]["text"] and len(p.stdout) > 0, (case, flags, nranks)
+        t = json.loads([ln for ln in p.stderr.decode().splitlines() if ln.startswith("{")][-1])
+        assert t["ranks"] == nranks and t["resolve_on"] == "ranks" and t["sink_calls"] == p.stdout.count(b"\n")
+    pad = tmp_path / "pad.bin"
+    synth.modes1_padded(os.path.join(ROOT, "tests", "golden", "modes1.bin")).tofile(pad)
+    one = subprocess.run([exe, "--ifile", str(pad), "--raw"], capture_output=True, check=True).stdout
+    with open(pad, "rb") as f:
+        p = subprocess.run([exe, "--ifile", "-", "--raw", "--batch-blocks", "1"] + ranks, stdin=f, capture_output=True, timeout=300)
+    assert p.returncode == 0 and p.stdout == one and hashlib.md5(one).hexdigest() == "4a81758c8bec5e45ffa8541c5622938a", p.stderr[-600:]
+    n = len(one) * 5 // 2
+    outs = []
+    for extra in ([], ranks):
+        q = subprocess.Popen([exe, "--ifile", str(pad), "--raw", "--loop", "--batch-blocks", "1"] + extra, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        got = b""
+        while len(got) < n:
+            chunk = q.stdout.read(n - len(got))
+            if not chunk:
+                break
+            got += chunk
+        q.kill()
+        q.wait()
+        outs.append(got)
+    assert outs[0] == outs[1] and len(outs[0]) == n
+
+
 def test_cli_more_ranks_than_gpus_fails_instead_of_hanging(torch_cuda, streams, tmp_path):
     """dump1090_amd --ranks 2 on a box with one GPU: rank 1 has no device, rank 0 already waits in the communicator's
     rendezvous.  Rank 0's watchdog ends the job: status 1 and a message, not a hang."""

@@ -411,7 +411,7 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "ranks-host"], capture_output=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout[-800:], p.stderr[-800:])
     # the reference's listing: 9 files x (N, batch size), N = 8, 6 pipes (--ifile -, round 5) and 3 restarts
-    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 19 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
+    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 19 + 11 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
     # (three of them: the start-up probe of the communicator fails - on every rank, on a peer, on rank 0 - and rank 0 starts the
     # job over once with the other IPC mode; that second run prints the listing)
     assert p.stdout.count(b", 1 restart") == 3
@@ -419,7 +419,7 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     assert p.stdout.count(b"fails to start: exit status 1") == 3
     # ... and so does a rank whose GPU call fails mid-stream, with its peer already inside that round's exchange (no teardown of
     # the communicator on that path: ADVICE round 3)
-    assert p.stdout.count(b"fails in GPU call") == 2 and p.stdout.count(b": exit status 1") == 6
+    assert p.stdout.count(b"fails in GPU call") == 2 and p.stdout.count(b": exit status 1") == 7      # (+ --resolve-on-ranks --stats, refused)
     # --stats through the gather's second list (every rank's preamble positions on rank 0): the reference's nine lines for N = 1, 2, 3;
     # a list that outgrows its buffers fails the job
     assert p.stdout.count(b"md5 bc3d1c04b24f4989f0fc4a2d1f45abdd") == 8        # N = 1, 2, 3 x two batch sizes, N = 8, and a pipe with N = 2
@@ -427,7 +427,16 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     assert b"--stats with 8 positions of room: exit status 1" in p.stdout
     # round 5: a pipe and --loop through --ranks (rank 0 reads, shared-memory slots): the pipe's listing for N = 1, 2, 3 x two batch sizes
     # is counted above; the replay's first 2.5 laps equal the one-process host's
-    assert p.stdout.count(b"--ifile - --ranks") == 6 and b"--loop --ranks 2 / 3: the first" in p.stdout
+    assert p.stdout.count(b"   --ifile - --ranks") == 6 and b"   --loop --ranks 2 / 3: the first" in p.stdout
+    # --resolve-on-ranks (every rank resolves its own batches, the ranks confirm each other through shared memory, rank 0 prints the texts;
+    # no gather library): N = 1, 2, 3, 8 x two batch sizes, a pipe, a replay; on a stream whose DF4 / DF5 / DF20 frames only validate against
+    # an address an earlier rank remembered: right guesses are kept (0 re-runs), wrong starts are noticed and resolved again - same listing
+    assert p.stdout.count(b"--resolve-on-ranks --ranks") == 8 + 2 + 4 and b"--resolve-on-ranks --ifile - --ranks 3: md5 4a81758c" in p.stdout
+    assert p.stdout.count(b"on AP-validated frames: md5 524f28a5613c2468123104e0a17e61f8, 0 re-run(s)") == 2
+    assert b"--ranks 2 on AP-validated frames, wrong starts: md5 524f28a5613c2468123104e0a17e61f8, 1 re-run(s)" in p.stdout
+    assert b"--ranks 3 on AP-validated frames, wrong starts: md5 524f28a5613c2468123104e0a17e61f8, 2 re-run(s)" in p.stdout
+    assert b"--resolve-on-ranks --loop --ranks 2 / 3: the first" in p.stdout and b"--resolve-on-ranks --stats: exit status 1" in p.stdout
+    assert p.stdout.count(b"fails in its GPU call") == 2 and p.stdout.count(b": status 1") == 2       # a failing rank ends the job there too
 
 
 def test_c_host_loop_replays_the_file_like_the_reference():

@@ -148,6 +148,64 @@ PY
     set -e
     cmp $D/loop_1proc.txt $D/loop_ranks2.txt && cmp $D/loop_1proc.txt $D/loop_ranks3.txt || { echo "   --loop --ranks differs from the one-process replay"; exit 1; }
     echo "   --loop --ranks 2 / 3: the first $n bytes (2.5 laps) equal the one-process host's"
+    # --resolve-on-ranks: every rank resolves its own batches from a guessed whitelist, the ranks confirm each other through shared memory,
+    # rank 0 prints their texts (no gather library is loaded at all: the stub is moved away for these runs) - the same listing for every N and
+    # batch size, from a file, a pipe and a replay; with every rank but the first started from a wrong state on purpose (MODES_RR_SPOIL: the
+    # logged answers do not hold, the rank resolves again); ranks without a batch; a mode it does not serve is refused
+    mv $D/libmodes_gather.so $D/libmodes_gather.so.away
+    for k in 1 2 3 8; do for bb in 1 2; do
+        got=$($D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw --ranks $k --batch-blocks $bb --resolve-on-ranks | md5sum | cut -c1-32)
+        echo "   --resolve-on-ranks --ranks $k --batch-blocks $bb: md5 $got"
+        [ "$got" = 4a81758c8bec5e45ffa8541c5622938a ] || { echo "   expected 4a81758c8bec5e45ffa8541c5622938a"; exit 1; }
+    done; done
+    for k in 2 3; do
+        got=$(MODES_RR_SPOIL=1 $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw --ranks $k --batch-blocks 1 --resolve-on-ranks --timing 2> $D/rr_spoil.err | md5sum | cut -c1-32)
+        echo "   --resolve-on-ranks --ranks $k, wrong starts: md5 $got, $(grep -o '"reruns": [0-9]*' $D/rr_spoil.err)"
+        [ "$got" = 4a81758c8bec5e45ffa8541c5622938a ] || { echo "   expected 4a81758c8bec5e45ffa8541c5622938a"; exit 1; }
+    done
+    # ... and a stream on which a wrong start SHOWS: an aircraft's DF17 in buffer 0, a DF4 and a DF5 whose parity only validates against
+    # that address at the head of buffers 1 and 2 (dump1090.c:942-983) - a rank started from an empty whitelist logs "unknown", the state the
+    # ranks before it really left says "known": it must resolve again, and the listing must still be the one-process host's
+    python - <<'PY'
+import sys
+sys.path[:0] = [".", "tests", "oracle"]
+import numpy as np, synth as sy
+iq = sy.noise_bytes(31, 0, 3 * 262144, sigma_q16=300)
+a17 = sy.make_frame(17, sy._payload(1, 14, 1))
+addr = int.from_bytes(a17[1:4], "big")
+sy.add_frame(iq, 1000, a17, 70, 3)
+sy.add_frame(iq, 131072 + 900, sy.make_frame(4, sy._payload(2, 7, 2), xor_parity=addr), 70, 9)
+sy.add_frame(iq, 131072 + 9000, a17, 70, 5)
+sy.add_frame(iq, 2 * 131072 + 700, sy.make_frame(5, sy._payload(2, 7, 3), xor_parity=addr), 70, 1)
+sy.add_frame(iq, 2 * 131072 + 5000, sy.make_frame(20, sy._payload(2, 14, 4), xor_parity=addr), 70, 1)
+sy.finish_stream(iq).tofile("/tmp/modes_ranks_host/ap.bin")
+PY
+    want=$($D/dump1090_amd_stub --ifile $D/ap.bin --raw | md5sum | cut -c1-32)
+    lines=$($D/dump1090_amd_stub --ifile $D/ap.bin --raw | wc -l)
+    # (524f28a5...: what the unmodified reference prints for this stream, oracle/_ref/dump1090_ref --ifile ap.bin --raw)
+    [ "$lines" = 5 ] && [ "$want" = 524f28a5613c2468123104e0a17e61f8 ] || { echo "   ap.bin: $lines lines, md5 $want from the one-process host; 5 lines, 524f28a5... expected"; exit 1; }
+    for k in 2 3; do for spoil in "" 1; do
+        got=$(env ${spoil:+MODES_RR_SPOIL=1} $D/dump1090_amd_stub --ifile $D/ap.bin --raw --ranks $k --batch-blocks 1 --resolve-on-ranks --timing 2> $D/rr_ap.err | md5sum | cut -c1-32)
+        re=$(grep -o '"reruns": [0-9]*' $D/rr_ap.err | cut -d' ' -f2)
+        echo "   --resolve-on-ranks --ranks $k on AP-validated frames${spoil:+, wrong starts}: md5 $got, $re re-run(s)"
+        [ "$got" = "$want" ] || { echo "   expected $want"; exit 1; }
+        if [ -n "$spoil" ]; then [ "$re" -ge $((k - 1)) ] || { echo "   a wrong start went unnoticed"; exit 1; }; else [ "$re" = 0 ] || { echo "   a right guess was rejected"; exit 1; }; fi
+    done; done
+    got=$($D/dump1090_amd_stub --ifile - --raw --ranks 3 --batch-blocks 1 --resolve-on-ranks < tests/golden/modes1.bin | md5sum | cut -c1-32)
+    echo "   --resolve-on-ranks --ifile - --ranks 3: md5 $got"
+    [ "$got" = 4a81758c8bec5e45ffa8541c5622938a ] || { echo "   expected 4a81758c8bec5e45ffa8541c5622938a"; exit 1; }
+    set +e
+    for r in 2 3; do
+        timeout 60 $D/dump1090_amd_stub --ifile $D/pad.bin --raw --loop --ranks $r --batch-blocks 1 --resolve-on-ranks 2> /dev/null | head -c $n > $D/loop_rr$r.txt
+    done
+    $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --stats --ranks 2 --resolve-on-ranks > /dev/null 2> $D/rr_refused.err
+    rc=$?
+    set -e
+    cmp $D/loop_1proc.txt $D/loop_rr2.txt && cmp $D/loop_1proc.txt $D/loop_rr3.txt || { echo "   --loop --resolve-on-ranks differs from the one-process replay"; exit 1; }
+    echo "   --resolve-on-ranks --loop --ranks 2 / 3: the first $n bytes (2.5 laps) equal the one-process host's"
+    echo "   --resolve-on-ranks --stats: exit status $rc"
+    [ "$rc" = 1 ] && grep -q "serves the --raw listing only" $D/rr_refused.err || { cat $D/rr_refused.err; exit 1; }
+    mv $D/libmodes_gather.so.away $D/libmodes_gather.so
     # a rank whose GPU does not come up while its peers already wait in the gather: the job ends with status 1, it does not hang
     # (rank 0's watchdog kills the other ranks; a rank never outlives rank 0)
     for bad in 0 1 2; do
@@ -173,6 +231,15 @@ PY
         rc=$?
         set -e
         echo "   rank ${bad%%:*} fails in GPU call ${bad##*:}: exit status $rc"
+        [ "$rc" = 1 ] || { cat $D/fail.err; exit 1; }
+    done
+    # the same under --resolve-on-ranks: the peers wait for that rank's tables in shared memory - they must see the failure and end
+    for bad in 0:1 1:0; do
+        set +e
+        MODES_STUB_FAIL_SUBMIT=$bad timeout 20 $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw --ranks 2 --batch-blocks 1 --resolve-on-ranks > /dev/null 2> $D/fail.err
+        rc=$?
+        set -e
+        echo "   resolving on the ranks, rank ${bad%%:*} fails in its GPU call ${bad##*:}: status $rc"
         [ "$rc" = 1 ] || { cat $D/fail.err; exit 1; }
     done
 }
