@@ -411,7 +411,7 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "ranks-host"], capture_output=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout[-800:], p.stderr[-800:])
     # the reference's listing: 9 files x (N, batch size), N = 8, 6 pipes (--ifile -, round 5) and 3 restarts
-    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 19 + 11 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
+    assert p.stdout.count(b"md5 4a81758c8bec5e45ffa8541c5622938a") == 19 + 12 and b"--onlyaddr --ranks 3: md5 bab0f055" in p.stdout
     # (three of them: the start-up probe of the communicator fails - on every rank, on a peer, on rank 0 - and rank 0 starts the
     # job over once with the other IPC mode; that second run prints the listing)
     assert p.stdout.count(b", 1 restart") == 3
@@ -431,7 +431,7 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     # --resolve-on-ranks (every rank resolves its own batches, the ranks confirm each other through shared memory, rank 0 prints the texts;
     # no gather library): N = 1, 2, 3, 8 x two batch sizes, a pipe, a replay; on a stream whose DF4 / DF5 / DF20 frames only validate against
     # an address an earlier rank remembered: right guesses are kept (0 re-runs), wrong starts are noticed and resolved again - same listing
-    assert p.stdout.count(b"--resolve-on-ranks --ranks") == 8 + 2 + 4 and b"--resolve-on-ranks --ifile - --ranks 3: md5 4a81758c" in p.stdout
+    assert p.stdout.count(b"--resolve-on-ranks --ranks") == 8 + 2 + 4 and b"orderly teardown (--clean-exit): md5 4a81758c" in p.stdout and b"--resolve-on-ranks --ifile - --ranks 3: md5 4a81758c" in p.stdout
     assert p.stdout.count(b"on AP-validated frames: md5 524f28a5613c2468123104e0a17e61f8, 0 re-run(s)") == 2
     assert b"--ranks 2 on AP-validated frames, wrong starts: md5 524f28a5613c2468123104e0a17e61f8, 1 re-run(s)" in p.stdout
     assert b"--ranks 3 on AP-validated frames, wrong starts: md5 524f28a5613c2468123104e0a17e61f8, 2 re-run(s)" in p.stdout

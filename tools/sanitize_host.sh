@@ -158,6 +158,9 @@ PY
         echo "   --resolve-on-ranks --ranks $k --batch-blocks $bb: md5 $got"
         [ "$got" = 4a81758c8bec5e45ffa8541c5622938a ] || { echo "   expected 4a81758c8bec5e45ffa8541c5622938a"; exit 1; }
     done; done
+    got=$($D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw --ranks 3 --batch-blocks 1 --resolve-on-ranks --clean-exit | md5sum | cut -c1-32)
+    echo "   --resolve-on-ranks, orderly teardown (--clean-exit): md5 $got"
+    [ "$got" = 4a81758c8bec5e45ffa8541c5622938a ] || { echo "   expected 4a81758c8bec5e45ffa8541c5622938a"; exit 1; }
     for k in 2 3; do
         got=$(MODES_RR_SPOIL=1 $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw --ranks $k --batch-blocks 1 --resolve-on-ranks --timing 2> $D/rr_spoil.err | md5sum | cut -c1-32)
         echo "   --resolve-on-ranks --ranks $k, wrong starts: md5 $got, $(grep -o '"reruns": [0-9]*' $D/rr_spoil.err)"
