@@ -481,7 +481,7 @@ int run_ranks(const Options &opt, double t_start) {
         // (profiles/r06/e2e_cli.json).  N readers at ~40 GB/s each win that time back only beyond kRanksPaysFromBytes (INTEGRATION.md 2b has
         // the arithmetic): say so once.
         constexpr double kRanksPaysFromBytes = 96e9;
-        if (rank == 0 && (double)size < kRanksPaysFromBytes && !getenv("MODES_RANKS_QUIET"))
+        if (rank == 0 && !rr && (double)size < kRanksPaysFromBytes && !getenv("MODES_RANKS_QUIET"))          // (--resolve-on-ranks makes no communicator)
             fprintf(stderr, "--ranks %d: %.1f GiB is below the ~%.0f GB from which one process per GPU is faster than --gpus %d (one process, the "
                             "same devices, no communicator to start)\n", N, size / 1073741824.0, kRanksPaysFromBytes / 1e9, N);
         map = size ? static_cast<const uint8_t *>(mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0)) : nullptr;
