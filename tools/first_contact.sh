@@ -31,6 +31,14 @@ except Exception as e:
 echo "first contact: N = $N, HSA_ENABLE_IPC_MODE_LEGACY=$HSA_ENABLE_IPC_MODE_LEGACY, $(rocm-smi --showcomputepartition 2>/dev/null | grep -m1 'GPU\[' | sed 's/.*: //') partition"
 NR=$((N < 2 ? N : 2))
 
+# (first of all the mode that needs nothing from RCCL: N processes, a device each, confirmation and texts through shared memory - if THIS fails
+#  the devices or the library are the matter, not the transport)
+run rr${N}_small 200 $EXE --ifile tests/golden/modes1.bin --raw --ranks $N --batch-blocks 1 --resolve-on-ranks --timing
+md5=$(md5sum < "$O/rr${N}_small.out" | cut -c1-32)
+record rr${N}_small $([ $RC = 0 ] && [ "$md5" = $REF_RAW ] && echo true || echo false) $SECS "status $RC, listing md5 $md5 (reference $REF_RAW)"
+means "$N PROCESSES, one device each, NO communicator (--resolve-on-ranks): every rank resolves its own batches, rank 0 prints the texts." \
+      "A failure here is a device that does not come up or a context that cannot be made on it - nothing RCCL could be blamed for."
+
 run ranks${NR}_small 400 $EXE --ifile tests/golden/modes1.bin --raw --ranks $NR --batch-blocks 1 --timing
 md5=$(md5sum < "$O/ranks${NR}_small.out" | cut -c1-32)
 record ranks${NR}_small $([ $RC = 0 ] && [ "$md5" = $REF_RAW ] && echo true || echo false) $SECS "status $RC, listing md5 $md5 (reference $REF_RAW)"
@@ -57,6 +65,12 @@ means "the same at N = $N with BASELINE's 8 GiB per GPU (configs[3]): $((N - 1))
       "against kernel_ms_per_step_max_rank says whether rank 0's host half bounds the step."
 fi
 
+run bench${N}_frames_rr 900 python bench.py --gpus $N --workload frames --steps 20 --resolve-on ranks $([ $N = 1 ] && echo --force-gather)
+ok=$(jget "$O/bench${N}_frames_rr.out" "d['listing_check'].get('equals_reference_md5') in (True, None) and d['n_gpus'] == $N and d['rank_resolve']['steps'] > 0")
+record bench${N}_frames_rr $([ $RC = 0 ] && [ "$ok" = True ] && echo true || echo false) $SECS "status $RC, $(jget "$O/bench${N}_frames_rr.out" "'%.0f Msamples/s, rank_resolve %s' % (d['value'], d['rank_resolve'])")"
+means "the same leg with every rank resolving its own records (DESIGN.md 5.4): three host all_gathers a step over gloo, the texts over RCCL." \
+      "Compare its Msamples/s and rank_resolve.work_ms_per_step with bench${N}_frames above: which mode is the default for N devices is decided here."
+
 run bench${N}_all 1500 python bench.py --gpus $N --steps 20 --warmup 5
 ok=$(jget "$O/bench${N}_all.out" "all(d[k]['listing_check'].get('equals_reference_md5') in (True, None) for k in ('frames', 'lowsnr', 'frames_strong')) and d['n_gpus'] == $N")
 record bench${N}_all $([ $RC = 0 ] && [ "$ok" = True ] && echo true || echo false) $SECS "status $RC, $(jget "$O/bench${N}_all.out" "'value %.0f Msamples/s over %d GPU(s); frames %.0f, low SNR %.0f, 64 GiB strong %.0f' % (d['value'], d['n_gpus'], d['frames']['Msamples_per_s'], d['lowsnr']['Msamples_per_s'], d['frames_strong']['Msamples_per_s'])")"
@@ -80,6 +94,10 @@ PY
   many=$(md5sum < "$O/ranks${N}_file.out" | cut -c1-32)
   record ranks${N}_file $([ $RC = 0 ] && [ "$one" = "$many" ] && echo true || echo false) $SECS "status $RC, 4 GiB of frames: one process md5 $one, --ranks $N md5 $many"
   means "the C host's one-process-per-GPU mode at full width: batches dealt round-robin, $N lists per round."
+  run rr${N}_file 600 $EXE --ifile /dev/shm/modes_fc.bin --raw --ranks $N --resolve-on-ranks --timing
+  many=$(md5sum < "$O/rr${N}_file.out" | cut -c1-32)
+  record rr${N}_file $([ $RC = 0 ] && [ "$one" = "$many" ] && echo true || echo false) $SECS "status $RC, the same file with --resolve-on-ranks: md5 $many; $(grep -o '"init_s": [0-9.]*, "stream_s": [0-9.]*' "$O/rr${N}_file.err" | tail -1) (gather: $(grep -o '"init_s": [0-9.]*, "stream_s": [0-9.]*' "$O/ranks${N}_file.err" | tail -1))"
+  means "the C host without the gather: compare init_s / stream_s with ranks${N}_file (the communicator's start is the difference in init_s)."
   run ranks${N}_file_stats 600 $EXE --ifile /dev/shm/modes_fc.bin --stats --ranks $N
   st=$(md5sum < "$O/ranks${N}_file_stats.out" | cut -c1-32)
   record ranks${N}_file_stats $([ $RC = 0 ] && [ "$st" = "$st1" ] && echo true || echo false) $SECS "status $RC, --stats: one process $st1, --ranks $N $st"
