@@ -137,9 +137,11 @@ def test_bench_eight_ranks_at_full_size_reproduce_the_reference_listings(resolve
         if resolve_on == "ranks":
             rr = j[leg]["rank_resolve"]
             assert rr["steps"] > 0 and rr["rounds_per_step"] >= 1.0, (leg, rr)
-            # rank 0 resolves an eighth of the records (measured 0.8-1.1 ms on the 64 GiB stream against 1.35-1.66 for all of them on 32
-            # threads: profiles/r08/rank_resolve_8ranks.txt); the bound only says "not everything"
-            assert j[leg]["rank0_resolve_ms_per_step"] <= 1.5, (leg, j[leg]["rank0_resolve_ms_per_step"])
+            # rank 0 resolves an eighth of the records (measured 0.8-1.1 ms per step on the 64 GiB stream against 1.35-1.66 for all of them
+            # on 32 threads: profiles/r08/rank_resolve_8ranks.txt - a box-dependent number, so only a sanity bound here) and receives text,
+            # not records: less than 64 bytes per line
+            assert 0 < j[leg]["rank0_resolve_ms_per_step"] <= 10.0, (leg, j[leg]["rank0_resolve_ms_per_step"])
+            assert 0 < rr["text_bytes_per_step"] < 40 * lines, (leg, rr)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_eight_ranks_%s.json" % resolve_on), "w") as f:
         json.dump(j, f)
