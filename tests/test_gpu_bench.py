@@ -44,7 +44,8 @@ def check(j, n_gpus):
 
 @pytest.mark.parametrize("extra", [[], ["--streams", "1"], ["--force-gather"], ["--force-gather", "--overlap", "2"]])
 def test_bench_small_single_rank(extra):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, capture_output=True, timeout=600)
+    # (the first RCCL communicator of a fresh box has taken 60 - 435 s by itself: profiles/r08/e2e_ranks.txt)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, capture_output=True, timeout=1500 if extra[:1] == ["--force-gather"] else 600)
     assert p.returncode == 0, p.stderr[-1500:]
     check(parse(p.stdout), 1)
 
