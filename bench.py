@@ -339,10 +339,10 @@ def visible_gpus():
     return torch.cuda.device_count()
 
 
-def ipc_probe(dist, torch, dev, rank, world, seconds=120.0):
+def ipc_probe(dist, torch, dev, rank, world, seconds=300.0):
     """The first transfer between two ranks' devices is where a wrong IPC mode or a missing peer-to-peer path shows - as a hang.
     A 64-byte ring (rank r -> r + 1) right behind init_process_group, watched: when it does not complete in `seconds` (generous:
-    on a fresh box RCCL's first communicator alone has taken 60-100 s while the image pages in, and the first send / recv between
+    on a fresh box RCCL's first communicator alone has taken 60-435 s while the image pages in, and the first send / recv between
     two ranks sets up its channels on top of that - a slow start must not be taken for a hang) the rank
     says which HSA_ENABLE_IPC_MODE_LEGACY it ran with, leaves $MODES_PROBE_MARK for a self-launched parent (which then starts the
     job over with the other value) and ends the process - a wrong guess costs seconds, not the lease."""

@@ -126,7 +126,8 @@ int modes_gather_create(const modes_gather_config *cfg, const void *id, modes_ga
     }
     {   // the probe: a 64-byte ring over the new communicator, watched - a transfer that never completes is the failure mode of
         // a wrong IPC mode / a missing P2P path, and nothing else would ever report it
-        double limit = 120.0;                                               // generous: a cold box has taken 60-100 s for the communicator alone
+        double limit = 300.0;                                               // generous: cold boxes have taken 60 - 435 s for ncclCommInitRank alone (profiles/r08/e2e_ranks.txt);
+                                                                            // a slow start must not be taken for a hang - the other IPC mode does not work on this pool
         if (const char *v = getenv("MODES_GATHER_PROBE_SECONDS")) limit = atof(v);
         if (limit > 0.0) {
             CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_probe), 128));     // (owned by g: every way out through bail() frees it)

@@ -69,8 +69,8 @@ typedef struct {
 int  modes_gather_unique_id(void *id);
 /* Collective: returns when all nranks ranks have joined AND a 64-byte ncclSend / ncclRecv ring (rank r -> r + 1) has completed on
  * the new communicator: the first transfer between two devices of two processes is where a wrong IPC mode or a missing
- * peer-to-peer path shows, and it shows as a hang.  The probe has 120 s ($MODES_GATHER_PROBE_SECONDS; 0 = no probe; generous
- * because on a fresh box RCCL's own start has taken 60-100 s while the image pages in); when it
+ * peer-to-peer path shows, and it shows as a hang.  The probe has 300 s ($MODES_GATHER_PROBE_SECONDS; 0 = no probe; generous
+ * because on a fresh box RCCL's own start has taken 60-435 s while the image pages in); when it
  * runs out the call returns MODES_GATHER_ERR_PROBE and the text names the value of HSA_ENABLE_IPC_MODE_LEGACY the process
  * ran with - the host's cue to start the job once more with the other one (dump1090_amd --ranks does).
  * AFTER MODES_GATHER_ERR_PROBE THE PROCESS MUST EXIT: a communicator with a transfer stuck in it cannot be torn down, so the

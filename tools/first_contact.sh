@@ -39,19 +39,19 @@ record rr${N}_small $([ $RC = 0 ] && [ "$md5" = $REF_RAW ] && echo true || echo 
 means "$N PROCESSES, one device each, NO communicator (--resolve-on-ranks): every rank resolves its own batches, rank 0 prints the texts." \
       "A failure here is a device that does not come up or a context that cannot be made on it - nothing RCCL could be blamed for."
 
-run ranks${NR}_small 400 $EXE --ifile tests/golden/modes1.bin --raw --ranks $NR --batch-blocks 1 --timing
+run ranks${NR}_small 1200 $EXE --ifile tests/golden/modes1.bin --raw --ranks $NR --batch-blocks 1 --timing
 md5=$(md5sum < "$O/ranks${NR}_small.out" | cut -c1-32)
 record ranks${NR}_small $([ $RC = 0 ] && [ "$md5" = $REF_RAW ] && echo true || echo false) $SECS "status $RC, listing md5 $md5 (reference $REF_RAW)"
 means "$NR PROCESS(ES), one device each, 3 batches: the unique id pipe, ncclCommInitRank across processes, the first ncclSend/ncclRecv between two GPUs." \
       "'hipIpcGetMemHandle: invalid argument' = the IPC mode (the host restarts itself once with the other one: look for 'starting over' in the .err);" \
-      "'probe' after 120 s = the communicator came up but the first transfer did not complete (xGMI / P2P access between the two devices)."
+      "'probe' after 300 s = the communicator came up but the first transfer did not complete (xGMI / P2P access between the two devices)."
 
 run ranks${NR}_stats 400 $EXE --ifile tests/golden/modes1.bin --stats --ranks $NR --batch-blocks 1
 md5=$(md5sum < "$O/ranks${NR}_stats.out" | cut -c1-32)
 record ranks${NR}_stats $([ $RC = 0 ] && [ "$md5" = $REF_STATS ] && echo true || echo false) $SECS "status $RC, --stats md5 $md5 (reference $REF_STATS)"
 means "the gather's second list (every rank's preamble positions) - the same transfers as above with a second buffer."
 
-run bench${NR}_frames 600 python bench.py --gpus $NR --workload frames --frames-mib 1024 --steps 10 $([ $NR = 1 ] && echo --force-gather)
+run bench${NR}_frames 1200 python bench.py --gpus $NR --workload frames --frames-mib 1024 --steps 10 $([ $NR = 1 ] && echo --force-gather)
 ok=$(jget "$O/bench${NR}_frames.out" "d['listing_check'].get('equals_reference_md5') in (True, None) and d['n_gpus'] == $NR and d['rccl']['p2p_ops_per_step'] > 0")
 record bench${NR}_frames $([ $RC = 0 ] && [ "$ok" = True ] && echo true || echo false) $SECS "status $RC, $(jget "$O/bench${NR}_frames.out" "'%.0f Msamples/s, %d msgs per step, rccl_start %s' % (d['value'], d['listing_check']['lines'], d.get('rccl_start'))")"
 means "torch.distributed over RCCL: init_process_group, the count all_gather, exact-size isend/irecv of device lists; the listing is checked" \
