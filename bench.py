@@ -332,6 +332,33 @@ def launcher_command(argv, gpus, port=None):
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def host_cpus():
+    """What the host side of this run can use: logical CPUs, the affinity mask, and the container's CPU-time quota in CPUs
+    (cgroup v2 cpu.max / v1 cfs quota; None = no limit).  The resolver's worker threads share the quota with the launch threads:
+    on round 5's boxes 256 logical CPUs sit behind a quota of 16 (profiles/r08/rank_resolve_8ranks.txt)."""
+    out = {"logical": os.cpu_count(), "affinity": None, "quota": None}
+    try:
+        out["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        if q != "max":
+            out["quota"] = round(int(q) / int(p), 2)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0:
+                out["quota"] = round(q / p, 2)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
 def visible_gpus():
     """GPUs this process can use: hipGetDeviceCount through torch (it honours the *_VISIBLE_DEVICES lists and what the container
     may open).  Called by the parent of a self-launched N-rank run only - the ranks are separate processes."""
@@ -795,6 +822,7 @@ def main():
                                head["depth"], args.overlap, 4 if (noise is not None and args.streams > 1) else args.time_every,
                                max(1, args.streams))},
         "msgs_per_s": round(head.get("msgs", 0) / head["elapsed"], 2) if rank == 0 else None,
+        "host_cpus": host_cpus(),                                  # what the host half (launch threads, resolver, its workers) had
         "host_ms_per_call": head.get("host_ms_per_call"),          # rank 0's host thread, by phase of the step loop
         "detect_us_per_call": head.get("detect_us_per_call"),      # inside modes_gpu_detect, by section (modes_gpu_host_profile)
         "region_tail_ms": head.get("region_tail_ms"),              # the end of the timed region: calls in flight, resolver, final sync

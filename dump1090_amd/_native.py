@@ -12,7 +12,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 GPU_LIB = os.environ.get("MODES_GPU_LIB") or os.path.join(PKG_DIR, "libmodes_gfx950.so")      # (MODES_GPU_LIB: another build of the library - tools/ab_scan.py, experiments)
-HOST_LIB = os.path.join(PKG_DIR, "libmodes_host.so")
+HOST_LIB = os.environ.get("MODES_HOST_LIB") or os.path.join(PKG_DIR, "libmodes_host.so")       # (MODES_HOST_LIB: another build, for A/B timings)
 GATHER_LIB = os.path.join(PKG_DIR, "libmodes_gather.so")      # the C hosts' record gather over RCCL (include/modes_gather.h)
 
 DATA_LEN = 262144
