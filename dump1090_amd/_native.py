@@ -45,7 +45,8 @@ GPU_ORDER_IN_STREAM = 2
 
 class Attempt(C.Structure):
     _fields_ = [("msg", C.c_uint8 * 14), ("errors", C.c_uint8), ("gate_ok", C.c_uint8), ("nfix", C.c_uint8),
-                ("fixpos", C.c_uint8 * 2), ("pad", C.c_uint8 * 5), ("syndrome", C.c_uint32)]
+                ("fixpos", C.c_uint8 * 2), ("cls", C.c_uint8), ("slot", C.c_uint16), ("pad", C.c_uint8 * 2),
+                ("syndrome", C.c_uint32)]
 
 
 class Record(C.Structure):
@@ -53,7 +54,8 @@ class Record(C.Structure):
 
 
 ATTEMPT_DTYPE = np.dtype([("msg", np.uint8, 14), ("errors", np.uint8), ("gate_ok", np.uint8), ("nfix", np.uint8),
-                          ("fixpos", np.uint8, 2), ("pad", np.uint8, 5), ("syndrome", np.uint32)])
+                          ("fixpos", np.uint8, 2), ("cls", np.uint8), ("slot", np.uint16), ("pad", np.uint8, 2),
+                          ("syndrome", np.uint32)])
 RECORD_DTYPE = np.dtype([("block", np.uint32), ("j", np.uint32), ("att", ATTEMPT_DTYPE, 2)])
 assert C.sizeof(Record) == 64 and RECORD_DTYPE.itemsize == 64
 
@@ -130,7 +132,7 @@ HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_set_time"
                 "modes_format_onlyaddr", "modes_format_verbose", "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
                 "modes_block_count",
                 "modes_host_get_whitelist", "modes_host_set_whitelist", "modes_host_whitelist_guess", "modes_host_resolve_raw_spec",
-                "modes_host_whitelist_check",
+                "modes_host_whitelist_check", "modes_host_cpu_budget", "modes_host_classify",
                 "modes_tracker_create", "modes_tracker_destroy", "modes_tracker_receive", "modes_tracker_expire",
                 "modes_tracker_count", "modes_tracker_get", "modes_tracker_reference", "modes_tracker_json", "modes_format_sbs")
 
@@ -226,6 +228,17 @@ def gpu_lib():
     return _gpu
 
 
+def classify_records(records: np.ndarray, maxfix: int = 1, fix=None, aggressive=None) -> np.ndarray:
+    """A copy of `records` with the class byte and whitelist slot of every attempt filled in (modes_host_classify): what the
+    kernels write for a context of that configuration - for records of another producer (the oracle in the CPU tests)."""
+    fix = (maxfix > 0) if fix is None else fix
+    aggressive = (maxfix > 1) if aggressive is None else aggressive
+    out = np.ascontiguousarray(records, dtype=RECORD_DTYPE).copy()
+    cfg = HostConfig(int(fix), int(aggressive), 1, 0)
+    host_lib().modes_host_classify(C.byref(cfg), out.ctypes.data, out.size)
+    return out
+
+
 def host_lib():
     global _host
     if _host is None:
@@ -264,6 +277,10 @@ def host_lib():
         L.modes_host_resolve_raw_spec.restype = C.c_uint64
         L.modes_host_whitelist_check.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.modes_host_whitelist_check.restype = C.c_int
+        L.modes_host_cpu_budget.argtypes = []
+        L.modes_host_cpu_budget.restype = C.c_int
+        L.modes_host_classify.argtypes = [C.POINTER(HostConfig), C.c_void_p, C.c_uint64]
+        L.modes_host_classify.restype = None
         L.modes_host_wants.argtypes = [C.c_void_p, C.POINTER(ModesMessage)]
         L.modes_host_get_stats.argtypes = [C.c_void_p, C.POINTER(HostStats)]
         L.modes_host_get_stats.restype = None

@@ -78,6 +78,51 @@ MODES_HD int modes_find_fix(uint32_t syndrome, int bits, int maxfix, const uint3
     return 0;
 }
 
+/* --------------------------------------------- what the decoder makes of an attempt */
+
+/* The MODES_CLS_* bytes and their meaning are part of the ABI: include/modes_gfx950.h. */
+#include "../../include/modes_gfx950.h"
+
+/* ICAOCacheHashAddress, dump1090.c:898-905 (MODES_ICAO_CACHE_LEN = 1024, dump1090.c:65). */
+MODES_HD uint32_t modes_icao_slot(uint32_t a) {
+    a = ((a >> 16) ^ a) * 0x45d9f3bu;
+    a = ((a >> 16) ^ a) * 0x45d9f3bu;
+    a = ((a >> 16) ^ a);
+    return a & 1023u;
+}
+
+/* Which way an attempt goes through detectModeS()/decodeModesMessage(), as far as the whitelist does not decide it:
+ * df = msg[0] >> 3 AS DEMODULATED (dump1090.c:1099: the type is read before any repair and never again), errors / gate_ok /
+ * syndrome / nfix as in modes_attempt (nfix found with maxfix = fix ? (aggressive ? 2 : 1) : 0).
+ *   :1723-1726  gate failed -> GATE;   :1731  errors > 0 (>= 3 with --aggressive) -> SKIP (not decoded)
+ *   :1183       DF other than 11/17/18 -> crcok only through bruteForceAP (:942-983; the types of :948-950) -> AP, else BAD
+ *   :1105       syndrome 0 -> CLEAN;   :1112-1128  repaired -> FIXED (the repaired frame's checksum is 0 by construction)
+ *   :1204       DF11, syndrome < 80 -> IID;  otherwise BAD.
+ * The one definition: the kernels (store_attempt) and the host's fallback for records without the byte both compile it. */
+MODES_HD uint32_t modes_classify(int df, uint32_t errors, uint32_t gate_ok, uint32_t syndrome, uint32_t nfix, uint32_t fix,
+                                 uint32_t aggressive) {
+    uint32_t c = MODES_CLS_VALID | (fix ? MODES_CLS_FIX : 0u) | (aggressive ? MODES_CLS_AGGRESSIVE : 0u) |
+                 (modes_len_by_df(df) == 112 ? MODES_CLS_LONG : 0u) | (errors == 0 ? MODES_CLS_NOERR : 0u);
+    uint32_t kind;
+    if (!gate_ok) kind = MODES_CLS_GATE;
+    else if (!(errors == 0 || (aggressive && errors < 3))) kind = MODES_CLS_SKIP;
+    else if (df != 11 && df != 17 && df != 18)
+        kind = (df == 0 || df == 4 || df == 5 || df == 16 || df == 20 || df == 21 || df == 24) ? MODES_CLS_AP : MODES_CLS_BAD;
+    else if (syndrome == 0) kind = MODES_CLS_CLEAN;
+    else if (fix && nfix > 0 && nfix <= (aggressive ? 2u : 1u)) kind = MODES_CLS_FIXED;
+    else if (df == 11 && syndrome < 80) kind = MODES_CLS_IID;
+    else kind = MODES_CLS_BAD;
+    return c | kind;
+}
+/* The whitelist slot that class touches: CLEAN / IID the address field msg[1..3], AP the address bruteForceAP recovers -
+ * AP field XOR parity of the data bits (dump1090.c:960-975) = the syndrome itself.  0 for the classes that touch none. */
+MODES_HD uint32_t modes_class_slot(uint32_t cls, uint32_t msg1, uint32_t msg2, uint32_t msg3, uint32_t syndrome) {
+    const uint32_t kind = cls & MODES_CLS_KIND;
+    if (kind == MODES_CLS_AP) return modes_icao_slot(syndrome);
+    if (kind == MODES_CLS_CLEAN || kind == MODES_CLS_IID) return modes_icao_slot((msg1 << 16) | (msg2 << 8) | msg3);
+    return 0u;
+}
+
 /* ------------------------------------------------------ magnitude / power */
 
 /* s = (I-127)^2 + (Q-127)^2, 0..32768.  The reference's magnitude

@@ -301,6 +301,7 @@ struct DemodParams {
     const uint32_t *counts;
     DeviceTables tab;
     int maxfix;                // 0 = --no-fix, 1 = default, 2 = --aggressive   (dump1090.c:1115)
+    int aggressive;            // Modes.aggressive by itself (dump1090.c:1731: it also admits attempts with 1-2 slicing errors)
     uint32_t *cand_slots;      // [nruns][slot_cap] or nullptr
     uint32_t *cand_counts;     // [nbatches]
     modes_record *staging;     // records in completion order
@@ -767,7 +768,10 @@ __device__ __forceinline__ AttemptFix wave_finish_attempt(modes_m128 bits, bool 
     return r;
 }
 
-__device__ __forceinline__ void store_attempt(modes_attempt *out, modes_m128 bits, uint8_t errors, bool gate_ok, AttemptFix f) {
+// `maxfix` / `aggressive`: the context's repair policy - the class byte (include/modes_gfx950.h MODES_CLS_*, modes_classify) is the
+// part of decodeModesMessage's decisions that the wavefront holding the DF, the syndrome and the repair can make for the host.
+__device__ __forceinline__ void store_attempt(modes_attempt *out, modes_m128 bits, uint8_t errors, bool gate_ok, AttemptFix f,
+                                              int maxfix, int aggressive) {
     uint8_t msg[14];
     modes_bits_to_msg(bits, msg);
 #pragma unroll
@@ -777,8 +781,11 @@ __device__ __forceinline__ void store_attempt(modes_attempt *out, modes_m128 bit
     out->nfix = f.nfix;
     out->fixpos[0] = f.pos0;
     out->fixpos[1] = f.pos1;
-#pragma unroll
-    for (int b = 0; b < 5; b++) out->pad[b] = 0;
+    const uint32_t cls = modes_classify(df_of_bits(bits), errors, gate_ok ? 1u : 0u, f.syndrome, f.nfix, maxfix > 0 ? 1u : 0u,
+                                        aggressive ? 1u : 0u);
+    out->cls = (uint8_t)cls;
+    out->slot = (uint16_t)modes_class_slot(cls, msg[1], msg[2], msg[3], f.syndrome);
+    out->pad[0] = out->pad[1] = 0;
     out->syndrome = f.syndrome;
 }
 
@@ -1008,8 +1015,8 @@ __device__ __forceinline__ bool demod_rest(const DemodParams &P, const Lut lut, 
         modes_record *rec = lane == 0 ? &P.staging[slot] : host_rec;
         rec->block = (uint32_t)(g / MODES_BLOCK_STRIDE);
         rec->j = j;
-        store_attempt(&rec->att[0], bits0, err0, true, f0);
-        store_attempt(&rec->att[1], bits1, err1, gate1, f1);
+        store_attempt(&rec->att[0], bits0, err0, true, f0, P.maxfix, P.aggressive);
+        store_attempt(&rec->att[1], bits1, err1, gate1, f1, P.maxfix, P.aggressive);
         if (KEYED && lane == 0) P.keys[slot] = key;
     }
     return true;
@@ -2469,7 +2476,16 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     size_t want = (size_t)nbatches * kDemodGroup * cap * sizeof(uint32_t);
     if ((rc = grow(ctx, &ctx->d_slots, &ctx->slots_bytes, want)) != MODES_OK) return rc;
     const bool split = ctx->cfg.demod_variant == 2 || (ctx->cfg.demod_variant == 0 && ctx->records_per_gib > kSplitAbove);
-    if (split && (rc = grow(ctx, &ctx->d_surv, &ctx->surv_bytes, want)) != MODES_OK) return rc;
+    if (split) {
+        // record_kernel requests a batch's first sixteen survivor slots TOGETHER with its count (one round trip instead of two) - slots
+        // select_kernel has not written when the batch has fewer survivors; the values are never used, but they are read: the list is
+        // zeroed once when it is (re)allocated, and a batch always has sixteen slots
+        static_assert(kDemodGroup >= 16, "record_kernel reads slots wave and wave + 8 of a batch before it knows the batch's count");
+        uint32_t *const before = ctx->d_surv;
+        const size_t had = ctx->surv_bytes;
+        if ((rc = grow(ctx, &ctx->d_surv, &ctx->surv_bytes, want)) != MODES_OK) return rc;
+        if (ctx->d_surv != before || ctx->surv_bytes != had) HIP_TRY(ctx, hipMemsetAsync(ctx->d_surv, 0, ctx->surv_bytes, st));
+    }
     if (ctx->cfg.keep_candidates && (rc = grow(ctx, &ctx->d_cand_slots, &ctx->cand_slots_bytes, want)) != MODES_OK) return rc;
     if (ctx->counts_elems < nruns) {
         if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -2510,6 +2526,7 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
     dp.counts = d_counts;
     dp.tab = DeviceTables{ctx->d_lut, ctx->d_esyn};
     dp.maxfix = ctx->maxfix;
+    dp.aggressive = ctx->cfg.aggressive ? 1 : 0;
     dp.cand_slots = ctx->cfg.keep_candidates ? ctx->d_cand_slots : nullptr;
     dp.cand_counts = d_cand_counts;
     dp.staging = ctx->d_staging;

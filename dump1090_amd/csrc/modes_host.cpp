@@ -7,6 +7,7 @@
 
 #include "../../include/modes_host.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -19,7 +20,14 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <memory>
 #include <vector>
+
+#include <sched.h>
+#include <unistd.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include "modes_core.h"
 
@@ -407,7 +415,160 @@ uint64_t modes_host_resolve_to_array(modes_host *h, const modes_record *recs, ui
     return s.n;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The --raw listing of a batch (what `dump1090 --raw` prints for these buffers, dump1090.c:1324-1326 behind the filter of
+// :1803) without a modesMessage: the LEAN resolve.  Everything decodeModesMessage() decides about an attempt that the
+// whitelist does not decide is in the attempt's class byte (include/modes_gfx950.h MODES_CLS_*; written by the GPU wavefront
+// that demodulated it, or - records of another producer, or of a context configured differently - by the same
+// modes_classify() here).  What is left per record: skip window (:1770), the class, at most one whitelist access through
+// the precomputed slot (:1198, :1204, :942-983), the counters of :1738-1753, and the line - two 16-byte stores of hex digits.
+// modes_host_resolve() with a raw sink is the definition it is tested against (tests/test_host.py, every stream x flag set).
+// ---------------------------------------------------------------------------------------------
 namespace {
+inline bool wl_known(modes_host *h, uint32_t addr, uint32_t slot) {                                // :919-925
+    const bool known = addr != 0 && h->icao[slot] == addr && h->now_s - h->icao_seen[slot] <= kIcaoTtl;
+    if (h->log && addr != 0 && !h->log->written[slot]) h->log->lookups.push_back({addr, known});
+    return known;
+}
+inline void wl_remember(modes_host *h, uint32_t addr, uint32_t slot) {                            // :910-914
+    h->icao[slot] = addr;
+    h->icao_seen[slot] = h->now_s;
+    if (h->log) h->log->written[slot] = true;
+}
+
+// 16 bytes -> 32 lower-case hex digits (the caller uses the first 14 or 28)
+inline void hex32(const unsigned char *src, char *dst) {
+#if defined(__SSE2__)
+    const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src));
+    const __m128i nib = _mm_set1_epi8(0x0f), nine = _mm_set1_epi8(9), zero = _mm_set1_epi8('0'), alpha = _mm_set1_epi8('a' - '0' - 10);
+    const __m128i hi = _mm_and_si128(_mm_srli_epi16(v, 4), nib), lo = _mm_and_si128(v, nib);
+    __m128i a = _mm_unpacklo_epi8(hi, lo), b = _mm_unpackhi_epi8(hi, lo);
+    a = _mm_add_epi8(_mm_add_epi8(a, zero), _mm_and_si128(_mm_cmpgt_epi8(a, nine), alpha));
+    b = _mm_add_epi8(_mm_add_epi8(b, zero), _mm_and_si128(_mm_cmpgt_epi8(b, nine), alpha));
+    _mm_storeu_si128(reinterpret_cast<__m128i *>(dst), a);
+    _mm_storeu_si128(reinterpret_cast<__m128i *>(dst + 16), b);
+#else
+    static const char digits[] = "0123456789abcdef";
+    for (int i = 0; i < 16; i++) { dst[2 * i] = digits[src[i] >> 4]; dst[2 * i + 1] = digits[src[i] & 15]; }
+#endif
+}
+
+// where the listing goes: out[0 .. cap), whole lines as long as they fit and nothing behind the first that does not
+struct LeanOut {
+    char *out;
+    uint64_t cap;
+    uint64_t n = 0;         // length of the whole listing
+    uint64_t stored = 0;    // bytes of it in out
+    uint64_t msgs = 0;
+    bool full = false;
+    LeanOut(char *o, uint64_t c) : out(o), cap(o ? c : 0) {}
+    // msg: 16 readable bytes (a modes_attempt's msg is followed by two more fields of the same struct)
+    inline void line(const unsigned char *msg, bool is_long) {
+        const uint64_t len = is_long ? 31 : 17;
+        if (!full) {
+            if (n + 40 <= cap) {                                                  // room for the two 16-byte stores and the NUL
+                char *p = out + n;
+                p[0] = '*';
+                hex32(msg, p + 1);
+                p[len - 2] = ';';
+                p[len - 1] = '\n';
+                stored = n + len;
+            } else if (n + len + 1 <= cap) {
+                char tmp[40];
+                tmp[0] = '*';
+                hex32(msg, tmp + 1);
+                tmp[len - 2] = ';';
+                tmp[len - 1] = '\n';
+                memcpy(out + n, tmp, (size_t)len);
+                stored = n + len;
+            } else {
+                full = true;
+            }
+        }
+        n += len;
+        msgs++;
+    }
+    void finish() { if (out && stored < cap) out[stored] = 0; }
+};
+
+void lean_resolve(modes_host *h, const modes_record *recs, uint64_t nrecs, LeanOut &o) {
+    const uint32_t fix = h->cfg.fix_errors ? 1u : 0u, aggressive = h->cfg.aggressive ? 1u : 0u;
+    const uint32_t cfg_mask = MODES_CLS_VALID | MODES_CLS_FIX | MODES_CLS_AGGRESSIVE;
+    const uint32_t cfg_want = MODES_CLS_VALID | (fix ? MODES_CLS_FIX : 0u) | (aggressive ? MODES_CLS_AGGRESSIVE : 0u);
+    const bool print_all = h->cfg.check_crc == 0;                                 // :1803
+    modes_host_stats st{};                                                        // this call's counts (added to h->st at the end)
+    uint32_t cur_block = 0xffffffffu, skip_to = 0;
+    for (uint64_t i = 0; i < nrecs; i++) {
+        const modes_record &r = recs[i];
+        if (r.block != cur_block) { cur_block = r.block; skip_to = 0; }
+        if (r.j < skip_to) continue;                                              // inside a decoded frame, :1770
+        st.valid_preamble++;                                                      // :1651
+        for (int pass = 0; pass < 2; pass++) {
+            const modes_attempt &a = r.att[pass];
+            if (pass == 1 && r.j != 0) st.out_of_phase++;                         // :1660-1663
+            uint32_t cls = a.cls, slot = a.slot;
+            if ((cls & cfg_mask) != cfg_want) {                                   // not classified for this configuration: here, the same way
+                cls = modes_classify(a.msg[0] >> 3, a.errors, a.gate_ok, a.syndrome, a.nfix, fix, aggressive);
+                slot = modes_class_slot(cls, a.msg[1], a.msg[2], a.msg[3], a.syndrome);
+            }
+            const uint32_t kind = cls & MODES_CLS_KIND;
+            if (kind == MODES_CLS_GATE) break;                                    // :1723-1726 (no retry)
+            if (kind == MODES_CLS_SKIP) continue;                                 // :1731
+            bool crcok = false, repaired = false;
+            switch (kind) {
+            case MODES_CLS_CLEAN:
+                crcok = true;
+                wl_remember(h, ((uint32_t)a.msg[1] << 16) | ((uint32_t)a.msg[2] << 8) | a.msg[3], slot);   // :1198
+                break;
+            case MODES_CLS_FIXED:
+                crcok = repaired = true;
+                if (a.nfix == 1) st.single_bit_fix++; else st.two_bits_fix++;     // :1122-1126
+                break;
+            case MODES_CLS_IID:                                                   // :1204
+                crcok = wl_known(h, ((uint32_t)a.msg[1] << 16) | ((uint32_t)a.msg[2] << 8) | a.msg[3], slot);
+                break;
+            case MODES_CLS_AP:                                                    // :942-983: the recovered address is the syndrome
+                crcok = wl_known(h, a.syndrome, slot);
+                break;
+            default: break;                                                       // BAD
+            }
+            if (crcok || pass == 1) {                                             // :1738-1753
+                if (cls & MODES_CLS_NOERR) st.demodulated++;
+                if (!repaired) {
+                    if (crcok) st.goodcrc++; else st.badcrc++;
+                } else {
+                    st.badcrc++;
+                    st.fixed++;
+                    st.single_bit_fix++;                                          // (errorbit < 112 always: the quirk of :1749)
+                }
+            }
+            const bool is_long = (cls & MODES_CLS_LONG) != 0;
+            if (print_all || crcok) {                                             // :1777 behind :1803
+                if (!repaired) {
+                    o.line(a.msg, is_long);
+                } else {
+                    unsigned char m[16];
+                    memcpy(m, a.msg, 16);
+                    for (int k = 0; k < a.nfix; k++) m[a.fixpos[k] >> 3] ^= (unsigned char)(0x80u >> (a.fixpos[k] & 7));
+                    o.line(m, is_long);
+                }
+            }
+            if (crcok) {                                                          // :1769-1774, :1786-1791
+                skip_to = r.j + (8 + (is_long ? 112u : 56u)) * 2 + 1;
+                break;
+            }
+        }
+    }
+    h->st.valid_preamble += st.valid_preamble;
+    h->st.out_of_phase += st.out_of_phase;
+    h->st.demodulated += st.demodulated;
+    h->st.goodcrc += st.goodcrc;
+    h->st.badcrc += st.badcrc;
+    h->st.fixed += st.fixed;
+    h->st.single_bit_fix += st.single_bit_fix;
+    h->st.two_bits_fix += st.two_bits_fix;
+}
+
 struct RawSink {
     modes_host *h;
     char *out;
@@ -423,12 +584,18 @@ void raw_sink(const struct modesMessage *mm, uint32_t, uint32_t, void *user) {
 }
 }  // namespace
 
-// The --raw listing of a batch straight into a text buffer (what `dump1090 --raw` prints for these buffers,
-// dump1090.c:1324-1326 behind the filter of :1803): the sink of the CLI's --raw mode without a callback per line.
+// With candidates (--stats: every preamble position counts) the general resolve with a raw sink; without, the lean one.
 uint64_t modes_host_resolve_raw(modes_host *h, const modes_record *recs, uint64_t nrecs, const uint64_t *cands, uint64_t ncand,
                                 char *out, uint64_t cap, uint64_t *nbytes) {
-    RawSink s{h, out, cap, 0, 0};
     if (out && cap) out[0] = 0;                                                   // an empty (or wholly cut) listing is ""
+    if (!cands && !getenv("MODES_HOST_NO_LEAN")) {
+        LeanOut o(out, cap);
+        lean_resolve(h, recs, nrecs, o);
+        o.finish();
+        if (nbytes) *nbytes = o.n;
+        return o.msgs;
+    }
+    RawSink s{h, out, cap, 0, 0};
     struct Lean { modes_host *h; bool was; ~Lean() { h->lean = was; } } lean{h, h->lean};
     h->lean = true;
     modes_host_resolve(h, recs, nrecs, cands, ncand, raw_sink, &s);
@@ -446,10 +613,54 @@ uint64_t modes_host_resolve_raw(modes_host *h, const modes_record *recs, uint64_
 // kept; a piece with a wrong answer is resolved again from the true state (rare: it takes a frame inside another frame's
 // skip window, or one only a not-yet-seen address validates).  Exact by construction; tests/test_host.py compares it with
 // the one-thread listing on every stream.
+//
+// Round 6: ONE parallel region holds the guess and the speculative resolve (a piece waits for the guesses of the pieces
+// before it, not for a second wake-up of the pool), piece i always runs on worker i (its records are in that core's cache
+// from the guess), the first piece writes straight into the caller's buffer, and every piece's text buffer, log and state
+// live as long as the process (a fresh 12 MB of text per call was 3,000 page faults under one address-space lock: the reason
+// four threads were 2.3 x one).  The pool never runs more pieces than the process has CPUs to run them on
+// (modes_host_cpu_budget: affinity and cgroup quota, not the machine's core count).
 // ---------------------------------------------------------------------------------------------
+extern "C" int modes_host_cpu_budget(void) {
+    static const int budget = [] {
+        long n = sysconf(_SC_NPROCESSORS_ONLN);
+        if (n < 1) n = 1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) {
+            const int a = CPU_COUNT(&set);
+            if (a >= 1 && a < n) n = a;
+        }
+        // cgroup v2: "max 100000" or "<quota> <period>"; v1: cpu.cfs_quota_us / cpu.cfs_period_us (-1 = none)
+        long long quota = -1, period = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = "";
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+            fclose(f1);
+            if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(f2, "%lld", &period) != 1) period = 0;
+                fclose(f2);
+            }
+        }
+        if (quota > 0 && period > 0) {
+            const long q = (long)((quota + period - 1) / period);
+            if (q >= 1 && q < n) n = q;
+        }
+        if (const char *e = getenv("MODES_HOST_CPUS")) {                          // (tests, experiments)
+            const long v = atol(e);
+            if (v >= 1) n = v;
+        }
+        return (int)n;
+    }();
+    return budget;
+}
+
 namespace {
 // Worker threads of the multi-threaded resolve: created once per process, on first use (starting 8-32 threads costs more
-// than resolving a batch of 35,000 records).  One parallel loop at a time; callers from different hosts take turns.
+// than resolving a batch of 35,000 records).  One parallel loop at a time; callers from different hosts take turns.  Index i
+// of a loop ALWAYS runs on worker i - 1 (index 0 on the caller).
 class WorkerPool {
 public:
     static WorkerPool &instance() {
@@ -459,11 +670,13 @@ public:
     // fn(0 .. n-1), the caller runs index 0 itself; returns when all are done
     void run(size_t n, const std::function<void(size_t)> &fn) {
         if (n <= 1) { if (n) fn(0); return; }
-        std::lock_guard<std::mutex> turn(turn_);
         {
             std::unique_lock<std::mutex> g(m_);
-            while (workers_.size() < n - 1) workers_.emplace_back([this] { work(); });
-            fn_ = &fn; next_ = 1; total_ = n; left_ = n - 1;
+            while (workers_.size() < n - 1) {
+                const size_t id = workers_.size();
+                workers_.emplace_back([this, id] { work(id); });
+            }
+            fn_ = &fn; total_ = n; left_ = n - 1; gen_++;
         }
         cv_.notify_all();
         fn(0);
@@ -471,21 +684,24 @@ public:
         done_.wait(g, [this] { return left_ == 0; });
         fn_ = nullptr;
     }
+    std::mutex &turn() { return turn_; }
     ~WorkerPool() {
         { std::lock_guard<std::mutex> g(m_); stop_ = true; }
         cv_.notify_all();
         for (auto &w : workers_) w.join();
     }
 private:
-    void work() {
+    void work(size_t id) {
         std::unique_lock<std::mutex> g(m_);
+        uint64_t seen = 0;
         for (;;) {
-            cv_.wait(g, [this] { return stop_ || (fn_ && next_ < total_); });
+            cv_.wait(g, [&] { return stop_ || gen_ != seen; });
             if (stop_) return;
-            const size_t i = next_++;
+            seen = gen_;
+            if (id + 1 >= total_ || !fn_) continue;                               // this loop is shorter than the pool
             const std::function<void(size_t)> *fn = fn_;
             g.unlock();
-            (*fn)(i);
+            (*fn)(id + 1);
             g.lock();
             if (--left_ == 0) done_.notify_all();
         }
@@ -494,68 +710,80 @@ private:
     std::mutex m_, turn_;
     std::condition_variable cv_, done_;
     const std::function<void(size_t)> *fn_ = nullptr;
-    size_t next_ = 0, total_ = 0, left_ = 0;
+    size_t total_ = 0, left_ = 0;
+    uint64_t gen_ = 0;
     bool stop_ = false;
 };
 
 struct Piece {
     const modes_record *recs = nullptr;   // the segment the piece lies in
     uint64_t lo = 0, hi = 0;              // records [lo, hi) of it: whole buffers
-    modes_host host;                 // private copy: config, clock, whitelist (guess, then the piece's own writes), stats of the piece
+    modes_host host;                      // private copy: config, clock, whitelist (guess, then the piece's own writes), stats of the piece
     IcaoLog log;
-    std::string text;
-    uint64_t msgs = 0;
+    char *text = nullptr;                 // the piece's listing: its own buffer (kept from call to call) or, the first piece's, the caller's
+    char *own = nullptr;
+    uint64_t own_cap = 0;
+    uint64_t cap = 0, nbytes = 0, stored = 0, msgs = 0;
     // guess: what the piece's clean DF11/17/18 frames would write to the whitelist (last write per slot)
     uint32_t guess_addr[kIcaoSlots];
     bool guess_set[kIcaoSlots];
+    std::atomic<int> guessed{0};
+    ~Piece() { free(own); }
+    bool own_text(uint64_t need) {
+        if (own_cap < need) {
+            free(own);
+            own_cap = need + need / 4;
+            own = static_cast<char *>(malloc((size_t)own_cap));
+            if (!own) { own_cap = 0; return false; }
+        }
+        text = own;
+        cap = own_cap;
+        return true;
+    }
 };
-struct TextSink {
-    modes_host *h;
-    std::string *text;
-    uint64_t msgs;
-};
-void text_sink(const struct modesMessage *mm, uint32_t, uint32_t, void *user) {
-    TextSink *s = static_cast<TextSink *>(user);
-    if (!modes_host_wants(s->h, mm)) return;
-    char line[40];
-    const int n = modes_format_raw(mm, line);
-    s->text->append(line, (size_t)n);
-    s->msgs++;
+// The pieces of the process (grow-only; used under the pool's turn).
+std::vector<std::unique_ptr<Piece>> &piece_store() {
+    static std::vector<std::unique_ptr<Piece>> store;
+    return store;
+}
+
+inline uint32_t attempt_class(const modes_attempt &a, uint32_t cfg_mask, uint32_t cfg_want, uint32_t fix, uint32_t aggressive) {
+    if ((a.cls & cfg_mask) == cfg_want) return a.cls;
+    return modes_classify(a.msg[0] >> 3, a.errors, a.gate_ok, a.syndrome, a.nfix, fix, aggressive);
 }
 // The addresses a piece's clean DF11/17/18 frames put on the whitelist (dump1090.c:1198: crcok without repair).  Which of
 // them really get decoded depends on skip windows: a guess, checked when the pieces are confirmed.
-void guess_piece(Piece &p, bool aggressive) {
+void guess_piece(Piece &p, const modes_host_config &cfg) {
     memset(p.guess_set, 0, sizeof p.guess_set);
+    const uint32_t fix = cfg.fix_errors ? 1u : 0u, aggressive = cfg.aggressive ? 1u : 0u;
+    const uint32_t cfg_mask = MODES_CLS_VALID | MODES_CLS_FIX | MODES_CLS_AGGRESSIVE;
+    const uint32_t cfg_want = MODES_CLS_VALID | (fix ? MODES_CLS_FIX : 0u) | (aggressive ? MODES_CLS_AGGRESSIVE : 0u);
     for (uint64_t i = p.lo; i < p.hi; i++) {
         for (int a = 0; a < 2; a++) {
             const modes_attempt &at = p.recs[i].att[a];
-            const int df = at.msg[0] >> 3;
-            if (at.gate_ok && at.syndrome == 0 && (df == 11 || df == 17 || df == 18) && (at.errors == 0 || (aggressive && at.errors < 3))) {
+            const uint32_t kind = attempt_class(at, cfg_mask, cfg_want, fix, aggressive) & MODES_CLS_KIND;
+            if (kind == MODES_CLS_CLEAN) {
                 const uint32_t addr = ((uint32_t)at.msg[1] << 16) | ((uint32_t)at.msg[2] << 8) | at.msg[3];
-                const uint32_t sl = icao_slot(addr);
+                const uint32_t sl = modes_icao_slot(addr);
                 p.guess_addr[sl] = addr;
                 p.guess_set[sl] = true;
-                break;                                                            // a good first attempt ends the position
             }
+            if (kind == MODES_CLS_CLEAN || kind == MODES_CLS_FIXED || kind == MODES_CLS_GATE) break;   // the position ends here
         }
     }
 }
 void run_piece(Piece &p) {
-    const modes_record *recs = p.recs;
-    p.log = IcaoLog{};
-    p.text.clear();
-    // (a hint, not a bound: one line per record is the common case - with check_crc off both attempts of a record reach the sink and a
-    //  record prints two lines; the string grows then)
-    p.text.reserve((size_t)(p.hi - p.lo) * 31 + 64);
+    p.log.lookups.clear();
+    memset(p.log.written, 0, sizeof p.log.written);
     p.host.st = modes_host_stats{};
     p.host.have_candidates = false;
     p.host.log = &p.log;
-    p.host.lean = true;
-    TextSink sink{&p.host, &p.text, 0};
-    modes_host_resolve(&p.host, recs + p.lo, p.hi - p.lo, nullptr, 0, text_sink, &sink);
+    LeanOut o(p.text, p.cap);
+    lean_resolve(&p.host, p.recs + p.lo, p.hi - p.lo, o);
     p.host.log = nullptr;
-    p.host.lean = false;
-    p.msgs = sink.msgs;
+    p.nbytes = o.n;
+    p.stored = o.stored;
+    p.msgs = o.msgs;
 }
 }  // namespace
 
@@ -565,12 +793,14 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
                                      char *out, uint64_t cap, uint64_t *nbytes, int threads, IcaoLog *outer) {
     uint64_t nrecs = 0;
     for (uint32_t g = 0; g < nsegs; g++) nrecs += seg_nrecs[g];
-    // threads < 0: exactly -threads pieces however short the list (tests); otherwise at least 2048 records per thread
+    // threads < 0: exactly -threads pieces however short the list and however few CPUs (tests); otherwise at least 2048 records
+    // per thread and no more threads than the process may run at once
     const uint64_t kMinPiece = threads < 0 ? 1 : 2048;
     int T = threads < 0 ? -threads : threads;
+    if (threads >= 0 && T > modes_host_cpu_budget()) T = modes_host_cpu_budget();
     T = T < 1 ? 1 : (T > 64 ? 64 : T);
     if ((uint64_t)T > nrecs / kMinPiece) T = (int)(nrecs / kMinPiece);
-    if (T <= 1) {                                                                 // one thread: segment after segment
+    auto one_thread = [&]() -> uint64_t {                                         // segment after segment
         uint64_t msgs = 0, total = 0;
         struct Log { modes_host *h; IcaoLog *was; ~Log() { h->log = was; } } keep{h, h->log};
         if (outer) h->log = outer;                                                // (the log's `written` carries over from segment to segment)
@@ -581,11 +811,13 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
         }
         if (nbytes) *nbytes = total;
         return msgs;
-    }
+    };
+    if (T <= 1) return one_thread();
     // pieces: about nrecs / T records each, inside one segment, cut where the buffer changes (the skip window resets
     // there; a segment ends with a whole buffer)
-    std::vector<Piece> pieces;
-    pieces.reserve((size_t)T + nsegs);
+    struct Cut { const modes_record *recs; uint64_t lo, hi; };
+    std::vector<Cut> cuts;
+    cuts.reserve((size_t)T + nsegs);
     const uint64_t share = (nrecs + (uint64_t)T - 1) / (uint64_t)T;
     for (uint32_t g = 0; g < nsegs; g++) {
         const modes_record *recs = segs[g];
@@ -595,14 +827,11 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
             uint64_t hi = lo + share < n ? lo + share : n;
             while (hi < n && recs[hi].block == recs[hi - 1].block) hi++;
             if (n - hi < share / 4) hi = n;                                       // no sliver at the end of a segment
-            pieces.emplace_back();
-            pieces.back().recs = recs;
-            pieces.back().lo = lo;
-            pieces.back().hi = hi;
+            cuts.push_back(Cut{recs, lo, hi});
             lo = hi;
         }
     }
-    const size_t P = pieces.size();
+    const size_t P = cuts.size();
     if (P > 64) {                                                                 // many short segments: fewer, longer pieces are not worth the code
         uint64_t msgs = 0, total = 0;
         for (uint32_t g = 0; g < nsegs; g++) {
@@ -613,32 +842,51 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
         if (nbytes) *nbytes = total;
         return msgs;
     }
+    WorkerPool &pool = WorkerPool::instance();
+    std::unique_lock<std::mutex> turn(pool.turn());                               // the pieces below belong to the process
+    std::vector<std::unique_ptr<Piece>> &pieces = piece_store();
+    while (pieces.size() < P) pieces.emplace_back(new Piece);
     const bool dbg = getenv("MODES_HOST_MT_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    // guesses, in parallel: every piece lists what its clean frames would write; the state a piece starts from is the
-    // batch's initial state with the lists of the pieces before it applied in order
-    const bool aggressive = h->cfg.aggressive != 0;
-    WorkerPool::instance().run(P, [&](size_t t) { guess_piece(pieces[t], aggressive); });
-    {
-        modes_host g = *h;
-        g.log = nullptr;
-        for (size_t t = 0; t < P; t++) {
-            pieces[t].host = g;
-            for (uint32_t sl = 0; sl < kIcaoSlots; sl++)
-                if (pieces[t].guess_set[sl]) { g.icao[sl] = pieces[t].guess_addr[sl]; g.icao_seen[sl] = g.now_s; }
+    const uint64_t per_record = h->cfg.check_crc ? 31 : 62;                       // lines a record can print: one behind the filter of :1803, else two
+    for (size_t t = 0; t < P; t++) {
+        Piece &p = *pieces[t];
+        p.recs = cuts[t].recs;
+        p.lo = cuts[t].lo;
+        p.hi = cuts[t].hi;
+        p.guessed.store(0, std::memory_order_relaxed);
+        if (t == 0 && out) { p.text = out; p.cap = cap; }                         // the first piece's text is where it belongs
+        else if (!p.own_text((p.hi - p.lo) * per_record + 64)) {                  // no memory for a piece's text: the sequential resolve needs none
+            turn.unlock();
+            return one_thread();
         }
     }
-    const double t1 = now();
-    // speculative resolve, one worker per piece
-    WorkerPool::instance().run(P, [&](size_t t) { run_piece(pieces[t]); });
+    // ONE parallel region: every piece lists what its clean frames would write; the state a piece starts from is the
+    // batch's initial state with the lists of the pieces before it applied in order; then the speculative resolve
+    modes_host start = *h;
+    start.log = nullptr;
+    start.lean = false;
+    pool.run(P, [&](size_t t) {
+        Piece &p = *pieces[t];
+        guess_piece(p, start.cfg);
+        p.guessed.store(1, std::memory_order_release);
+        p.host = start;
+        for (size_t k = 0; k < t; k++) {
+            const Piece &q = *pieces[k];
+            for (int spin = 0; !q.guessed.load(std::memory_order_acquire); spin++)
+                if (spin > 64) std::this_thread::yield();
+            for (uint32_t sl = 0; sl < kIcaoSlots; sl++)
+                if (q.guess_set[sl]) { p.host.icao[sl] = q.guess_addr[sl]; p.host.icao_seen[sl] = start.now_s; }
+        }
+        run_piece(p);
+    });
     const double t2 = now();
     int reruns = 0;
     // confirm in order: the true state at the start of piece t is the confirmed state at the end of piece t - 1
-    modes_host truth = *h;                                                        // whitelist + clock of the true sequential run
-    truth.log = nullptr;
+    modes_host truth = start;                                                     // whitelist + clock of the true sequential run
     for (size_t t = 0; t < P; t++) {
-        Piece &p = pieces[t];
+        Piece &p = *pieces[t];
         bool ok = true;
         for (const IcaoLog::Lookup &q : p.log.lookups) {
             if (icao_known(&truth, q.addr) != q.known) { ok = false; break; }
@@ -670,7 +918,7 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
     bool full = false;
     std::vector<uint64_t> at(P, 0), take(P, 0);                                  // where a piece's text goes, how much of it
     for (size_t t = 0; t < P; t++) {
-        Piece &p = pieces[t];
+        Piece &p = *pieces[t];
         h->st.valid_preamble += p.host.st.valid_preamble;
         h->st.out_of_phase += p.host.st.out_of_phase;
         h->st.demodulated += p.host.st.demodulated;
@@ -682,26 +930,27 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
         // what the header promises when the listing outgrows `cap`: whole lines, as many as fit, nothing behind them -
         // the first piece that does not fit contributes the whole lines of its beginning, every later piece nothing
         if (out && !full) {
-            size_t n = p.text.size();
-            if (total + n + 1 > cap) {
+            uint64_t n = p.stored;                                                // (== p.nbytes unless the piece's own buffer was too small: never, by its size)
+            if (p.stored < p.nbytes || total + n + 1 > cap) {
                 full = true;
-                n = cap > total + 1 ? (size_t)(cap - total - 1) : 0;
+                if (total + n + 1 > cap) n = cap > total + 1 ? cap - total - 1 : 0;
                 while (n > 0 && p.text[n - 1] != '\n') n--;
             }
             at[t] = total;
             take[t] = n;
             stored = total + n;
         }
-        total += p.text.size();
+        total += p.nbytes;
         msgs += p.msgs;
     }
-    // the copies themselves on the workers: 12 MB for the 524,000 lines of a --gpus 8 step is 0.4 ms on one thread
-    if (out) WorkerPool::instance().run(P, [&](size_t t) { if (take[t]) memcpy(out + at[t], pieces[t].text.data(), (size_t)take[t]); });
+    // the copies themselves on the workers (the first piece's text is in place): 12 MB for the 524,000 lines of a --gpus 8
+    // step is 0.4 ms on one thread
+    if (out) pool.run(P, [&](size_t t) { if (take[t] && pieces[t]->text != out + at[t]) memcpy(out + at[t], pieces[t]->text, (size_t)take[t]); });
     if (out && stored < cap) out[stored] = 0;
     if (nbytes) *nbytes = total;
     if (dbg)
-        fprintf(stderr, "resolve_raw_mt: %zu pieces in %u segment(s), %llu records: guess %.2f ms, speculative %.2f ms, confirm %.2f ms (%d re-run), merge %.2f ms\n",
-                P, nsegs, (unsigned long long)nrecs, t1 - t0, t2 - t1, t3 - t2, reruns, now() - t3);
+        fprintf(stderr, "resolve_raw_mt: %zu pieces in %u segment(s), %llu records: guess + speculative %.2f ms, confirm %.2f ms (%d re-run), merge %.2f ms\n",
+                P, nsegs, (unsigned long long)nrecs, t2 - t0, t3 - t2, reruns, now() - t3);
     return msgs;
 }
 
@@ -740,21 +989,28 @@ void modes_host_whitelist_guess(const modes_host *h, const modes_record *const *
     if (nrecs == 0) return;
     // pieces in stream order (any cut will do: the lists are only read); a later piece's address wins its slot
     int T = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+    if (T > modes_host_cpu_budget()) T = modes_host_cpu_budget();
     if ((uint64_t)T > nrecs / 4096 + 1) T = (int)(nrecs / 4096 + 1);
     const uint64_t share = (nrecs + (uint64_t)T - 1) / (uint64_t)T;
-    std::vector<Piece> pieces;
+    WorkerPool &pool = WorkerPool::instance();
+    std::lock_guard<std::mutex> turn(pool.turn());
+    std::vector<std::unique_ptr<Piece>> &pieces = piece_store();
+    size_t P = 0;
     for (uint32_t g = 0; g < nsegs; g++)
         for (uint64_t lo = 0; lo < seg_nrecs[g]; lo += share) {
-            pieces.emplace_back();
-            pieces.back().recs = segs[g];
-            pieces.back().lo = lo;
-            pieces.back().hi = lo + share < seg_nrecs[g] ? lo + share : seg_nrecs[g];
+            if (pieces.size() <= P) pieces.emplace_back(new Piece);
+            Piece &p = *pieces[P++];
+            p.recs = segs[g];
+            p.lo = lo;
+            p.hi = lo + share < seg_nrecs[g] ? lo + share : seg_nrecs[g];
         }
-    const bool aggressive = h->cfg.aggressive != 0;
-    WorkerPool::instance().run(pieces.size(), [&](size_t t) { guess_piece(pieces[t], aggressive); });
-    for (const Piece &p : pieces)
+    const modes_host_config cfg = h->cfg;
+    // (more segments than the pool has workers for: the pieces of one worker in turn)
+    const size_t W = P < 64 ? P : 64;
+    pool.run(W, [&](size_t w) { for (size_t t = w; t < P; t += W) guess_piece(*pieces[t], cfg); });
+    for (size_t t = 0; t < P; t++)
         for (uint32_t s = 0; s < kIcaoSlots; s++)
-            if (p.guess_set[s]) guess[s] = p.guess_addr[s];
+            if (pieces[t]->guess_set[s]) guess[s] = pieces[t]->guess_addr[s];
 }
 
 uint64_t modes_host_resolve_raw_spec(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
@@ -777,6 +1033,19 @@ int modes_host_whitelist_check(const modes_host *h, const modes_icao_lookup *loo
     for (uint64_t i = 0; i < n; i++)
         if (icao_known(&probe, lookups[i].addr) != (lookups[i].known != 0)) return 0;
     return 1;
+}
+
+// What the kernels leave in modes_attempt.cls / .slot, for records of another producer (the oracle in the CPU tests, a
+// capture replayed from disk): the same modes_classify() on the host, in place.
+void modes_host_classify(const modes_host_config *cfg, modes_record *recs, uint64_t nrecs) {
+    const uint32_t fix = cfg->fix_errors ? 1u : 0u, aggressive = cfg->aggressive ? 1u : 0u;
+    for (uint64_t i = 0; i < nrecs; i++)
+        for (int a = 0; a < 2; a++) {
+            modes_attempt &at = recs[i].att[a];
+            const uint32_t cls = modes_classify(at.msg[0] >> 3, at.errors, at.gate_ok, at.syndrome, at.nfix, fix, aggressive);
+            at.cls = (uint8_t)cls;
+            at.slot = (uint16_t)modes_class_slot(cls, at.msg[1], at.msg[2], at.msg[3], at.syndrome);
+        }
 }
 
 // '*' + two hex digits per byte + ";\n".  A byte -> its two digits through a 256-entry table (one 2-byte store per message

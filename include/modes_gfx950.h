@@ -95,9 +95,31 @@ typedef struct {
     uint8_t  gate_ok;      /* 1 if mean |lo-hi| >= 2550 (dump1090.c:1723)             */
     uint8_t  nfix;         /* bits fixBitErrors would flip: 0, 1 or 2                 */
     uint8_t  fixpos[2];    /* their message-relative positions, 0xff if unused        */
-    uint8_t  pad[5];
+    uint8_t  cls;          /* MODES_CLS_*: what decodeModesMessage() will make of this attempt (below); 0 = not classified */
+    uint16_t slot;         /* ICAO-whitelist slot (dump1090.c:898-905) of the address a CLEAN / IID / AP attempt writes or asks for */
+    uint8_t  pad[2];
     uint32_t syndrome;     /* modesChecksum() of msg (dump1090.c:733); 0 if !gate_ok  */
 } modes_attempt;
+
+/* modes_attempt.cls (ABI 5) - the per-message decisions of decodeModesMessage() that do not depend on the ICAO whitelist, made on
+ * the GPU by the wavefront that demodulated the attempt (it holds the DF, the syndrome and the repair): which branch of
+ * dump1090.c:1099-1128 / :1183-1210 / :1731 the attempt takes.  The host's --raw resolve (modes_host_resolve_raw*) is then: skip
+ * window, this byte, at most one whitelist access through `slot`, and the hex line.  A host configured differently from the context
+ * that wrote the byte (MODES_CLS_FIX / MODES_CLS_AGGRESSIVE disagree), or handed records without it (cls == 0: another producer),
+ * classifies by itself - modes_classify() in dump1090_amd/csrc/modes_core.h is the one definition both sides compile. */
+#define MODES_CLS_KIND       0x07u
+#define MODES_CLS_GATE       1u   /* the noise gate failed: the position ends here (dump1090.c:1723-1726)                      */
+#define MODES_CLS_SKIP       2u   /* too many slicing errors for this mode (dump1090.c:1731): not decoded, the retry follows   */
+#define MODES_CLS_CLEAN      3u   /* DF11/17/18, syndrome 0: crcok, the address goes on the whitelist (dump1090.c:1198)        */
+#define MODES_CLS_FIXED      4u   /* DF11/17/18 repaired by nfix bits (dump1090.c:1112-1128): crcok, no whitelist access       */
+#define MODES_CLS_IID        5u   /* DF11, syndrome 1..79, no repair: crcok iff the whitelist knows msg[1..3] (dump1090.c:1204) */
+#define MODES_CLS_AP         6u   /* DF0/4/5/16/20/21/24: crcok iff the whitelist knows the address = the syndrome (dump1090.c:942-983) */
+#define MODES_CLS_BAD        7u   /* decoded, never crcok                                                                      */
+#define MODES_CLS_LONG       0x08u  /* 112-bit message (the DF as demodulated, dump1090.c:1100)                                */
+#define MODES_CLS_NOERR      0x10u  /* errors == 0 (the "demodulated with zero errors" counter, dump1090.c:1739)              */
+#define MODES_CLS_FIX        0x20u  /* classified with fix_errors on ...                                                       */
+#define MODES_CLS_AGGRESSIVE 0x40u  /* ... with aggressive on                                                                  */
+#define MODES_CLS_VALID      0x80u  /* the byte has been written                                                               */
 
 /* att[0]: samples as received.  att[1]: after applyPhaseCorrection
  * (dump1090.c:1498-1558; identical to att[0] when j == 0, dump1090.c:1660).
@@ -237,7 +259,7 @@ int modes_gpu_stream_ceiling(modes_gpu *ctx, const void *d_iq, uint64_t nbytes, 
                              float *avg_ms, float *min_ms, void *stream);
 
 /* ABI version of this header. */
-#define MODES_GFX950_ABI 4
+#define MODES_GFX950_ABI 5
 int modes_gpu_abi_version(void);
 
 #ifdef __cplusplus

@@ -161,6 +161,21 @@ uint64_t modes_host_resolve_raw(modes_host *h, const modes_record *recs, uint64_
                                 const uint64_t *candidates, uint64_t ncand,
                                 char *out, uint64_t cap, uint64_t *nbytes);
 
+/* How the --raw resolvers above and below work since ABI 5 of modes_gfx950.h (the LEAN resolve): the per-message decisions of
+ * decodeModesMessage() that do not need the whitelist arrive in modes_attempt.cls / .slot, made by the GPU wavefront that
+ * demodulated the attempt; the host keeps the skip window (dump1090.c:1770), answers at most one whitelist question per attempt
+ * (dump1090.c:1198, :1204, :942-983) and writes the line.  Records without the byte (cls == 0) or classified for another
+ * configuration are classified here, by the same function.  modes_host_resolve() with a sink is the general form. */
+
+/* CPUs this process may use at once: the smallest of online CPUs, the affinity mask and the cgroup CPU quota (cpu.max /
+ * cfs_quota_us, rounded up) - what a pool of threads has to be sized by (a container on a 256-thread host may be held to 16).
+ * The multi-threaded resolvers below never run more pieces than this at a time. */
+int modes_host_cpu_budget(void);
+
+/* modes_attempt.cls / .slot (include/modes_gfx950.h MODES_CLS_*) for records that do not carry them - another producer's, a
+ * capture replayed from disk - written in place, for the configuration `cfg`: what the kernels write. */
+void modes_host_classify(const modes_host_config *cfg, modes_record *recs, uint64_t nrecs);
+
 /* The same listing (and the same whitelist / counter updates) computed by up to `threads` threads: the batch is cut at
  * buffer boundaries, the pieces are resolved speculatively and confirmed in order (modes_host.cpp) - byte-identical to
  * modes_host_resolve_raw without candidates.  For hosts whose one resolve thread would be the bottleneck: a

@@ -4,7 +4,7 @@ records can be compared field by field."""
 import numpy as np
 
 import oracle as orc
-from dump1090_amd import RECORD_DTYPE, BLOCK_STRIDE
+from dump1090_amd import RECORD_DTYPE, BLOCK_STRIDE, _native as N
 
 
 def oracle_records(data: np.ndarray, maxfix: int, blocks=None):
@@ -49,3 +49,15 @@ def assert_records_equal(got: np.ndarray, want: np.ndarray, ctx=""):
             sel = np.ones(want.size, dtype=bool)
         for f in ("msg", "errors", "nfix", "fixpos", "syndrome"):
             assert np.array_equal(got["att"][f][sel, a], want["att"][f][sel, a]), (ctx, a, f)
+    if got.size and got["att"]["cls"].any():
+        # the class byte and whitelist slot the kernels leave (include/modes_gfx950.h MODES_CLS_*): every attempt carries them, all
+        # for one repair policy, and they are what modes_classify makes of the ORACLE's attempt for that policy
+        c = got["att"]["cls"]
+        assert (c & 0x80).all() and len(set((c & 0x60).reshape(-1).tolist())) == 1, (ctx, "class bytes: valid, one policy")
+        fix, aggressive = bool(c[0, 0] & 0x20), bool(c[0, 0] & 0x40)
+        ref = N.classify_records(want, fix=fix, aggressive=aggressive)
+        for a in (0, 1):
+            live = want["att"]["gate_ok"][:, a] == 1
+            assert np.array_equal(c[live, a], ref["att"]["cls"][live, a]), (ctx, a, "cls")
+            assert np.array_equal(got["att"]["slot"][live, a], ref["att"]["slot"][live, a]), (ctx, a, "slot")
+            assert ((c[~live, a] & 7) == 1).all(), (ctx, a, "a failed gate is class GATE")

@@ -31,7 +31,7 @@ def test_gpu_library_exports_header():
     L = N.gpu_lib()
     for n in names:
         assert getattr(L, n)
-    assert L.modes_gpu_abi_version() == 4
+    assert L.modes_gpu_abi_version() == 5
 
 
 def test_gather_library_exports_header():

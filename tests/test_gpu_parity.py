@@ -37,7 +37,7 @@ def test_native_library_is_loaded(torch_cuda):
     maps = open("/proc/self/maps").read()
     assert os.path.realpath(N.GPU_LIB) in maps, "libmodes_gfx950.so is not mapped"
     assert os.path.realpath(N.HOST_LIB) in maps, "libmodes_host.so is not mapped"
-    assert N.gpu_lib().modes_gpu_abi_version() == 4
+    assert N.gpu_lib().modes_gpu_abi_version() == 5
     r.close()
     d.close()
 
@@ -162,6 +162,8 @@ def test_records_and_candidates_match_oracle(torch_cuda, streams, case, demod_va
         assert np.array_equal(cands, want_cands), (case, "preamble positions")
         assert info["n_preambles"] == want_cands.size and info["n_forwarded"] >= want_cands.size
         assert_records_equal(recs, want, ctx=(case, mf))
+        if recs.size:       # the class bytes are for THIS context's repair policy (the host believes no others)
+            assert ((recs["att"]["cls"] & 0xE0) == (0x80 | (0x20 if flags["fix"] else 0) | (0x40 if flags["aggressive"] else 0))).all()
         d.close()
 
 

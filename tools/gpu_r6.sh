@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-6 GPU call: named steps, each with its own timeout and log under gpurun_out/<tag>/.
+#   tools/gpu_r6.sh <tag> step [step ...]
+TAG=${1:-r6}
+shift || true
+R=$PWD
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+export TMPDIR=/tmp
+run() { name=$1; shift; echo "== $name"; ( time timeout "$@" ) > "$O/$name.log" 2>&1; echo "   rc=$? $(tail -n 4 "$O/$name.log" | tr '\n' ' ' | cut -c1-500)"; }
+for s in "$@"; do
+  case $s in
+    smoke)     run smoke 400 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    parity)    run parity 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider ;;
+    all)       run pytest_gpu_all 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider ;;
+    resolve)   run resolve_rate 600 python tools/resolve_rate.py; grep '^{' "$O/resolve_rate.log" > "$O/resolve_rate.json" ;;
+    ranks8)    run rank_resolve_8ranks 1200 python -m pytest tests/test_gpu_bench.py -m gpu -q -x -p no:cacheprovider -k eight_ranks -s ;;
+    bench)     run bench 900 python bench.py ;;
+    bench20)   run bench20 900 python bench.py --steps 20 --warmup 5 ;;
+    prof)      bash tools/profile.sh ${TAG} noise > "$O/prof_noise.log" 2>&1; tail -n 30 "$O/prof_noise.log" ;;
+    prof_low)  bash tools/profile.sh ${TAG}_lowsnr lowsnr > "$O/prof_lowsnr.log" 2>&1; tail -n 40 "$O/prof_lowsnr.log" ;;
+    prof_frames) bash tools/profile.sh ${TAG}_frames frames > "$O/prof_frames.log" 2>&1; tail -n 40 "$O/prof_frames.log" ;;
+    prof_strong) bash tools/profile.sh ${TAG}_strong frames --frames-mib 65536 > "$O/prof_strong.log" 2>&1; tail -n 40 "$O/prof_strong.log" ;;
+    e2e)       run e2e_cli 900 python tools/e2e_cli.py 8 ;;
+    pipe)      run pipe_cadence 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider -k "pipe or paced" ;;
+    fuzz)      run fuzz_parity 900 python tools/fuzz_parity.py 5000 600 ;;
+    *)         echo "unknown step $s" ;;
+  esac
+done
+for f in "$O"/bench*.log; do
+  [ -f "$f" ] && grep '^{' "$f" > "${f%.log}.json"
+done
+for d in $R/gpurun_out/prof_${TAG}*; do
+  [ -d "$d" ] && mkdir -p "$O/$(basename $d)" && cp "$d"/summary.txt "$d"/traffic.json "$O/$(basename $d)/" 2>/dev/null
+  [ -d "$d" ] && find "$d" -name "*kernel_stats.csv" -exec cp {} "$O/$(basename $d)/kt_kernel_stats.csv" \;
+done
+echo "== done"
