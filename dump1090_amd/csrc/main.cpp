@@ -44,6 +44,7 @@
 
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <poll.h>
 #include <sys/mman.h>
 #include <sys/prctl.h>
 #include <sys/stat.h>
@@ -76,6 +77,8 @@ struct Options {
     char **argv = nullptr;                 // for the one restart --ranks may need (the other IPC mode)
     uint32_t gather_cands = 0;             // --gather-candidates: preamble positions per rank and round (--stats); 0 = positions of a batch / 64
     bool resolve_on_ranks = false;         // --resolve-on-ranks: with --ranks and --raw, every rank resolves its own batch; only text reaches rank 0
+    int flush_ms = 66;                     // --flush-ms: a pipe's batch is submitted when it is full OR this long after it began, whole buffers
+                                           // only (one 256 KiB buffer is 65.5 ms of air time at 2 Msps: the reference's own cadence)
 };
 
 struct Sink {
@@ -110,7 +113,11 @@ void show_help() {
         "                         record leaves its rank, no communicator is made (the listing is the same).\n"
         "--gather-records <n>     With --ranks: records per rank and round the gather buffers hold (default: 262144).\n"
         "--gather-candidates <n>  With --ranks --stats: preamble positions per rank and round (default: a batch's positions / 64).\n"
-        "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).\n"
+        "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).  A file always fills its batches; a pipe\n"
+        "                         (--ifile -, a FIFO) is served at the pace it delivers: see --flush-ms.\n"
+        "--flush-ms <n>           Input that cannot seek: submit what has arrived - whole 256 KiB buffers - when the batch is\n"
+        "                         full or <n> ms after it began (default: 66 = one buffer at 2 Msps).  A fast pipe still gets\n"
+        "                         full batches; a live one is printed within two buffers, like the reference's own loop.\n"
         "--depth <n>              Batches in flight per device (default: 2; --ranks: at least 3).\n"
         "--read-threads <n>       Threads reading a regular file (default: 16).\n"
         "--no-mmap                Read a regular file with pread() instead of copying out of a mapping of it.\n"
@@ -242,6 +249,35 @@ bool read_full(int fd, uint8_t *dst, size_t want, size_t *got) {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// Input that cannot seek (a pipe, a FIFO, a socket): the reference prints a buffer's messages 65 ms after its samples arrived
+// (dump1090.c:460-512 hands over ONE buffer; :2969-2990 decodes it at once), and a host that waits for 128 MiB before its first
+// GPU call would sit on a 2 Msps stream for 33 s.  So a batch read from such an input ends when it is full, when the stream
+// ends, or - at least one whole buffer being there - flush_s after the read began; until a whole buffer is there it waits
+// without a deadline.  dst[0 .. have) already holds bytes (what the previous batch read beyond its last whole buffer).
+// *n = bytes at dst afterwards, *eof = the stream has ended.
+bool read_paced(int fd, uint8_t *dst, size_t have, size_t want, double flush_s, size_t *n, bool *eof) {
+    const double t0 = now_s();
+    *n = have;
+    *eof = false;
+    while (*n < want) {
+        int timeout = -1;                                                        // no whole buffer yet: wait for as long as it takes
+        if (*n >= MODES_DATA_LEN) {
+            const double left = t0 + flush_s - now_s();
+            if (left <= 0) break;
+            timeout = (int)(left * 1e3) + 1;
+        }
+        struct pollfd pf{fd, POLLIN, 0};
+        const int pr = poll(&pf, 1, timeout);
+        if (pr < 0) { if (errno == EINTR) continue; return false; }
+        if (pr == 0) break;                                                      // the deadline, with whole buffers in hand
+        const ssize_t r = read(fd, dst + *n, want - *n);
+        if (r < 0) { if (errno == EINTR || errno == EAGAIN) continue; return false; }
+        if (r == 0) { *eof = true; break; }
+        *n += (size_t)r;
+    }
+    return true;
+}
+
 struct Lane {
     modes_gpu *gpu = nullptr;
     uint8_t *buf = nullptr;
@@ -306,7 +342,9 @@ int run_ranks(const Options &opt, double t_start) {
     const bool feed = opt.loop || opt.filename == "-";
     const int depth = std::max(3, opt.depth);        // three stages are in flight per rank (round q submits, q - 1 exchanges, q - 2 is resolved)
     const size_t batch_bytes = (size_t)opt.batch_blocks * MODES_DATA_LEN;
-    struct FeedSlot { std::atomic<uint64_t> seq; uint64_t nbytes; };           // seq: 0 = free, b + 1 = holds batch b (carry + nbytes new bytes)
+    // seq: 0 = free, b + 1 = holds batch b (carry + nbytes new bytes, buffers first_block ..; eof: the stream ends here and the batch carries
+    // the EOF buffer).  A file's batches all have batch_blocks buffers; a pipe's have what had arrived when they were cut (read_paced).
+    struct FeedSlot { std::atomic<uint64_t> seq; uint64_t nbytes, first_block; int eof; };
     struct FeedHead { std::atomic<uint64_t> total; std::atomic<int> failed; };  // total: batches of the stream, ~0 until the reader has seen the end
     const size_t slot_bytes = (MODES_CARRY_BYTES + batch_bytes + 4095) & ~(size_t)4095;
     const size_t nslots = (size_t)N * (size_t)depth;
@@ -321,7 +359,7 @@ int run_ranks(const Options &opt, double t_start) {
         feed_head->total.store(~0ull);
         feed_head->failed.store(0);
         feed_slots = reinterpret_cast<FeedSlot *>(static_cast<uint8_t *>(m) + sizeof(FeedHead));
-        for (size_t i = 0; i < nslots; i++) { new (&feed_slots[i]) FeedSlot; feed_slots[i].seq.store(0); feed_slots[i].nbytes = 0; }
+        for (size_t i = 0; i < nslots; i++) { new (&feed_slots[i]) FeedSlot; feed_slots[i].seq.store(0); feed_slots[i].nbytes = 0; feed_slots[i].first_block = 0; feed_slots[i].eof = 0; }
         feed_mem = static_cast<uint8_t *>(m) + ctl;
     }
     // --resolve-on-ranks (include/modes_host.h "resolve on the ranks that demodulated"; dump1090_amd/distributed.py has the same protocol over
@@ -554,31 +592,52 @@ int run_ranks(const Options &opt, double t_start) {
         reader = std::thread([&] {
             // dump1090.c:460-512 for N consumers: batch b = the previous batch's last 476 bytes + the next batch_bytes of the stream;
             // --loop seeks back and keeps filling the same batch (:488-494); a short batch ends the stream
-            std::vector<uint8_t> tail(MODES_CARRY_BYTES, 127);
+            std::vector<uint8_t> tail(MODES_CARRY_BYTES, 127), pend;
+            // input that cannot seek is served at the pace it delivers (read_paced): a batch is what had arrived - whole buffers - when it
+            // was full or --flush-ms after it began; the bytes read beyond the last whole buffer open the next batch
+            const bool paced = lseek(fd, 0, SEEK_CUR) == (off_t)-1;
+#ifdef F_SETPIPE_SZ
+            if (paced) (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);
+#endif
+            uint64_t first_block = 0;
             for (uint64_t b = 0;; b++) {
                 FeedSlot &sl = feed_slots[b % nslots];
-                while (sl.seq.load(std::memory_order_acquire) != 0) {
+                for (int spin = 0; sl.seq.load(std::memory_order_acquire) != 0; spin++) {
                     if (feed_head->failed.load()) return;
-                    usleep(50);
+                    usleep(spin < 100 ? 50 : 1000);
                 }
                 uint8_t *dst = feed_mem + (b % nslots) * slot_bytes;
                 if (b) memcpy(dst, tail.data(), MODES_CARRY_BYTES);
                 uint8_t *data = dst + (b ? MODES_CARRY_BYTES : 0);
                 size_t got = 0;
-                if (!read_full(fd, data, batch_bytes, &got)) { perror("read"); feed_head->failed.store(1); return; }
-                while (got < batch_bytes && opt.loop && fd != 0) {
-                    if (lseek(fd, 0, SEEK_SET) == -1) break;
-                    size_t more = 0;
-                    if (!read_full(fd, data + got, batch_bytes - got, &more)) { perror("read"); feed_head->failed.store(1); return; }
-                    if (more == 0) break;                                    // empty file
-                    got += more;
+                bool ended = false;
+                if (paced) {
+                    if (!pend.empty()) memcpy(data, pend.data(), pend.size());
+                    size_t n = 0;
+                    if (!read_paced(fd, data, pend.size(), batch_bytes, opt.flush_ms * 1e-3, &n, &ended)) { perror("read"); feed_head->failed.store(1); return; }
+                    pend.clear();
+                    got = n;
+                    if (!ended && n < batch_bytes) { got = n - n % MODES_DATA_LEN; pend.assign(data + got, data + n); }
+                } else {
+                    if (!read_full(fd, data, batch_bytes, &got)) { perror("read"); feed_head->failed.store(1); return; }
+                    while (got < batch_bytes && opt.loop && fd != 0) {
+                        if (lseek(fd, 0, SEEK_SET) == -1) break;
+                        size_t more = 0;
+                        if (!read_full(fd, data + got, batch_bytes - got, &more)) { perror("read"); feed_head->failed.store(1); return; }
+                        if (more == 0) break;                                    // empty file
+                        got += more;
+                    }
+                    ended = got < batch_bytes;
                 }
                 if (got >= MODES_CARRY_BYTES) memcpy(tail.data(), data + got - MODES_CARRY_BYTES, MODES_CARRY_BYTES);
                 fed_bytes += got;
                 sl.nbytes = got;
-                if (got < batch_bytes) feed_head->total.store(b + 1, std::memory_order_release);      // this batch carries the EOF buffer
+                sl.first_block = first_block;
+                sl.eof = ended ? 1 : 0;
+                first_block += got / MODES_DATA_LEN;
+                if (ended) feed_head->total.store(b + 1, std::memory_order_release);                  // this batch carries the EOF buffer
                 sl.seq.store(b + 1, std::memory_order_release);
-                if (got < batch_bytes) return;
+                if (ended) return;
             }
         });
     Pool pool(std::max(1, opt.read_threads / N));
@@ -592,9 +651,10 @@ int run_ranks(const Options &opt, double t_start) {
     uint64_t rr_applied = 0;                                                 // rounds whose writes are in `truth`
     auto rr_at = [&](uint64_t round, int r) -> RrRank & { return rr_ranks[(size_t)(round % (uint64_t)depth) * (size_t)N + (size_t)r]; };
     auto rr_wait = [&](const std::atomic<uint64_t> &a, uint64_t v) {         // false: another rank failed (or this one's peers are gone)
-        for (int spin = 0; a.load(std::memory_order_acquire) < v; spin++) {
+        for (int spin = 0; a.load(std::memory_order_acquire) < v;) {
             if (rr_head->failed.load()) return false;
-            if (spin > 200) usleep(20);
+            if (spin < 100000) spin++;                                           // (saturates: a live pipe can keep a rank here for minutes)
+            if (spin > 200) usleep(spin < 2000 ? 20 : 1000);                     // short waits spin, long ones - a batch of a live stream - sleep
         }
         return true;
     };
@@ -635,7 +695,9 @@ int run_ranks(const Options &opt, double t_start) {
             for (uint32_t sidx = 0; sidx < MODES_ICAO_SLOTS; sidx++)
                 if (o.guess[sidx] != MODES_ICAO_NONE) { st_addr[sidx] = o.guess[sidx]; st_seen[sidx] = now; }
         }
-        if (const char *sp = getenv("MODES_RR_SPOIL"); sp && *sp && rank > 0) { std::fill(st_addr.begin(), st_addr.end(), 0u); std::fill(st_seen.begin(), st_seen.end(), (int64_t)0); }   // tests: a wrong start
+#ifdef MODES_TEST_HOOKS                                                          // (the stub builds of tools/sanitize_host.sh: a wrong start on purpose)
+        if (const char *sp = getenv("MODES_RR_SPOIL"); sp && *sp && rank > 0) { std::fill(st_addr.begin(), st_addr.end(), 0u); std::fill(st_seen.begin(), st_seen.end(), (int64_t)0); }
+#endif
         char *text = rr_text + ((size_t)l * (size_t)N + (size_t)rank) * rr_text_cap;
         lookups.resize((size_t)nrec * 2 + 16);
         uint64_t nb = 0, nl = 0, lines = 0;
@@ -677,89 +739,118 @@ int run_ranks(const Options &opt, double t_start) {
         }
         return true;
     };
-    for (uint64_t q = 0; (nrounds == ~0ull || q < nrounds + 2) && !rc; q++) {
-        if (nrounds == ~0ull || q < nrounds) {                               // submit this rank's batch of round q
-            const int l = (int)(q % (uint64_t)depth);
-            const uint64_t b = q * (uint64_t)N + (uint64_t)rank;
-            const uint8_t *src = nullptr;
-            size_t got = 0;
-            FeedSlot *slot = nullptr;
-            if (feed) {
-                // wait for the reader: either batch b is there, or the stream has ended in front of it (then the round may not exist at all)
-                slot = &feed_slots[b % nslots];
-                for (;;) {
-                    if (slot->seq.load(std::memory_order_acquire) == b + 1) break;
-                    const uint64_t total = feed_head->total.load(std::memory_order_acquire);
-                    if (total != ~0ull && total <= b) { slot = nullptr; break; }
-                    if (feed_head->failed.load()) { fail_rank("input", "the reader failed"); break; }
-                    usleep(50);
-                }
-                if (rc) break;
-                const uint64_t total = feed_head->total.load(std::memory_order_acquire);
-                if (total != ~0ull && nbatches == ~0ull) { nbatches = total; nrounds = rounds_of(nbatches); }
-                if (nrounds != ~0ull && q >= nrounds) { q--; continue; }     // the stream ended before this round: drain (the loop's header takes over)
-                has[(size_t)l] = slot != nullptr;
-                if (slot) { src = feed_mem + (b % nslots) * slot_bytes; got = (size_t)slot->nbytes; }
-            } else {
-                has[(size_t)l] = b < nbatches;
-                if (has[(size_t)l]) {
-                    const size_t lo = (size_t)b * batch_bytes;
-                    got = std::min(batch_bytes, size - std::min(size, lo));
-                    src = map + lo - (b ? MODES_CARRY_BYTES : 0);
-                }
-            }
+    // ---- the three stages of a round, and the order they run in ----
+    // submit(q): this rank's batch of round q -> pinned buffer -> H2D + kernels.  exchange(q): lengths and lists to rank 0 (or, resolving on
+    // the ranks, the whole of rr_round).  resolve(q): rank 0 resolves and prints what arrived.  With input at hand the stages run one round
+    // apart - submit(q), exchange(q - 1), resolve(q - 2): the kernels of a round run under the exchange of the round before, the transfers
+    // under the resolve of the round before that.  When the NEXT batch is not there yet (a pipe at the radio's pace) nothing is held back for
+    // it: the rounds in flight are exchanged, resolved and printed while the rank waits (output lagged two batch times).  The order
+    // of the collective calls is the same on every rank either way - round after round -, only when a rank issues them differs.
+    enum class Input { Ready, NotYet, Ended, Failed };
+    auto input_state = [&](uint64_t q) -> Input {                            // of round q, without waiting
+        if (nrounds != ~0ull && q >= nrounds) return Input::Ended;
+        if (!feed) return Input::Ready;                                      // (a rank without a batch in the last round still takes part in it)
+        const uint64_t b = q * (uint64_t)N + (uint64_t)rank;
+        if (feed_slots[b % nslots].seq.load(std::memory_order_acquire) == b + 1) return Input::Ready;
+        const uint64_t total = feed_head->total.load(std::memory_order_acquire);
+        if (total != ~0ull) {
+            if (nbatches == ~0ull) { nbatches = total; nrounds = rounds_of(nbatches); }
+            if (q >= nrounds) return Input::Ended;
+            if (b >= total) return Input::Ready;                             // the round exists, this rank has no batch in it
+        }
+        return feed_head->failed.load() ? Input::Failed : Input::NotYet;
+    };
+    auto submit = [&](uint64_t q) {
+        const int l = (int)(q % (uint64_t)depth);
+        const uint64_t b = q * (uint64_t)N + (uint64_t)rank;
+        const uint8_t *src = nullptr;
+        size_t got = 0;
+        uint64_t first_block = b * opt.batch_blocks;
+        bool last = false;
+        FeedSlot *slot = nullptr;
+        if (feed) {
+            slot = &feed_slots[b % nslots];
+            if (slot->seq.load(std::memory_order_acquire) != b + 1) slot = nullptr;          // (input_state said Ready: no batch of this rank in the round)
+            has[(size_t)l] = slot != nullptr;
+            if (slot) { src = feed_mem + (b % nslots) * slot_bytes; got = (size_t)slot->nbytes; first_block = slot->first_block; last = slot->eof != 0; }
+        } else {
+            has[(size_t)l] = b < nbatches;
             if (has[(size_t)l]) {
                 const size_t lo = (size_t)b * batch_bytes;
-                const size_t carry = b ? MODES_CARRY_BYTES : 0;
-                const size_t n = carry + got, sl = (n / (size_t)pool.size() + 4095) & ~(size_t)4095;
-                uint8_t *dst = lanes[(size_t)l].buf;
-                pool.run(pool.size(), [&](int t) { const size_t o = (size_t)t * sl; if (o < n) memcpy(dst + o, src + o, std::min(sl, n - o)); });
-                if (slot) slot->seq.store(0, std::memory_order_release);     // the reader may fill it again
-                uint64_t nblocks = got / MODES_DATA_LEN;
-                if (got < batch_bytes) nblocks += 1;                         // the EOF buffer
-                if (modes_gpu_submit_host(lanes[(size_t)l].gpu, dst, n, (uint64_t)lo - carry, b * opt.batch_blocks, nblocks) != MODES_OK)
-                    fail_rank("GPU demodulation failed", modes_gpu_last_error(lanes[(size_t)l].gpu));
+                got = std::min(batch_bytes, size - std::min(size, lo));
+                src = map + lo - (b ? MODES_CARRY_BYTES : 0);
+                last = got < batch_bytes;
             }
         }
+        if (!has[(size_t)l]) return;
+        const size_t carry = b ? MODES_CARRY_BYTES : 0;
+        const size_t n = carry + got, sl = (n / (size_t)pool.size() + 4095) & ~(size_t)4095;
+        uint8_t *dst = lanes[(size_t)l].buf;
+        pool.run(pool.size(), [&](int t) { const size_t o = (size_t)t * sl; if (o < n) memcpy(dst + o, src + o, std::min(sl, n - o)); });
+        if (slot) slot->seq.store(0, std::memory_order_release);             // the reader may fill it again
+        const uint64_t nblocks = got / MODES_DATA_LEN + (last ? 1 : 0);      // (+ the EOF buffer)
+        if (modes_gpu_submit_host(lanes[(size_t)l].gpu, dst, n, first_block * (uint64_t)MODES_DATA_LEN - carry, first_block, nblocks) != MODES_OK)
+            fail_rank("GPU demodulation failed", modes_gpu_last_error(lanes[(size_t)l].gpu));
+    };
+    auto exchange = [&](uint64_t q) {                                        // kernels done -> lengths -> transfers
+        const int l = (int)(q % (uint64_t)depth);
         if (rr) {
-            if (q >= 1 && q - 1 < nrounds && !rc && !rr_round(q - 1, has[(size_t)((q - 1) % (uint64_t)depth)] != 0) && !rc) fail_rank("resolve", "another rank failed");
-            continue;
+            if (!rr_round(q, has[(size_t)l] != 0) && !rc) fail_rank("resolve", "another rank failed");
+            return;
         }
-        if (q >= 1 && q - 1 < nrounds && !rc) {                              // round q - 1: kernels done -> lengths -> transfers
-            const int l = (int)((q - 1) % (uint64_t)depth);
-            if (has[(size_t)l]) {
-                modes_gpu_result res{};
-                // (a list that outgrew the buffers still goes through the length exchange: every rank then fails together)
-                const int frc = modes_gpu_fetch_device(lanes[(size_t)l].gpu, &res);
-                if (frc != MODES_OK && frc != MODES_ERR_OVERFLOW) fail_rank("GPU demodulation failed", modes_gpu_last_error(lanes[(size_t)l].gpu));
-                else if (opt.stats && G.set_candidates(g, (uint32_t)l, res.candidates, res.n_candidates) != MODES_OK) fail_rank("gather", G.last_error(g));
-            } else if (G.set_empty(g, (uint32_t)l) != MODES_OK) fail_rank("gather", G.last_error(g));
-            if (!rc && (G.counts(g, (uint32_t)l) != MODES_OK || G.records(g, (uint32_t)l) != MODES_OK)) fail_rank("gather", G.last_error(g));
+        if (has[(size_t)l]) {
+            modes_gpu_result res{};
+            // (a list that outgrew the buffers still goes through the length exchange: every rank then fails together)
+            const int frc = modes_gpu_fetch_device(lanes[(size_t)l].gpu, &res);
+            if (frc != MODES_OK && frc != MODES_ERR_OVERFLOW) fail_rank("GPU demodulation failed", modes_gpu_last_error(lanes[(size_t)l].gpu));
+            else if (opt.stats && G.set_candidates(g, (uint32_t)l, res.candidates, res.n_candidates) != MODES_OK) fail_rank("gather", G.last_error(g));
+        } else if (G.set_empty(g, (uint32_t)l) != MODES_OK) fail_rank("gather", G.last_error(g));
+        if (!rc && (G.counts(g, (uint32_t)l) != MODES_OK || G.records(g, (uint32_t)l) != MODES_OK)) fail_rank("gather", G.last_error(g));
+    };
+    auto resolve = [&](uint64_t q) {                                         // rank 0 resolves what arrived
+        if (rr) return;                                                      // (rr_round has printed the round)
+        const int l = (int)(q % (uint64_t)depth);
+        const modes_record *recs = nullptr;
+        uint64_t nrec = 0;
+        if (G.wait(g, (uint32_t)l, &recs, &nrec, nullptr) != MODES_OK) { fail_rank("gather", G.last_error(g)); return; }
+        if (rank != 0) return;
+        if (feed) modes_host_set_time(host, (int64_t)time(nullptr));       // a live stream: the whitelist's 60 s run on the wall clock (dump1090.c:913,924)
+        const uint64_t *cands = nullptr;
+        uint64_t ncand = 0;
+        if (opt.stats && G.candidates(g, (uint32_t)l, &cands, &ncand) != MODES_OK) { fail_rank("gather", G.last_error(g)); return; }
+        if (raw_fast) {
+            const uint64_t cap = nrec * 62 + 64;
+            if (rawbuf.size() < cap) rawbuf.resize(cap);
+            uint64_t nb = 0;
+            n_messages_out += modes_host_resolve_raw_mt(host, recs, nrec, rawbuf.data(), rawbuf.size(), &nb, opt.resolve_threads);
+            sink.out.assign(rawbuf.data(), (size_t)nb);
+        } else
+            n_messages_out += modes_host_resolve(host, recs, nrec, cands, ncand, on_message, &sink);
+        if (!sink.out.empty()) {
+            fwrite(sink.out.data(), 1, sink.out.size(), out);
+            fflush(out);
+            sink.out.clear();
         }
-        if (q >= 2 && !rc) {                                                 // round q - 2: rank 0 resolves what arrived
-            const int l = (int)((q - 2) % (uint64_t)depth);
-            const modes_record *recs = nullptr;
-            uint64_t nrec = 0;
-            if (G.wait(g, (uint32_t)l, &recs, &nrec, nullptr) != MODES_OK) { fail_rank("gather", G.last_error(g)); break; }
-            if (rank != 0) continue;
-            if (feed) modes_host_set_time(host, (int64_t)time(nullptr));       // a live stream: the whitelist's 60 s run on the wall clock (dump1090.c:913,924)
-            const uint64_t *cands = nullptr;
-            uint64_t ncand = 0;
-            if (opt.stats && G.candidates(g, (uint32_t)l, &cands, &ncand) != MODES_OK) { fail_rank("gather", G.last_error(g)); break; }
-            if (raw_fast) {
-                const uint64_t cap = nrec * 62 + 64;
-                if (rawbuf.size() < cap) rawbuf.resize(cap);
-                uint64_t nb = 0;
-                n_messages_out += modes_host_resolve_raw_mt(host, recs, nrec, rawbuf.data(), rawbuf.size(), &nb, opt.resolve_threads);
-                sink.out.assign(rawbuf.data(), (size_t)nb);
-            } else
-                n_messages_out += modes_host_resolve(host, recs, nrec, cands, ncand, on_message, &sink);
-            if (!sink.out.empty()) {
-                fwrite(sink.out.data(), 1, sink.out.size(), out);
-                fflush(out);
-                sink.out.clear();
-            }
+    };
+    uint64_t ns = 0, nx = 0, nr = 0;                                         // next round to submit / exchange / resolve
+    for (int idle_spins = 0; !rc;) {
+        bool did = false;
+        Input in = input_state(ns);
+        if (in == Input::Failed) { fail_rank("input", "the reader failed"); break; }
+        if (in == Input::Ready && ns - nr < (uint64_t)depth) {               // (the lane of round ns is free once round ns - depth is resolved)
+            submit(ns++);
+            did = true;
+            if (rc) break;
+            in = input_state(ns);
         }
+        // the next batch is at hand: stay one round behind it (its kernels cover this exchange); it is not: nothing waits for it
+        const bool at_hand = in == Input::Ready && ns - nr < (uint64_t)depth;
+        if (nx < (at_hand && ns ? ns - 1 : ns)) { exchange(nx++); did = true; if (rc) break; }
+        if (nr < (at_hand && nx ? nx - 1 : nx)) { resolve(nr++); did = true; if (rc) break; }
+        if (in == Input::Ended && nr == ns) break;
+        if (did) { idle_spins = 0; continue; }
+        if (idle_spins < 100000) idle_spins++;
+        usleep(idle_spins < 200 ? 50 : 1000);                                // a live pipe: a batch interval is tens of milliseconds
     }
     const double t_end = now_s();
     if (feed && rc) feed_head->failed.store(1);                              // (the reader and the other ranks stop waiting for slots)
@@ -859,6 +950,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--gather-records") && more) opt.gather_cap = (uint32_t)strtoul(argv[++j], nullptr, 10);
         else if (!strcmp(a, "--gather-candidates") && more) opt.gather_cands = (uint32_t)strtoul(argv[++j], nullptr, 10);
         else if (!strcmp(a, "--batch-blocks") && more) opt.batch_blocks = strtoull(argv[++j], nullptr, 10);
+        else if (!strcmp(a, "--flush-ms") && more) opt.flush_ms = std::max(0, atoi(argv[++j]));
         else if (!strcmp(a, "--depth") && more) opt.depth = std::max(1, atoi(argv[++j]));
         else if (!strcmp(a, "--read-threads") && more) opt.read_threads = std::max(1, atoi(argv[++j]));
         else if (!strcmp(a, "--no-mmap")) opt.use_mmap = false;
@@ -1059,6 +1151,15 @@ int main(int argc, char **argv) {
     uint8_t carry_bytes[MODES_CARRY_BYTES];
     bool eof = false;
     int rc = 0;
+    // a pipe is served at the pace it delivers (read_paced): batches of whole buffers, the bytes read beyond the last whole one wait here
+    const bool paced = !seekable && lseek(fd, 0, SEEK_CUR) == (off_t)-1;
+    std::vector<uint8_t> pend;
+    if (paced) {
+        pend.reserve(MODES_DATA_LEN);
+#ifdef F_SETPIPE_SZ
+        (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);                                  // (a FIFO's default 64 KiB is 16 wake-ups per buffer)
+#endif
+    }
     for (uint64_t b = 0; !eof; b++) {
         {   // the lane of batch b is free once batch b - nlanes has been resolved
             std::unique_lock<std::mutex> g(m);
@@ -1071,8 +1172,20 @@ int main(int argc, char **argv) {
         size_t got = 0;
         uint8_t *dst = ln.buf + carry;
         const off_t pos_before = file_pos;
-        const bool ok = seekable ? read_parallel(pool, fd, map, map_len, &file_pos, dst, batch_bytes, &got)
-                                 : read_full(fd, dst, batch_bytes, &got);
+        bool ok, ended = false;
+        if (paced) {
+            if (!pend.empty()) memcpy(dst, pend.data(), pend.size());
+            size_t n = 0;
+            ok = read_paced(fd, dst, pend.size(), batch_bytes, opt.flush_ms * 1e-3, &n, &ended);
+            pend.clear();
+            got = n;
+            if (ok && !ended && n < batch_bytes) {                           // the deadline: whole buffers go, the rest waits for the next batch
+                got = n - n % MODES_DATA_LEN;
+                pend.assign(dst + got, dst + n);
+            }
+        } else
+            ok = seekable ? read_parallel(pool, fd, map, map_len, &file_pos, dst, batch_bytes, &got)
+                          : read_full(fd, dst, batch_bytes, &got);
         if (!ok) { perror("read"); rc = 1; break; }
         // The batch has been copied out of the mapping and is never looked at again: hand its pages back now, on a thread of its
         // own, instead of leaving 2 M page-table entries of an 8 GiB file to the exit of the process (~0.1 s there, and nothing
@@ -1097,7 +1210,7 @@ int main(int argc, char **argv) {
         // The reader publishes one buffer per full 262144 bytes and one more at EOF
         // (dump1090.c:484-510): a short batch ends the stream with floor(got/262144)+1 buffers.
         uint64_t nblocks = got / MODES_DATA_LEN;
-        if (got < batch_bytes) { eof = true; nblocks += 1; }
+        if (paced ? ended : got < batch_bytes) { eof = true; nblocks += 1; }
         const uint64_t byte0 = first_block * (uint64_t)MODES_DATA_LEN - carry;
         if (modes_gpu_submit_host(ln.gpu, ln.buf, carry + got, byte0, first_block, nblocks) != MODES_OK) {
             fprintf(stderr, "GPU demodulation failed: %s\n", modes_gpu_last_error(ln.gpu));

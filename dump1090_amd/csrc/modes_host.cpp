@@ -7,6 +7,7 @@
 
 #include "../../include/modes_host.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -728,6 +729,7 @@ struct Piece {
     uint32_t guess_addr[kIcaoSlots];
     bool guess_set[kIcaoSlots];
     std::atomic<int> guessed{0};
+    double t_begin = 0, t_guessed = 0, t_started = 0, t_done = 0;   // MODES_HOST_MT_DEBUG: when the piece's worker got going, ...
     ~Piece() { free(own); }
     bool own_text(uint64_t need) {
         if (own_cap < need) {
@@ -869,8 +871,10 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
     start.lean = false;
     pool.run(P, [&](size_t t) {
         Piece &p = *pieces[t];
+        if (dbg) p.t_begin = now();
         guess_piece(p, start.cfg);
         p.guessed.store(1, std::memory_order_release);
+        if (dbg) p.t_guessed = now();
         p.host = start;
         for (size_t k = 0; k < t; k++) {
             const Piece &q = *pieces[k];
@@ -879,7 +883,9 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
             for (uint32_t sl = 0; sl < kIcaoSlots; sl++)
                 if (q.guess_set[sl]) { p.host.icao[sl] = q.guess_addr[sl]; p.host.icao_seen[sl] = start.now_s; }
         }
+        if (dbg) p.t_started = now();
         run_piece(p);
+        if (dbg) p.t_done = now();
     });
     const double t2 = now();
     int reruns = 0;
@@ -948,9 +954,17 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
     if (out) pool.run(P, [&](size_t t) { if (take[t] && pieces[t]->text != out + at[t]) memcpy(out + at[t], pieces[t]->text, (size_t)take[t]); });
     if (out && stored < cap) out[stored] = 0;
     if (nbytes) *nbytes = total;
-    if (dbg)
-        fprintf(stderr, "resolve_raw_mt: %zu pieces in %u segment(s), %llu records: guess + speculative %.2f ms, confirm %.2f ms (%d re-run), merge %.2f ms\n",
-                P, nsegs, (unsigned long long)nrecs, t2 - t0, t3 - t2, reruns, now() - t3);
+    if (dbg) {
+        double wake = 0, guess = 0, wait = 0, run = 0;
+        for (size_t t = 0; t < P; t++) {
+            const Piece &p = *pieces[t];
+            wake = std::max(wake, p.t_begin - t0); guess = std::max(guess, p.t_guessed - p.t_begin);
+            wait = std::max(wait, p.t_started - p.t_guessed); run = std::max(run, p.t_done - p.t_started);
+        }
+        fprintf(stderr, "resolve_raw_mt: %zu pieces in %u segment(s), %llu records: guess + speculative %.3f ms (slowest piece: woke after %.3f, guess %.3f, "
+                        "start state %.3f, resolve %.3f), confirm %.3f ms (%d re-run), merge %.3f ms\n",
+                P, nsegs, (unsigned long long)nrecs, t2 - t0, wake, guess, wait, run, t3 - t2, reruns, now() - t3);
+    }
     return msgs;
 }
 

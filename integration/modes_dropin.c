@@ -17,7 +17,9 @@
  * modesGpuReadFile() below, which hands over K x 262,144 bytes per round trip through data_mutex / data_cond instead of one
  * buffer (K = $MODES_DROPIN_BLOCKS, default 512 = 128 MiB; 1 with --interactive, which replays at the radio's pace).  The
  * library does the framing of a multi-buffer call itself (modes_gpu_submit_host(..., nblocks)), so modesGpuDemod() only passes
- * the count on; two pinned buffers and two GPU contexts alternate, so that the reader fills one buffer while the GPU works on
+ * the count on (input that cannot seek - stdin, a FIFO - is handed over at the pace it delivers: whole buffers, when the batch is
+ * full or $MODES_DROPIN_FLUSH_MS = 66 ms after it began, so that a radio's stream through a pipe is printed within two buffers, as the
+ * reference does); two pinned buffers and two GPU contexts alternate, so that the reader fills one buffer while the GPU works on
  * the other and the main thread resolves the batch before; the resolve runs once per hand-off.  Live RTL-SDR input
  * (rtlsdrCallback, dump1090.c:442-456) is untouched and keeps one buffer per call.  The main loop (:2969-2990) is the same
  * four edits; the reference's EOF race (its loop usually drops the last buffer) does not exist on this path -
@@ -26,6 +28,7 @@
 #define MODES_HOST_NO_MESSAGE_STRUCT        /* dump1090.c:211-260 is the definition in this translation unit */
 #include "modes_gfx950.h"
 #include "modes_host.h"
+#include <poll.h>
 #include <stddef.h>
 #include <time.h>
 
@@ -177,10 +180,15 @@ static void modesGpuReadFile(void) {
     size_t carry = 0;
     uint64_t first_block = 0;
     off_t pos = 0;
-    int w = 0, last = 0, seekable;
+    int w = 0, last = 0, seekable, paced;
+    static unsigned char pendbuf[MODES_DATA_LEN];                         /* read beyond the last whole buffer of a paced hand-off */
+    size_t pend = 0;
+    double dropin_flush_s = 0.066;
     dropin_setup_batched();
     dropin_t_first_read = dropin_now();
     seekable = Modes.fd != STDIN_FILENO && !Modes.loop && lseek(Modes.fd, 0, SEEK_CUR) != (off_t)-1;
+    paced = lseek(Modes.fd, 0, SEEK_CUR) == (off_t)-1;                    /* a pipe, a FIFO, a socket */
+    if (getenv("MODES_DROPIN_FLUSH_MS")) dropin_flush_s = atof(getenv("MODES_DROPIN_FLUSH_MS")) * 1e-3;
     pthread_mutex_lock(&Modes.data_mutex);
     while (!last) {
         const size_t batch = dropin_k * (size_t)MODES_DATA_LEN;
@@ -200,6 +208,42 @@ static void modesGpuReadFile(void) {
         if (seekable) {
             got = dropin_read_parallel(Modes.fd, pos, p + carry, batch);
             pos += (off_t)got;
+            last = got < batch;
+        } else if (paced) {
+            /* Input that cannot seek (stdin, a FIFO) is handed over at the pace it delivers - the reference's reader publishes every
+             * buffer as it fills (dump1090.c:460-512) and a radio at 2 Msps fills one in 65.5 ms: waiting for K = 512 of them would be
+             * 33 s of silence.  So the hand-off is what HAS arrived - whole buffers - when the batch is full or $MODES_DROPIN_FLUSH_MS
+             * (default 66) after it began; until one whole buffer is there it waits.  The bytes read beyond the last whole buffer open
+             * the next hand-off.  A fast pipe (cat file |) still fills its batches. */
+            const double t0 = dropin_now();
+            int ended = 0;
+            if (pend) memcpy(p + carry, pendbuf, pend);
+            got = pend;
+            pend = 0;
+            while (got < batch) {                                             /* (under data_mutex, like the reference's read, dump1090.c:484) */
+                struct pollfd pf;
+                int timeout = -1, pr;
+                ssize_t n;
+                if (got >= MODES_DATA_LEN) {
+                    const double left = t0 + dropin_flush_s - dropin_now();
+                    if (left <= 0) break;
+                    timeout = (int)(left * 1e3) + 1;
+                }
+                pf.fd = Modes.fd; pf.events = POLLIN; pf.revents = 0;
+                pr = poll(&pf, 1, timeout);
+                if (pr < 0 && errno == EINTR) continue;
+                if (pr <= 0) break;
+                n = read(Modes.fd, p + carry + got, batch - got);
+                if (n < 0 && (errno == EINTR || errno == EAGAIN)) continue;
+                if (n <= 0) { ended = 1; break; }
+                got += (size_t)n;
+            }
+            if (!ended && got < batch) {                                      /* the deadline: whole buffers go, the rest waits */
+                pend = got % MODES_DATA_LEN;
+                got -= pend;
+                memcpy(pendbuf, p + carry + got, pend);
+            }
+            last = ended;
         } else {
             while (got < batch) {
                 ssize_t n = read(Modes.fd, p + carry + got, batch - got);
@@ -210,8 +254,8 @@ static void modesGpuReadFile(void) {
                 if (n <= 0) break;
                 got += (size_t)n;
             }
+            last = got < batch;
         }
-        last = got < batch;
         dropin_bytes += got;
         dropin_hand.which = w;
         dropin_hand.carry = carry;
@@ -222,7 +266,7 @@ static void modesGpuReadFile(void) {
         if (!last) {
             memcpy(tail, p + carry + got - MODES_CARRY_BYTES, MODES_CARRY_BYTES);
             carry = MODES_CARRY_BYTES;
-            first_block += dropin_k;
+            first_block += got / MODES_DATA_LEN;
             w ^= 1;
         }
         Modes.data_ready = 1;

@@ -209,6 +209,50 @@ def test_batched_dropin_on_a_generated_stream_equals_the_cxx_host(tmp_path):
         assert got == want, k
 
 
+def _paced(cmd, path, ms=150, repeat=4, env=None):
+    """tools/paced_pipe.py: `path` (x repeat) into cmd's stdin one 256 KiB buffer every `ms` milliseconds -> its JSON report."""
+    import json
+    p = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "paced_pipe.py"), str(ms), path, "--repeat", str(repeat), "--"] + cmd,
+                       capture_output=True, timeout=300, env=env)
+    assert p.returncode == 0, (p.stdout[-400:], p.stderr[-600:])
+    return json.loads(p.stdout)
+
+
+def test_batched_reader_serves_a_pipe_at_the_pace_it_delivers(stub_hosted, tmp_path):
+    """The batched patch with its default K = 512 on a pipe that delivers one buffer every 150 ms: the hand-off is what
+    has arrived - whole buffers - 66 ms after the batch began, so the first line is printed long before the writer is done; the bytes
+    are the file run's (the capture four times over), paced or not."""
+    raw = os.path.join(ROOT, "tests", "golden", "modes1.bin")
+    four = tmp_path / "four.bin"
+    four.write_bytes(open(raw, "rb").read() * 4)
+    want = run_md5(stub_hosted["batched"], ["--ifile", str(four), "--raw"])
+    d = _paced([stub_hosted["batched"], "--ifile", "-", "--raw"], raw)
+    assert (d["lines"], d["md5"]) == want and d["first_output_s"] is not None and d["first_output_s"] < d["writer_done_s"] - 0.2, d
+    with open(four, "rb") as f:
+        assert run_md5(stub_hosted["batched"], ["--ifile", "-", "--raw"], dict(os.environ, MODES_DROPIN_BLOCKS="3"), stdin=f) == want
+    d = _paced([stub_hosted["batched_tsan"], "--ifile", "-", "--raw"], raw, ms=40, repeat=2, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:report_thread_leaks=0"))
+    assert d["status"] == 0 and d["lines"] == want[0] // 2
+
+
+@pytest.mark.gpu
+def test_paced_pipe_through_both_hosts_on_the_gpu(tmp_path):
+    """GPU box: the C++ host and the batched drop-in on a pipe at the radio's cadence (one buffer per 66 ms) with their default batch
+    sizes - first output before the writer is done, stdout byte-identical to the file run; an unpaced pipe too."""
+    raw = os.path.join(ROOT, "tests", "golden", "modes1.bin")
+    four = tmp_path / "four.bin"
+    four.write_bytes(open(raw, "rb").read() * 4)
+    exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
+    want = run_md5(exe, ["--ifile", str(four), "--raw"])
+    assert want[0] > 1000
+    for cmd in ([exe, "--ifile", "-", "--raw"], [BATCHED, "--ifile", "-", "--raw"], [exe, "--ifile", "-", "--raw", "--ranks", "1", "--resolve-on-ranks"]):
+        d = _paced(cmd, raw, ms=66)
+        assert (d["lines"], d["md5"]) == want, (cmd, d)
+        # (the process starts the HIP runtime while the first buffers arrive: ~0.2 s; the writer needs 0.7 s)
+        assert d["first_output_s"] is not None and d["first_output_s"] < d["writer_done_s"] - 0.1, (cmd, d)
+        with open(four, "rb") as f:
+            assert run_md5(cmd[0], cmd[1:], stdin=f) == want, cmd
+
+
 def _first_bytes(cmd, n, env=None):
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
     got = b""

@@ -454,3 +454,19 @@ def test_c_host_loop_replays_the_file_like_the_reference():
     assert b"first lap = the plain listing" in p.stdout and b"--clean-exit: md5 4a81758c8bec5e45ffa8541c5622938a" in p.stdout
     if os.path.exists(os.path.join(root, "oracle", "_ref", "dump1090_ref")):
         assert b"--loop == oracle/_ref/dump1090_ref --loop" in p.stdout
+
+
+def test_c_host_serves_a_pipe_at_the_pace_it_delivers():
+    """tools/sanitize_host.sh pipe-host (dump1090.c:460-512, :2969-2990: the reference prints a buffer's messages
+    within that buffer): the capture written one 256 KiB buffer every 150 ms into `dump1090_amd --ifile -` with the DEFAULT batch of
+    512 buffers - the first line is out long before the writer has finished (one process, --ranks 2 in both resolve modes), the listing
+    and --stats are the file run's, and an unpaced pipe prints the same bytes for any --flush-ms."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS")}
+    p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "pipe-host"], capture_output=True, timeout=600, env=env)
+    assert p.returncode == 0 and b"FAIL" not in p.stdout, (p.stdout[-1200:], p.stderr[-800:])
+    assert p.stdout.count(b"paced pipe, ") == 4 and b"unpaced pipe (cat |)" in p.stdout

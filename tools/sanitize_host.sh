@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs the CPU tests of the host library and of the header-only device arithmetic against sanitizer builds:
 #   tools/sanitize_host.sh                 UBSan, then ASan, then TSan
-#   tools/sanitize_host.sh ubsan|asan|tsan|tsan-host|ranks-host|loop-host one of them
+#   tools/sanitize_host.sh ubsan|asan|tsan|tsan-host|ranks-host|loop-host|pipe-host one of them
 # tsan: the multi-threaded resolve (modes_host_resolve_raw_mt: worker pool, speculative pieces) in a C++ harness built
 # together with the host sources under -fsanitize=thread, on the records of the reference's capture.
 # (-fno-sanitize-recover / abort_on_error: any finding kills the test process).  The host library is built with
@@ -91,7 +91,7 @@ run_ranks_host() {
     D=/tmp/modes_ranks_host
     mkdir -p $D
     gcc -O1 -g -c -o $D/modes_oracle.o oracle/modes_oracle.c
-    g++ -O1 -g -std=c++17 -Iinclude -o $D/dump1090_amd_stub dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -Iinclude -o $D/dump1090_amd_stub dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
         dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp $D/modes_oracle.o -lpthread -lm -ldl -rdynamic
     g++ -O1 -g -std=c++17 -fPIC -shared -Iinclude -o $D/libmodes_gather.so tests/native/gather_stub.cpp -lpthread -lrt
     for n in 1 2 3; do for bb in 1 2 5; do
@@ -255,7 +255,7 @@ run_loop_host() {
     D=/tmp/modes_loop_host
     mkdir -p $D
     gcc -O1 -g -c -o $D/modes_oracle.o oracle/modes_oracle.c
-    g++ -O1 -g -std=c++17 -Iinclude -o $D/dump1090_amd_stub dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -Iinclude -o $D/dump1090_amd_stub dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
         dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp $D/modes_oracle.o -lpthread -lm -ldl -rdynamic
     python - <<'PY'
 import sys
@@ -297,12 +297,58 @@ PY
         echo "   --loop == oracle/_ref/dump1090_ref --loop over the same 2.5 laps"
     fi
 }
+# pipe-host: a pipe is served at the pace it delivers (main.cpp read_paced; dump1090.c:460-512, :2969-2990 print a buffer's messages
+# within that buffer): the reference's capture written one 256 KiB buffer every 150 ms into `dump1090_amd --ifile -` with the DEFAULT
+# batch size (512 buffers: a host that waits for a full batch prints nothing before the writer is done) - the first line must be out
+# before the writer has finished, the listing must be the file run's; the same through --ranks 2 (rank 0's reader deals the batches
+# out) in both resolve modes, and unpaced (cat |): full speed, same bytes.
+run_pipe_host() {
+    export MODES_RANKS_QUIET=1
+    echo "== pipe-host =="
+    D=/tmp/modes_pipe_host
+    mkdir -p $D
+    gcc -O1 -g -c -o $D/modes_oracle.o oracle/modes_oracle.c
+    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -Iinclude -o $D/dump1090_amd_stub dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+        dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp $D/modes_oracle.o -lpthread -lm -ldl -rdynamic
+    g++ -O1 -g -std=c++17 -fPIC -shared -Iinclude -o $D/libmodes_gather.so tests/native/gather_stub.cpp -lpthread -lrt
+    check() { what=$1; want=$2; shift 2
+        python tools/paced_pipe.py 150 tests/golden/modes1.bin --repeat 4 -- "$@" > $D/paced.json || { cat $D/paced.json; echo "   $what: the host failed"; exit 1; }
+        python - "$what" "$want" $D/paced.json <<'PY'
+import json, sys
+what, want, d = sys.argv[1], sys.argv[2], json.load(open(sys.argv[3]))
+ok = d["md5"] == want and d["first_output_s"] is not None and d["first_output_s"] < d["writer_done_s"] - 0.2
+print("   %s: first output after %.2f s, writer done after %.2f s (%d buffers, one per %g ms), %d lines, md5 %s%s" % (
+    what, d["first_output_s"] or -1, d["writer_done_s"], d["buffers"], d["ms_per_buffer"], d["lines"], d["md5"], "" if ok else "  <-- FAIL (want %s)" % want))
+sys.exit(0 if ok else 1)
+PY
+    }
+    python - <<'PY'
+import numpy as np
+one = np.fromfile("tests/golden/modes1.bin", dtype=np.uint8)
+np.tile(one, 4).tofile("/tmp/modes_pipe_host/four.bin")
+PY
+    want=$($D/dump1090_amd_stub --ifile $D/four.bin --raw | md5sum | cut -c1-32)
+    echo "   the file run (4 x the reference's capture): md5 $want"
+    check "paced pipe, one process" $want $D/dump1090_amd_stub --ifile - --raw
+    check "paced pipe, --ranks 2" $want $D/dump1090_amd_stub --ifile - --raw --ranks 2
+    check "paced pipe, --ranks 2 --resolve-on-ranks" $want $D/dump1090_amd_stub --ifile - --raw --ranks 2 --resolve-on-ranks
+    wants=$($D/dump1090_amd_stub --ifile $D/four.bin --stats | md5sum | cut -c1-32)
+    python tools/paced_pipe.py 20 tests/golden/modes1.bin --repeat 4 -- $D/dump1090_amd_stub --ifile - --stats > $D/paced.json
+    grep -q "\"md5\": \"$wants\"" $D/paced.json || { cat $D/paced.json; echo "   --stats through a paced pipe differs from the file run ($wants)"; exit 1; }
+    echo "   paced pipe, --stats: md5 $wants (the file run's)"
+    for fl in 0 5 66 1000; do
+        got=$(cat $D/four.bin | $D/dump1090_amd_stub --ifile - --raw --flush-ms $fl --batch-blocks 3 | md5sum | cut -c1-32)
+        [ "$got" = "$want" ] || { echo "   cat | --flush-ms $fl: $got, want $want"; exit 1; }
+    done
+    echo "   unpaced pipe (cat |), --flush-ms 0 / 5 / 66 / 1000, --batch-blocks 3: md5 $want"
+}
 case "${1:-all}" in
+    pipe-host) run_pipe_host ;;
     ubsan) run_one ubsan ;;
     asan)  run_one asan ;;
     tsan)  run_tsan ;;
     tsan-host) run_tsan_host ;;
     ranks-host) run_ranks_host ;;
     loop-host) run_loop_host ;;
-    *)     run_one ubsan; run_one asan; run_tsan; run_tsan_host; run_ranks_host; run_loop_host ;;
+    *)     run_one ubsan; run_one asan; run_tsan; run_tsan_host; run_ranks_host; run_loop_host; run_pipe_host ;;
 esac
