@@ -356,7 +356,21 @@ def host_cpus():
                 out["quota"] = round(q / p, 2)
         except (OSError, ValueError):
             pass
+    try:                                             # what the host library sizes its pools by (modes_host_cpu_budget)
+        from dump1090_amd import _native as N
+        out["budget"] = int(N.host_lib().modes_host_cpu_budget())
+    except Exception:                                # noqa: BLE001
+        out["budget"] = None
     return out
+
+
+def auto_resolve_threads(world, ranks_resolve):
+    """Threads of a rank's resolve when --resolve-threads is not given: what the process may really run at once - the smallest of
+    online CPUs, affinity and cgroup quota (modes_host_cpu_budget; round 5's min(32, cores / 4) asked a 16-CPU container for 32) - less
+    one per rank for the launching threads that poll for their kernels, shared out among the ranks when every rank resolves."""
+    from dump1090_amd import _native as N
+    spare = max(1, N.host_lib().modes_host_cpu_budget() - world)
+    return max(1, min(32, spare // world if ranks_resolve else spare))
 
 
 def visible_gpus():
@@ -405,6 +419,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of the headline leg, back to back behind one warm-up, each exactly --steps steps between a barrier + "
+                         "device sync on both sides: `value` / `ms_per_step` are the MEDIAN region, `value_min` / `value_max` and "
+                         "`ms_per_step_regions` say how far one region is from another (a 20-step region is 4 ms)")
     ap.add_argument("--workload", default="all", choices=("all", "noise", "frames", "lowsnr", "strong"),
                     help="all (default): every leg, the noise leg's numbers in the headline fields; one name: that leg only (a leg "
                          "other than noise then fills the headline fields)")
@@ -437,7 +455,7 @@ def parse_args(argv=None):
                          "kernel boundary); 1 = every call")
     ap.add_argument("--resolve-threads", type=int, default=0,
                     help="threads of rank 0's resolve (modes_host_resolve_raw_mt: exact, speculative pieces confirmed in order); "
-                         "0 = min(32, host cores / 4): rank 0 is the only rank that resolves")
+                         "0 = the process's CPU budget (affinity, cgroup quota) less one launching thread per rank, at most 32")
     ap.add_argument("--streams", type=int, default=2,
                     help="launch streams of the throughput region.  2 (default): the scan kernel of call i+1 does not queue behind the "
                          "demod / finalize kernels of call i.  Kernel durations are measured in a second timed region on ONE stream, "
@@ -547,7 +565,7 @@ def main():
         lo, hi = shard_byte_range(first_block, nblocks, total_bytes)
         return first_block, nblocks, lo, hi
 
-    def leg(iq, lo, calls, flags, steps, warm, cap_records, nstreams, timing, time_every=None):
+    def leg(iq, lo, calls, flags, steps, warm, cap_records, nstreams, timing, time_every=None, regions=1):
         """K timed steps over this rank's HBM-resident shard (dump1090_amd/pipeline.py).  timing: one call in --time-every
         carries HIP timing events around its kernels (one launch stream only: the times are then the kernels' own); without:
         no events at all - pure throughput."""
@@ -572,8 +590,8 @@ def main():
                          device_sync=lambda: torch.cuda.synchronize(dev), time_every=max(1, time_every or args.time_every),
                          # (root: rank 0 resolves every rank's records on up to 32 threads; ranks: every rank its own, all at the same
                          #  time - half the hardware threads shared out among them)
-                         resolve_threads=args.resolve_threads or max(1, min(32, (os.cpu_count() or 4) // (2 * world if ranks_resolve else 4))),
-                         gather=dist_on, resolve_on=args.resolve_on, ctl_group=ctl_group)
+                         resolve_threads=args.resolve_threads or auto_resolve_threads(world, ranks_resolve),
+                         gather=dist_on, resolve_on=args.resolve_on, ctl_group=ctl_group, regions=regions)
 
     def gathered(obj):
         """[obj of rank 0, of rank 1, ...] on rank 0 (None elsewhere)"""
@@ -678,12 +696,14 @@ def main():
         # (--streams 1: one region serves all three; its kernel times come from one call in --time-every.)
         noflags = dict(fix=False, aggressive=False)
         settle = args.settle + args.warmup
+        # R regions each (--regions): one region of 20 steps is 4 ms - a single sample; the line carries the median and the spread
+        R = max(1, args.regions)
         if args.streams <= 1:
-            noise = noise1 = noise_s1 = leg(iq_noise, lo, calls, noflags, args.steps, settle, 1 << 16, 1, True)
+            noise = noise1 = noise_s1 = leg(iq_noise, lo, calls, noflags, args.steps, settle, 1 << 16, 1, True, regions=R)
         else:
-            noise1 = leg(iq_noise, lo, calls, noflags, max(args.steps, 96), settle, 1 << 16, 1, True, time_every=4)
+            noise1 = leg(iq_noise, lo, calls, noflags, max(args.steps, 32 if R > 1 else 96), settle, 1 << 16, 1, True, time_every=4, regions=R)
             noise_s1 = leg(iq_noise, lo, calls, noflags, args.steps, settle, 1 << 16, 1, False)
-            noise = leg(iq_noise, lo, calls, noflags, args.steps, settle, 1 << 16, args.streams, False)
+            noise = leg(iq_noise, lo, calls, noflags, args.steps, settle, 1 << 16, args.streams, False, regions=R)
         for x in (noise, noise1, noise_s1):
             x.update(total=total, span=hi - lo, per_gpu=per_gpu)
         if not args.no_ceiling:
@@ -734,9 +754,9 @@ def main():
         if leg["scan_ms"] > 0:
             kind = name.split(":")[0].replace("BASELINE.json ", "")
             tkind = "lowsnr" if "configs[4]" in kind else "frames"
-            # (the committed counter passes ran the weak legs' launch sizes: none for the strong leg's 7.1 GiB calls - same kernels, same
-            #  stream statistics as `frames`, whose ratio of traffic to algorithmic bytes applies)
-            tr = leg_traffic(tkind) if scaling == "weak" else None
+            if scaling != "weak":
+                tkind = "strong"                                     # its own pass (tools/profile.sh <tag> strong): 7.1 GiB calls
+            tr = leg_traffic(tkind)
             per_launch = leg["call_bytes"]
             a_scan = per_launch / (leg["scan_ms"] * 1e-3) / 1e9
             a_step = leg["per_gpu"] / (d["ms_per_step"] * 1e-3) / 1e9
@@ -793,6 +813,7 @@ def main():
                      "frames_strong" if head_kind == "strong" else head_kind]["workload"]
     samples_per_step = head["total"] // 2                                     # the whole stream: every rank's shard
     value = samples_per_step * head_steps / head["elapsed"] / 1e6
+    region_s = head.get("elapsed_regions") or [head["elapsed"]]
     assert kern["timed_calls"] > 0 and kern["scan_ms"] > 0, "no call of the timed region carried timing events"
     achieved = kern["call_bytes"] / (kern["scan_ms"] * 1e-3) / 1e9             # this rank's launches: 2 B per sample
     traffic, traffic_note = measured_traffic(args.mib) if noise is not None else (None, "no PMC pass for this workload")
@@ -806,6 +827,13 @@ def main():
         "metric": "IQ Msamples/s demodulated", "value": round(value, 1), "unit": "Msamples/s",
         "n_gpus": world, "steps": head_steps, "warmup": args.warmup,
         "ms_per_step": round(head["elapsed"] / head_steps * 1e3, 4), "higher_is_better": True,
+        # `value` / `ms_per_step`: the MEDIAN of `regions` timed regions of exactly `steps` steps each (barrier + device sync on both
+        # sides of every one, max over the ranks per region), back to back behind one warm-up; the others are here
+        "regions": head.get("regions", 1),
+        "ms_per_step_regions": [round(e / head_steps * 1e3, 4) for e in region_s],
+        "value_min": round(samples_per_step * head_steps / max(region_s) / 1e6, 1),
+        "value_max": round(samples_per_step * head_steps / min(region_s) / 1e6, 1),
+        "value_spread_pct": round((max(region_s) - min(region_s)) / head["elapsed"] * 50, 2),      # +- half the range, in percent of the median
         "scaling": "strong" if head_kind == "strong" else "weak",
         "vs_baseline": None, "dtype": "u16", "data": "synthetic",
         "config": {"workload": head_name, "bytes_per_gpu": head["per_gpu"],
@@ -830,12 +858,16 @@ def main():
         "forwarded_per_step_rank0": int(head["last"].get("n_forwarded", 0)),
         "kernel_ms": {"scan": round(kern["scan_ms"], 4), "demod": round(kern["demod_ms"], 4), "order": round(kern["order_ms"], 4),
                       "scan_median": round(kern["scan_ms_median"], 4),
+                      # the scan kernel's average in each of the kernel-timing regions (`scan` is over all of them)
+                      "scan_regions": [round(v, 4) for v in kern.get("scan_ms_regions", []) if v > 0],
                       "timed_calls": kern["timed_calls"], "of_calls": kern.get("kernel_steps", kern["steps"]) * kern["calls_per_step"],
                       "measured_in": "a region of %d steps of the same workload on ONE launch stream, HIP events on one call in 4 (every "
                                      "kernel alone; averages over the timed calls)" % kern["steps"] if kern is not head
                       else kern.get("kernel_timing", "the timed region")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "frac_regions": [round(kern["call_bytes"] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for v in kern.get("scan_ms_regions", []) if v > 0],
+                     "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": "scan_kernel", "algorithmic_bytes_per_launch": int(kern["call_bytes"]),
                      # the same bytes over the WHOLE step (every kernel, the fetch and the resolve behind it: the clock `value` is on)
                      "achieved_step": round(head["per_gpu"] / (head["elapsed"] / head_steps) / 1e9, 1),
@@ -852,7 +884,7 @@ def main():
     if rank == 0 and world > 1:
         line["kernel_ms_per_rank"] = per_rank_kernels
     if rank == 0 and dist_on and noise is not None:
-        line["rccl"] = comm_facts(noise, noise["steps"])           # the headline leg's lists are empty: the count exchange only
+        line["rccl"] = comm_facts(noise, noise["steps"] * noise.get("regions", 1))     # the headline leg's lists are empty: the count exchange only
     if noise1 is not None and noise_s1 is not noise:
         line["one_launch_stream"] = {
             "Msamples_per_s": round(noise_s1["total"] // 2 * noise_s1["steps"] / noise_s1["elapsed"] / 1e6, 1),

@@ -77,6 +77,7 @@ struct Options {
     char **argv = nullptr;                 // for the one restart --ranks may need (the other IPC mode)
     uint32_t gather_cands = 0;             // --gather-candidates: preamble positions per rank and round (--stats); 0 = positions of a batch / 64
     bool resolve_on_ranks = false;         // --resolve-on-ranks: with --ranks and --raw, every rank resolves its own batch; only text reaches rank 0
+    bool read_threads_given = false, resolve_threads_given = false;   // (else: clamped to the process's CPU budget, modes_host_cpu_budget)
     int flush_ms = 66;                     // --flush-ms: a pipe's batch is submitted when it is full OR this long after it began, whole buffers
                                            // only (one 256 KiB buffer is 65.5 ms of air time at 2 Msps: the reference's own cadence)
 };
@@ -119,9 +120,10 @@ void show_help() {
         "                         full or <n> ms after it began (default: 66 = one buffer at 2 Msps).  A fast pipe still gets\n"
         "                         full batches; a live one is printed within two buffers, like the reference's own loop.\n"
         "--depth <n>              Batches in flight per device (default: 2; --ranks: at least 3).\n"
-        "--read-threads <n>       Threads reading a regular file (default: 16).\n"
+        "--read-threads <n>       Threads reading a regular file (default: 16, or what the CPU budget - affinity, cgroup quota - leaves).\n"
         "--no-mmap                Read a regular file with pread() instead of copying out of a mapping of it.\n"
-        "--resolve-threads <n>    With --raw: threads that resolve one batch (default: 8; the listing does not depend on it).\n"
+        "--resolve-threads <n>    With --raw: threads that resolve one batch (default: 8, or what the CPU budget leaves; the listing\n"
+        "                         does not depend on it).\n"
         "--timing                 Print a JSON line with the phase times to stderr.\n"
         "--clean-exit             Release every buffer, context and mapping before exiting (default: leave it to the process\n"
         "                         exit - unmapping 8 GiB and unpinning the buffers is a quarter of a short run's wall clock).\n"
@@ -952,9 +954,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--batch-blocks") && more) opt.batch_blocks = strtoull(argv[++j], nullptr, 10);
         else if (!strcmp(a, "--flush-ms") && more) opt.flush_ms = std::max(0, atoi(argv[++j]));
         else if (!strcmp(a, "--depth") && more) opt.depth = std::max(1, atoi(argv[++j]));
-        else if (!strcmp(a, "--read-threads") && more) opt.read_threads = std::max(1, atoi(argv[++j]));
+        else if (!strcmp(a, "--read-threads") && more) { opt.read_threads = std::max(1, atoi(argv[++j])); opt.read_threads_given = true; }
         else if (!strcmp(a, "--no-mmap")) opt.use_mmap = false;
-        else if (!strcmp(a, "--resolve-threads") && more) opt.resolve_threads = std::max(1, atoi(argv[++j]));
+        else if (!strcmp(a, "--resolve-threads") && more) { opt.resolve_threads = std::max(1, atoi(argv[++j])); opt.resolve_threads_given = true; }
         else if (!strcmp(a, "--help")) { show_help(); return 0; }
         else {
             fprintf(stderr, "Unknown or not enough arguments for option '%s'.\n\n", a);
@@ -967,6 +969,14 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (opt.batch_blocks == 0) opt.batch_blocks = 1;
+    {   // The pools' defaults are for a whole machine; a container may be held to a fraction of it (a 256-thread host behind a cgroup
+        // quota of 16: modes_host_cpu_budget).  Threads beyond the budget only take CPU time from each other - and from the threads
+        // that launch and poll: one per lane, plus the resolver.  Explicit --read-threads / --resolve-threads are honoured.
+        const int budget = modes_host_cpu_budget(), procs = opt.ranks > 0 ? opt.ranks : 1;
+        const int spare = std::max(1, budget / procs - 2);
+        if (!opt.read_threads_given) opt.read_threads = std::min(opt.read_threads, std::max(1, spare * (opt.ranks > 0 ? procs : 1)));   // (--ranks divides it by N again)
+        if (!opt.resolve_threads_given) opt.resolve_threads = std::min(opt.resolve_threads, spare);
+    }
     if (opt.ranks > 0) {
         // a regular file shorter than a batch: buffers of its size (see below) - every rank pins depth x batch, rank 0 also
         // depth x ranks x the gather capacity

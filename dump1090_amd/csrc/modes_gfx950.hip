@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <string>
 #include <thread>
@@ -2657,16 +2658,30 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
 // to time so that a faulted kernel is an error, not a hang.
 static int wait_results(modes_gpu *ctx) {
     volatile uint32_t *seq = &ctx->h_hdr->seq;
+    // The word is polled hot for the length of a short call (~0.2 ms: the 1 GiB step), then politely: a host has one such
+    // thread per context in flight and per rank, next to its resolver's pool, and a container's CPU quota counts a spinning
+    // thread like a working one (the leases hold a 256-thread host to 16 CPUs) - a call that takes milliseconds
+    // is waited for in 20 us naps, which cost it nothing it could notice.
+    using clk = std::chrono::steady_clock;
+    clk::time_point t0{};
+    uint32_t naps = 0;
     for (uint64_t spins = 1;; spins++) {
         if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == ctx->seq) break;
-        if ((spins & 0x3FFF) == 0) {
-            const hipError_t q = hipStreamQuery(ctx->tail_stream);
-            if (q == hipSuccess) {                                          // everything on the stream has run
-                if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == ctx->seq) break;
-                return fail(ctx, MODES_ERR_HIP, "the kernels of the call completed without publishing results");
+        if ((spins & 0x3FF) == 0) {
+            if (spins == 0x400) t0 = clk::now();
+            const double waited_us = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+            if (waited_us > 250.0) {
+                if ((++naps & 63) == 0) {                                   // every ~1.5 ms: has the stream failed, or ended without a word?
+                    const hipError_t q = hipStreamQuery(ctx->tail_stream);
+                    if (q == hipSuccess) {                                  // everything on the stream has run
+                        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == ctx->seq) break;
+                        return fail(ctx, MODES_ERR_HIP, "the kernels of the call completed without publishing results");
+                    }
+                    if (q != hipErrorNotReady) return fail(ctx, MODES_ERR_HIP, "while waiting for results: %s", hipGetErrorString(q));
+                }
+                struct timespec nap = {0, 20000};
+                nanosleep(&nap, nullptr);
             }
-            if (q != hipErrorNotReady) return fail(ctx, MODES_ERR_HIP, "while waiting for results: %s", hipGetErrorString(q));
-            if (spins > (1u << 20)) std::this_thread::yield();              // a long call: stop hogging the core
         }
     }
     if (ctx->done_recorded) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done));

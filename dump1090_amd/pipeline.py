@@ -184,7 +184,7 @@ def split_calls(first_block, nblocks, ncalls, lo, total_bytes):
 
 def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, rank=0, dist=None, coll_device=None,
               cap_records=1 << 16, streams=(None,), device_sync=lambda: None, time_every=8, resolve_threads=1,
-              gather=None, oplog=None, lag=None, resolve_on="root", ctl_group=None):
+              gather=None, oplog=None, lag=None, resolve_on="root", ctl_group=None, regions=1):
     """`warm` untimed + `steps` timed steps of the hot path over this rank's shard `iq` (stream bytes from `lo`;
     a CUDA uint8 tensor - anything sliceable that make_demod()'s detect accepts); a step is the sequence `calls`
     of GPU calls (split_calls).  `depth` contexts (make_demod() each) are used in rotation, so that the GPU always
@@ -201,6 +201,11 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
 
     Kernel times cost idle GPU time (events around the kernels: ~9 us per boundary), so only one call in `time_every`
     carries them (modes_gpu_set_timing); the averages returned are over those calls of the timed steps.
+
+    regions > 1: the timed part is `regions` regions of `steps` steps each, back to back behind ONE warm-up, every one of them
+    bracketed by the flush + barrier + device sync of a single region; "elapsed" is then the MEDIAN region (max over the ranks
+    per region first), "elapsed_regions" has them all - one region of 20 steps is 4 ms, a sample of a distribution whose spread
+    is larger than a round's gain.  Per-step figures are averages over all regions' steps.
 
     gather: exchange the record lists through RecordGather (default: when world > 1; True with world == 1 runs the whole
     N > 1 code path - device output buffers, count all_gather, transfers - on a single rank, which is how the RCCL calls
@@ -274,6 +279,10 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
             device_sync()
 
     scan_ms, demod_ms, order_ms = [], [], []
+    scan_region = []                                                         # the region each timed call's sample belongs to
+    region_elapsed = []
+    cur_region = [0]
+    regions = max(1, int(regions))
     last = {}
     host = dict(wait_kernels=0.0, queue_counts=0.0, queue_records=0.0, wait_records=0.0, detect=0.0, wait_free=0.0,
                 fetch=0.0)                                                   # host seconds by phase
@@ -283,6 +292,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         last.update({k: v for k, v in info.items() if not k.endswith("_ms")})
         if timed and info.get("scan_ms", 0.0) > 0.0:                        # a call that carried timing events
             scan_ms.append(info["scan_ms"])
+            scan_region.append(cur_region[0])
             demod_ms.append(info["demod_ms"])
             order_ms.append(info["order_ms"])
 
@@ -374,7 +384,20 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     ncall = 0
     first_timed_call = warm * len(calls)
     timed_phase = (min(time_every, steps * len(calls)) - 1) % time_every
-    for step in range(warm + steps):
+    t0_region = None
+    for step in range(warm + regions * steps):
+        if step > warm and (step - warm) % steps == 0:          # a region ends here, the next one begins: the same bracket as at the very end
+            for k in list(order):
+                advance(k, 3)
+            for e in free:
+                e.wait()
+            if resolver is not None:
+                resolver.drain()
+            sync_all()
+            t_now = time.perf_counter()
+            region_elapsed.append(t_now - t0_region)
+            t0_region = t_now
+            cur_region[0] += 1
         if step == warm:
             for k in list(order):
                 advance(k, 3)
@@ -388,7 +411,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                 rr0 = dict(steps=rr.steps, rounds=rr.rounds, reruns=rr.reruns, p2p_ops=rr.p2p_ops, bytes=rr.bytes_moved, phase=list(rr.phase_s))
             for key in host:                                    # host time by phase: of the timed calls only (the warm-up
                 host[key] = 0.0                                 # holds one-off costs: list growth, RCCL's connection set-up)
-            t0 = time.perf_counter()
+            t0 = t0_region = time.perf_counter()
         timed = step >= warm
         for ci, (b0, nb, clo, chi) in enumerate(calls):
             k = ncall % depth
@@ -433,7 +456,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                     if w is not stream:
                         demods[k].stream_wait(w)
             # (first call, last call of its step, the step's listing is wanted: the last step's - it is what the caller checks)
-            stage[k] = [0, timed, (ci == 0, ci == len(calls) - 1, step == warm + steps - 1), ncall]
+            stage[k] = [0, timed, (ci == 0, ci == len(calls) - 1, step == warm + regions * steps - 1), ncall]
             order.append(k)
             ncall += 1
             # keep the older calls moving - the same communication calls at the same point on every rank
@@ -456,19 +479,25 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         resolver.drain()                                        # the timed region ends when the last message is out
     t_drain = time.perf_counter()
     sync_all()
-    elapsed = time.perf_counter() - t0
-    # where the region's last moments go (ms): the calls still in flight when the loop ends, the resolver, the final sync
+    t_end = time.perf_counter()
+    region_elapsed.append(t_end - t0_region)
+    # where the (last) region's final moments go (ms): the calls still in flight when the loop ends, the resolver, the final sync
     tail_ms = {"in_flight": round((t_adv - t_loop) * 1e3, 4), "resolver": round((t_drain - t_adv) * 1e3, 4),
-               "sync": round((t0 + elapsed - t_drain) * 1e3, 4)}
+               "sync": round((t_end - t_drain) * 1e3, 4)}
     if sync_ranks:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+        t = torch.tensor(region_elapsed, dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        region_elapsed = [float(x) for x in t.tolist()]
+    elapsed = float(np.median(region_elapsed))                               # (one region: that region)
+    all_steps = steps * regions
     mean = lambda v: float(np.mean(v)) if v else 0.0
-    out = {"elapsed": elapsed, "scan_ms": mean(scan_ms), "demod_ms": mean(demod_ms), "order_ms": mean(order_ms),
+    out = {"elapsed": elapsed, "elapsed_regions": region_elapsed, "regions": regions,
+           "scan_ms": mean(scan_ms), "demod_ms": mean(demod_ms), "order_ms": mean(order_ms),
            "scan_ms_median": float(np.median(scan_ms)) if scan_ms else 0.0,
+           # the scan kernel's average per region (what the headline's roofline.frac spread comes from)
+           "scan_ms_regions": [mean([v for v, r in zip(scan_ms, scan_region) if r == g]) for g in range(regions)],
            "timed_calls": len(scan_ms), "last": dict(last), "depth": depth, "calls_per_step": len(calls),
-           "host_ms_per_call": {k: round(v / max(1, steps * len(calls)) * 1e3, 4) for k, v in host.items()},
+           "host_ms_per_call": {k: round(v / max(1, all_steps * len(calls)) * 1e3, 4) for k, v in host.items()},
            "call_bytes": float(np.mean([chi - clo for _, _, clo, chi in calls])), "steps": steps, "comm": comm,
            "region_tail_ms": tail_ms}
     prof = [d.host_profile() for d in demods if hasattr(d, "host_profile")]
@@ -483,8 +512,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
         nst = max(1, rr.steps - rr0["steps"])
         out["rank_resolve"] = {"steps": rr.steps - rr0["steps"], "rounds_per_step": round((rr.rounds - rr0["rounds"]) / nst, 3),
                                "reruns": rr.reruns - rr0["reruns"], "threads": resolve_threads,
-                               "work_ms_per_step": round(resolver.resolve_s / max(1, steps) * 1e3, 4),
-                               "exchange_ms_per_step": round(resolver.exchange_s / max(1, steps) * 1e3, 4),
+                               "work_ms_per_step": round(resolver.resolve_s / max(1, all_steps) * 1e3, 4),
+                               "exchange_ms_per_step": round(resolver.exchange_s / max(1, all_steps) * 1e3, 4),
                                "text_bytes_per_step": int((rr.bytes_moved - rr0["bytes"]) / nst),
                                # the work by stretch between the exchanges: [guess, resolve, check, totals, end] (+ re-run rounds)
                                "work_ms_by_phase": [round((a - b) / nst * 1e3, 4) for a, b in zip(rr.phase_s, rr0["phase"])]}
@@ -498,10 +527,10 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     if rank == 0:
         if resolver.error is not None:
             raise resolver.error
-        out.update(msgs=resolver.msgs, listing=resolver.last_text, lines=resolver.last_lines)
+        out.update(msgs=resolver.msgs / regions, listing=resolver.last_text, lines=resolver.last_lines)   # (messages of one region's steps)
         # rank 0's host half per STEP (its own thread, next to the launches): the resolve + --raw formatting of everything the
         # step gathered - what bounds an N-GPU step when it exceeds the kernels' time per rank
-        out["host_ms_per_call"]["resolve_per_step"] = round(resolver.resolve_s / max(1, steps) * 1e3, 4)
+        out["host_ms_per_call"]["resolve_per_step"] = round(resolver.resolve_s / max(1, all_steps) * 1e3, 4)
         resolver.stop()
         if rr is not None:
             rr.close()

@@ -67,7 +67,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_resolver=0.0, lag=None, resolve_on="root"):
+def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_resolver=0.0, lag=None, resolve_on="root", regions=1):
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -101,7 +101,21 @@ def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_res
         demod.HostResolver.raw_listing_spec = lambda self, *a, **k: (time.sleep(slow_resolver * (1 + rank)), fasts(self, *a, **k))[1]
     oplog = []
     out = run_steps(make, data[lo:hi], lo, calls, dict(fix=True, aggressive=False), steps=2, warm=1, depth=depth,
-                    world=world, rank=rank, dist=dist, coll_device="cpu", cap_records=4096, oplog=oplog, lag=lag, resolve_on=resolve_on)
+                    world=world, rank=rank, dist=dist, coll_device="cpu", cap_records=4096, oplog=oplog, lag=lag, resolve_on=resolve_on,
+                    regions=regions)
+    if regions > 1:
+        # `regions` timed regions of 2 steps behind ONE warm-up step: every region has its own bracket and its own clock, `elapsed` is
+        # the median; what is counted per step is counted over all of them
+        assert sum(d.calls for d in made) == (1 + 2 * regions) * ncalls and out["regions"] == regions and len(out["elapsed_regions"]) == regions
+        assert out["elapsed"] == float(np.median(out["elapsed_regions"])) and min(out["elapsed_regions"]) > 0
+        if rank == 0:
+            with open(os.path.join(outdir, "out.txt"), "wb") as f:
+                f.write(out["listing"])
+            assert out["msgs"] == 2 * out["lines"]               # the messages of ONE region's two steps
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert sum(d.calls for d in made) == 3 * ncalls and out["calls_per_step"] == ncalls
     if resolve_on == "ranks":
         # no record left its rank: the launching threads issued no communication call at all; three all_gathers a step and the texts
@@ -144,6 +158,16 @@ def _spawn2(args, deadline=180.0, nprocs=2):
 def test_single_rank_pipeline(tmp_path, golden, case, ncalls, depth):
     _run(0, 1, 0, case, ncalls, depth, str(tmp_path))
     assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
+
+
+def test_several_timed_regions_behind_one_warm_up(tmp_path, golden):
+    """run_steps(regions=3) - bench.py's headline: three regions of K steps back to back, each between its own flush + barrier + sync;
+    the listing is the last step's, the median region is `elapsed`.  One rank, and two over gloo (the regions' clocks are max-reduced)."""
+    _run(0, 1, 0, "edges", 2, 3, str(tmp_path), regions=3)
+    assert open(tmp_path / "out.txt").read() == golden["edges"]["raw"]["default"]["text"]
+    os.remove(tmp_path / "out.txt")
+    _spawn2((2, _free_port(), "edges", 2, 3, str(tmp_path), False, 0.0, None, "root", 3))
+    assert open(tmp_path / "out.txt").read() == golden["edges"]["raw"]["default"]["text"]
 
 
 @pytest.mark.parametrize("case,ncalls,depth", [("frames", 1, 3), ("edges", 2, 3), ("edges", 2, 2), ("edges", 2, 1), ("edges", 3, 4)])

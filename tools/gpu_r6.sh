@@ -20,7 +20,7 @@ for s in "$@"; do
     prof)      bash tools/profile.sh ${TAG} noise > "$O/prof_noise.log" 2>&1; tail -n 30 "$O/prof_noise.log" ;;
     prof_low)  bash tools/profile.sh ${TAG}_lowsnr lowsnr > "$O/prof_lowsnr.log" 2>&1; tail -n 40 "$O/prof_lowsnr.log" ;;
     prof_frames) bash tools/profile.sh ${TAG}_frames frames > "$O/prof_frames.log" 2>&1; tail -n 40 "$O/prof_frames.log" ;;
-    prof_strong) bash tools/profile.sh ${TAG}_strong frames --frames-mib 65536 > "$O/prof_strong.log" 2>&1; tail -n 40 "$O/prof_strong.log" ;;
+    prof_strong) bash tools/profile.sh ${TAG}_strong strong > "$O/prof_strong.log" 2>&1; tail -n 40 "$O/prof_strong.log" ;;
     e2e)       run e2e_cli 900 python tools/e2e_cli.py 8 ;;
     pipe)      run pipe_cadence 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider -k "pipe or paced" ;;
     fuzz)      run fuzz_parity 900 python tools/fuzz_parity.py 5000 600 ;;
