@@ -109,9 +109,11 @@ void show_help() {
         "                         A pipe (--ifile -) and --loop have ONE reader: rank 0 reads and hands every rank its batches\n"
         "                         through shared memory.  --gpus <n> (one process, the same devices) is the faster of the two for\n"
         "                         any input below ~96 GB: a communicator takes 1.6 s to start (a minute on a fresh box).\n"
-        "--resolve-on-ranks       With --ranks and --raw: every rank resolves its own batches from a guessed whitelist, the ranks\n"
-        "                         confirm each other in stream order through shared memory and rank 0 prints their texts - no\n"
-        "                         record leaves its rank, no communicator is made (the listing is the same).\n"
+        "--resolve-on-ranks       With --ranks and --raw / --onlyaddr / --raw-net / --stats: every rank resolves its own batches from\n"
+        "                         a guessed whitelist, the ranks confirm each other in stream order through shared memory and rank 0\n"
+        "                         prints their texts (--stats: adds their counters up) - no record leaves its rank, no communicator\n"
+        "                         is made; the output is the same.  On a pipe the whitelist's 60 s run on rank 0's clock, read once\n"
+        "                         per round of n batches.\n"
         "--gather-records <n>     With --ranks: records per rank and round the gather buffers hold (default: 262144).\n"
         "--gather-candidates <n>  With --ranks --stats: preamble positions per rank and round (default: a batch's positions / 64).\n"
         "--batch-blocks <n>       256 KiB buffers per GPU call (default: 512).  A file always fills its batches; a pipe\n"
@@ -380,19 +382,23 @@ int run_ranks(const Options &opt, double t_start) {
         uint8_t written[MODES_ICAO_SLOTS];
     };
     struct RrHead { std::atomic<uint64_t> printed; std::atomic<int> failed; std::atomic<uint64_t> reruns; int64_t now[16]; };   // printed: rounds rank 0 has written out
+    struct RrTotals { std::atomic<uint64_t> ready; modes_host_stats st; };    // --stats: a rank's nine counters when its last round is final
     RrHead *rr_head = nullptr;
     RrRank *rr_ranks = nullptr;
+    RrTotals *rr_totals = nullptr;
     char *rr_text = nullptr;
     const size_t rr_text_cap = ((size_t)opt.gather_cap * 62 + 64 + 4095) & ~(size_t)4095;     // two 31-byte lines per record at most
     if (rr) {
         if (depth > 16) { fprintf(stderr, "--resolve-on-ranks: --depth %d (at most 16)\n", depth); return 1; }
-        const size_t ctl = (sizeof(RrHead) + (size_t)depth * (size_t)N * sizeof(RrRank) + 4095) & ~(size_t)4095;
+        const size_t ctl = (sizeof(RrHead) + (size_t)depth * (size_t)N * sizeof(RrRank) + (size_t)N * sizeof(RrTotals) + 4095) & ~(size_t)4095;
         void *m = mmap(nullptr, ctl + (size_t)depth * (size_t)N * rr_text_cap, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
         if (m == MAP_FAILED) { perror("--resolve-on-ranks: shared buffers"); return 1; }
         rr_head = new (m) RrHead;
         rr_head->printed.store(0); rr_head->failed.store(0); rr_head->reruns.store(0);
         rr_ranks = reinterpret_cast<RrRank *>(static_cast<uint8_t *>(m) + sizeof(RrHead));
         for (size_t i = 0; i < (size_t)depth * (size_t)N; i++) { new (&rr_ranks[i]) RrRank; rr_ranks[i].guess_seq.store(0); rr_ranks[i].final_seq.store(0); }
+        rr_totals = reinterpret_cast<RrTotals *>(rr_ranks + (size_t)depth * (size_t)N);
+        for (int r = 0; r < N; r++) { new (&rr_totals[r]) RrTotals; rr_totals[r].ready.store(0); }
         rr_text = static_cast<char *>(m) + ctl;
     }
     if (!opt.devices.empty() && (int)opt.devices.size() != N) { fprintf(stderr, "--ranks %d with a --gpu-list of %zu devices\n", N, opt.devices.size()); return 1; }
@@ -671,11 +677,15 @@ int run_ranks(const Options &opt, double t_start) {
         if (qq >= (uint64_t)depth && !rr_wait(rr_head->printed, qq - (uint64_t)depth + 1)) return false;
         const modes_record *recs = nullptr;
         uint64_t nrec = 0;
+        const uint64_t *cands = nullptr;                                     // --stats: every preamble position of the batch (dump1090.c:1651)
+        uint64_t ncand = 0;
         if (have) {
             modes_gpu_result res{};
             if (modes_gpu_fetch(lanes[(size_t)l].gpu, &res) != MODES_OK) { fail_rank("GPU demodulation failed", modes_gpu_last_error(lanes[(size_t)l].gpu)); return false; }
             recs = res.records;
             nrec = res.n_records;
+            cands = res.candidates;
+            ncand = res.n_candidates;
             if (nrec > opt.gather_cap) { fail_rank("resolve", "a batch's records exceed --gather-records (the text buffers are sized by it)"); return false; }
         }
         modes_host_whitelist_guess(host, &recs, &nrec, 1, me.guess, opt.resolve_threads);
@@ -703,10 +713,25 @@ int run_ranks(const Options &opt, double t_start) {
         char *text = rr_text + ((size_t)l * (size_t)N + (size_t)rank) * rr_text_cap;
         lookups.resize((size_t)nrec * 2 + 16);
         uint64_t nb = 0, nl = 0, lines = 0;
+        // --raw: the lean resolve on several threads.  The other sinks this mode serves go through the general resolve and the host's
+        // own sink: --onlyaddr / --raw-net format their line there, --stats prints nothing and counts (with the batch's preamble
+        // positions: the counters of dump1090.c:2993-3006 are sums of per-batch counts, rank 0 adds the ranks' up at the end).
+        // A resolve that is repeated starts from the counters the first one found.
+        modes_host_stats st_before;
+        modes_host_get_stats(host, &st_before);
         auto resolve_from = [&](const std::vector<uint32_t> &addr, const std::vector<int64_t> &seen) {
             modes_host_set_time(host, now);
             modes_host_set_whitelist(host, addr.data(), seen.data());
-            lines = modes_host_resolve_raw_spec(host, &recs, &nrec, 1, text, rr_text_cap, &nb, opt.resolve_threads, me.written, lookups.data(), lookups.size(), &nl);
+            if (raw_fast) {
+                lines = modes_host_resolve_raw_spec(host, &recs, &nrec, 1, text, rr_text_cap, &nb, opt.resolve_threads, me.written, lookups.data(), lookups.size(), &nl);
+                return;
+            }
+            modes_host_set_stats(host, &st_before);
+            sink.out.clear();
+            lines = modes_host_resolve_spec(host, recs, nrec, cands, ncand, on_message, &sink, me.written, lookups.data(), lookups.size(), &nl);
+            nb = sink.out.size();
+            if (nb < rr_text_cap) memcpy(text, sink.out.data(), (size_t)nb);
+            sink.out.clear();
         };
         resolve_from(st_addr, st_seen);
         // confirmation, in rank order: the ranks before this one are final -> their tables give the true start
@@ -869,7 +894,25 @@ int run_ranks(const Options &opt, double t_start) {
         if (rank != 0) _exit(rc);
         _exit(finish(rc));
     }
-    if (rank == 0 && opt.stats) {                                            // dump1090.c:2993-3006
+    if (rr && opt.stats) {                                                   // every rank's counters -> rank 0, which adds them up
+        modes_host_get_stats(host, &rr_totals[rank].st);
+        rr_totals[rank].ready.store(1, std::memory_order_release);
+        if (rank == 0) {
+            modes_host_stats sum{};
+            for (int r = 0; r < N; r++) {
+                if (!rr_wait(rr_totals[r].ready, 1)) { fail_rank("resolve", "another rank failed"); break; }
+                const modes_host_stats &o = rr_totals[r].st;
+                sum.valid_preamble += o.valid_preamble > 0 ? o.valid_preamble : 0;   // (a rank that never had a batch saw no positions)
+                sum.out_of_phase += o.out_of_phase; sum.demodulated += o.demodulated; sum.goodcrc += o.goodcrc; sum.badcrc += o.badcrc;
+                sum.fixed += o.fixed; sum.single_bit_fix += o.single_bit_fix; sum.two_bits_fix += o.two_bits_fix;
+            }
+            if (rc) { fflush(out); fflush(stderr); rr_head->failed.store(1); _exit(finish(rc)); }
+            char text[512];
+            modes_format_stats(&sum, text);
+            fputs(text, out);
+            fflush(out);
+        }
+    } else if (rank == 0 && opt.stats) {                                     // dump1090.c:2993-3006
         modes_host_stats hs;
         modes_host_get_stats(host, &hs);
         char text[512];
@@ -986,9 +1029,13 @@ int main(int argc, char **argv) {
             if (in_file < opt.batch_blocks) opt.batch_blocks = in_file;
         }
         if (ngpus > 0) { fprintf(stderr, "--ranks and --gpus are two ways to use N GPUs: give one of them\n"); return 1; }
-        if (opt.resolve_on_ranks && !(opt.raw && !opt.stats && !opt.sbs && !opt.raw_net && !opt.onlyaddr)) {
-            // (--stats needs every preamble position in one place, --sbs the aircraft table in stream order: rank 0's business)
-            fprintf(stderr, "--resolve-on-ranks serves the --raw listing only (no --stats, --sbs, --raw-net, --onlyaddr): leave it out for those\n");
+        if (opt.resolve_on_ranks && (opt.sbs || !(opt.raw || opt.stats || opt.onlyaddr || opt.raw_net))) {
+            // --raw, --onlyaddr, --raw-net: a line is a function of its message; --stats: the nine counters are sums of per-batch counts.
+            // --sbs is not: a BaseStation line reads the AIRCRAFT TABLE (positions from CPR pairs, speed and track of earlier messages,
+            // dump1090.c:2069-2167, :2397-2448) - state that crosses every batch in stream order, like the whitelist but 200 bytes per
+            // aircraft and written by nearly every message: there is nothing to guess.  The verbose dump is 11 lines a message: rank 0's.
+            fprintf(stderr, "--resolve-on-ranks serves --raw, --onlyaddr, --raw-net and --stats; --sbs needs the aircraft table in stream order and the "
+                            "verbose dump is too much text to ship: leave it out for those\n");
             return 1;
         }
         return run_ranks(opt, t_start);

@@ -1041,6 +1041,34 @@ uint64_t modes_host_resolve_raw_spec(modes_host *h, const modes_record *const *s
     return msgs;
 }
 
+// The general resolve (any sink, candidates for --stats) with the log a later confirmation needs - what --resolve-on-ranks runs for
+// the modes the lean --raw resolve does not serve (--stats: counters only; --onlyaddr / --raw-net: the sink formats).  One thread.
+uint64_t modes_host_resolve_spec(modes_host *h, const modes_record *recs, uint64_t nrecs, const uint64_t *cands, uint64_t ncand,
+                                 modes_sink_fn sink, void *user, uint8_t *written, modes_icao_lookup *lookups, uint64_t lookup_cap,
+                                 uint64_t *nlookups) {
+    IcaoLog log;
+    uint64_t calls;
+    {
+        struct Log { modes_host *h; IcaoLog *was; ~Log() { h->log = was; } } keep{h, h->log};
+        h->log = &log;
+        calls = modes_host_resolve(h, recs, nrecs, cands, ncand, sink, user);
+    }
+    if (written)
+        for (uint32_t s = 0; s < kIcaoSlots; s++) written[s] = log.written[s] ? 1 : 0;
+    const uint64_t n = log.lookups.size();
+    if (lookups)
+        for (uint64_t i = 0; i < n && i < lookup_cap; i++) lookups[i] = modes_icao_lookup{log.lookups[i].addr, log.lookups[i].known ? 1u : 0u};
+    if (nlookups) *nlookups = n;
+    return calls;
+}
+
+// The counters as they stand (a speculative resolve that has to be repeated starts from the counters it found: modes_host_get_stats
+// before, this after; a negative valid_preamble - "no candidates seen" - restores as 0).
+void modes_host_set_stats(modes_host *h, const modes_host_stats *st) {
+    h->st = *st;
+    if (h->st.valid_preamble < 0) h->st.valid_preamble = 0;
+}
+
 int modes_host_whitelist_check(const modes_host *h, const modes_icao_lookup *lookups, uint64_t n) {
     modes_host probe = *h;                                                        // (no log: a check is not a lookup of the run)
     probe.log = nullptr;

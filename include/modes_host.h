@@ -223,6 +223,14 @@ uint64_t modes_host_resolve_raw_spec(modes_host *h, const modes_record *const *s
                                      char *out, uint64_t cap, uint64_t *nbytes, int threads,
                                      uint8_t *written, modes_icao_lookup *lookups, uint64_t lookup_cap, uint64_t *nlookups);
 
+/* modes_host_resolve (any sink; candidates for --stats) with the same log: for the sinks the lean --raw resolve does not serve
+ * (--stats: the counters of dump1090.c:2993-3006 are sums over the ranks; --onlyaddr, --raw-net: the sink formats the line).  One
+ * thread.  A resolve that has to be repeated must not count twice: modes_host_get_stats before, modes_host_set_stats to go back. */
+uint64_t modes_host_resolve_spec(modes_host *h, const modes_record *recs, uint64_t nrecs, const uint64_t *candidates, uint64_t ncand,
+                                 modes_sink_fn sink, void *user, uint8_t *written, modes_icao_lookup *lookups, uint64_t lookup_cap,
+                                 uint64_t *nlookups);
+void modes_host_set_stats(modes_host *h, const modes_host_stats *st);
+
 /* 1 when h's whitelist (at h's clock) gives every one of the logged answers, else 0. */
 int modes_host_whitelist_check(const modes_host *h, const modes_icao_lookup *lookups, uint64_t n);
 

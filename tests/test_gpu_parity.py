@@ -426,6 +426,27 @@ def test_cli_ranks_resolve_their_own_batches(torch_cuda, golden, streams, tmp_pa
     assert outs[0] == outs[1] and len(outs[0]) == n
 
 
+@pytest.mark.parametrize("nranks", [1, 3])
+def test_cli_ranks_resolve_stats_and_onlyaddr(torch_cuda, golden, streams, tmp_path, nranks):
+    """--resolve-on-ranks for the sinks beyond --raw (round 6; dump1090.c:2993-3006, :1317-1331): --stats - every rank counts its own
+    batches, preamble positions included, rank 0 adds the nine counters up - and --onlyaddr / --raw-net, as real processes sharing the
+    device; the reference's md5s on its capture, the one-process host's output on the frames stream."""
+    exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
+    ranks = ["--ranks", str(nranks), "--gpu-list", ",".join(["0"] * nranks), "--resolve-on-ranks", "--batch-blocks", "1"]
+    cap = os.path.join(ROOT, "tests", "golden", "modes1.bin")
+    for flags, lines, md5 in ((["--stats"], 9, "bc3d1c04b24f4989f0fc4a2d1f45abdd"), (["--onlyaddr"], 284, "bab0f055e262e216208a5cbbdf63fe24")):
+        p = subprocess.run([exe, "--ifile", cap] + flags + ranks, capture_output=True, timeout=300)
+        assert p.returncode == 0 and (p.stdout.count(b"\n"), hashlib.md5(p.stdout).hexdigest()) == (lines, md5), (flags, p.stderr[-400:])
+    path = tmp_path / "frames.bin"
+    streams["frames"].tofile(path)
+    for flags in (["--stats"], ["--stats", "--aggressive"], ["--raw-net"], ["--onlyaddr", "--no-fix"]):
+        want = subprocess.run([exe, "--ifile", str(path)] + flags, capture_output=True, check=True).stdout
+        got = subprocess.run([exe, "--ifile", str(path)] + flags + ranks, capture_output=True, timeout=300)
+        assert got.returncode == 0 and got.stdout == want and len(want) > 0, (flags, got.stderr[-400:])
+    p = subprocess.run([exe, "--ifile", cap, "--sbs"] + ranks, capture_output=True, timeout=60)
+    assert p.returncode == 1 and b"aircraft table" in p.stderr
+
+
 def test_cli_more_ranks_than_gpus_fails_instead_of_hanging(torch_cuda, streams, tmp_path):
     """dump1090_amd --ranks 2 on a box with one GPU: rank 1 has no device, rank 0 already waits in the communicator's
     rendezvous.  Rank 0's watchdog ends the job: status 1 and a message, not a hang."""

@@ -419,7 +419,7 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     assert p.stdout.count(b"fails to start: exit status 1") == 3
     # ... and so does a rank whose GPU call fails mid-stream, with its peer already inside that round's exchange (no teardown of
     # the communicator on that path: ADVICE round 3)
-    assert p.stdout.count(b"fails in GPU call") == 2 and p.stdout.count(b": exit status 1") == 7      # (+ --resolve-on-ranks --stats, refused)
+    assert p.stdout.count(b"fails in GPU call") == 2 and p.stdout.count(b": exit status 1") == 7      # (+ --resolve-on-ranks --sbs, refused)
     # --stats through the gather's second list (every rank's preamble positions on rank 0): the reference's nine lines for N = 1, 2, 3;
     # a list that outgrows its buffers fails the job
     assert p.stdout.count(b"md5 bc3d1c04b24f4989f0fc4a2d1f45abdd") == 8        # N = 1, 2, 3 x two batch sizes, N = 8, and a pipe with N = 2
@@ -431,11 +431,15 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     # --resolve-on-ranks (every rank resolves its own batches, the ranks confirm each other through shared memory, rank 0 prints the texts;
     # no gather library): N = 1, 2, 3, 8 x two batch sizes, a pipe, a replay; on a stream whose DF4 / DF5 / DF20 frames only validate against
     # an address an earlier rank remembered: right guesses are kept (0 re-runs), wrong starts are noticed and resolved again - same listing
-    assert p.stdout.count(b"--resolve-on-ranks --ranks") == 8 + 2 + 4 and b"orderly teardown (--clean-exit): md5 4a81758c" in p.stdout and b"--resolve-on-ranks --ifile - --ranks 3: md5 4a81758c" in p.stdout
+    assert p.stdout.count(b"--resolve-on-ranks --ranks") == 8 + 2 + 4 + 4 and b"orderly teardown (--clean-exit): md5 4a81758c" in p.stdout and b"--resolve-on-ranks --ifile - --ranks 3: md5 4a81758c" in p.stdout
     assert p.stdout.count(b"on AP-validated frames: md5 524f28a5613c2468123104e0a17e61f8, 0 re-run(s)") == 2
     assert b"--ranks 2 on AP-validated frames, wrong starts: md5 524f28a5613c2468123104e0a17e61f8, 1 re-run(s)" in p.stdout
     assert b"--ranks 3 on AP-validated frames, wrong starts: md5 524f28a5613c2468123104e0a17e61f8, 2 re-run(s)" in p.stdout
-    assert b"--resolve-on-ranks --loop --ranks 2 / 3: the first" in p.stdout and b"--resolve-on-ranks --stats: exit status 1" in p.stdout
+    assert b"--resolve-on-ranks --loop --ranks 2 / 3: the first" in p.stdout and b"--resolve-on-ranks --sbs: exit status 1" in p.stdout
+    # round 6: --stats (the ranks' counters added up by rank 0; a repeated resolve does not count twice), --onlyaddr and --raw-net resolved
+    # on the ranks: N = 1, 2, 3, 8 with right and wrong starts, and a pipe
+    assert p.stdout.count(b"--stats / --onlyaddr / --raw-net --ranks") == 8 and b"--ifile - --stats --ranks 3 --resolve-on-ranks: md5 bc3d1c04" in p.stdout
+    assert p.stdout.count(b"--stats --resolve-on-ranks --ranks") == 4
     assert p.stdout.count(b"fails in its GPU call") == 2 and p.stdout.count(b": status 1") == 2       # a failing rank ends the job there too
 
 

@@ -13,7 +13,7 @@ for s in "$@"; do
     smoke)     run smoke 400 python -c "import __graft_entry__ as g; g.smoke()" ;;
     parity)    run parity 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider ;;
     all)       run pytest_gpu_all 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider ;;
-    resolve)   run resolve_rate 600 python tools/resolve_rate.py; grep '^{' "$O/resolve_rate.log" > "$O/resolve_rate.json" ;;
+    resolve)   MODES_HOST_MT_DEBUG=1 run resolve_rate 600 python tools/resolve_rate.py; grep '^{' "$O/resolve_rate.log" > "$O/resolve_rate.json" ;;
     ranks8)    run rank_resolve_8ranks 1200 python -m pytest tests/test_gpu_bench.py -m gpu -q -x -p no:cacheprovider -k eight_ranks -s ;;
     bench)     run bench 900 python bench.py ;;
     bench20)   run bench20 900 python bench.py --steps 20 --warmup 5 ;;
@@ -22,7 +22,7 @@ for s in "$@"; do
     prof_frames) bash tools/profile.sh ${TAG}_frames frames > "$O/prof_frames.log" 2>&1; tail -n 40 "$O/prof_frames.log" ;;
     prof_strong) bash tools/profile.sh ${TAG}_strong strong > "$O/prof_strong.log" 2>&1; tail -n 40 "$O/prof_strong.log" ;;
     e2e)       run e2e_cli 900 python tools/e2e_cli.py 8 ;;
-    pipe)      run pipe_cadence 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider -k "pipe or paced" ;;
+    pipe)      run pipe_cadence 600 python -m pytest tests/test_gpu_parity.py tests/test_dropin.py -m gpu -q -x -p no:cacheprovider -k "pipe or paced" ;;
     fuzz)      run fuzz_parity 900 python tools/fuzz_parity.py 5000 600 ;;
     *)         echo "unknown step $s" ;;
   esac

@@ -201,13 +201,35 @@ PY
     for r in 2 3; do
         timeout 60 $D/dump1090_amd_stub --ifile $D/pad.bin --raw --loop --ranks $r --batch-blocks 1 --resolve-on-ranks 2> /dev/null | head -c $n > $D/loop_rr$r.txt
     done
-    $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --stats --ranks 2 --resolve-on-ranks > /dev/null 2> $D/rr_refused.err
+    $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --sbs --ranks 2 --resolve-on-ranks > /dev/null 2> $D/rr_refused.err
     rc=$?
     set -e
     cmp $D/loop_1proc.txt $D/loop_rr2.txt && cmp $D/loop_1proc.txt $D/loop_rr3.txt || { echo "   --loop --resolve-on-ranks differs from the one-process replay"; exit 1; }
     echo "   --resolve-on-ranks --loop --ranks 2 / 3: the first $n bytes (2.5 laps) equal the one-process host's"
-    echo "   --resolve-on-ranks --stats: exit status $rc"
-    [ "$rc" = 1 ] && grep -q "serves the --raw listing only" $D/rr_refused.err || { cat $D/rr_refused.err; exit 1; }
+    echo "   --resolve-on-ranks --sbs: exit status $rc"
+    [ "$rc" = 1 ] && grep -q "needs the aircraft table in stream order" $D/rr_refused.err || { cat $D/rr_refused.err; exit 1; }
+    # round 6: the other sinks whose output is a function of the message (--onlyaddr, --raw-net) or a sum over the batches (--stats: every
+    # rank counts its own batches - preamble positions included - and rank 0 adds the nine counters up), right and wrong starts, a pipe
+    for k in 1 2 3 8; do for spoil in "" 1; do
+        for mode in --stats --onlyaddr --raw-net; do
+            case $mode in --stats) want=bc3d1c04b24f4989f0fc4a2d1f45abdd ;; --onlyaddr) want=bab0f055e262e216208a5cbbdf63fe24 ;;
+                          --raw-net) want=$($D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw-net | md5sum | cut -c1-32) ;; esac
+            got=$(env ${spoil:+MODES_RR_SPOIL=1} $D/dump1090_amd_stub --ifile tests/golden/modes1.bin $mode --ranks $k --batch-blocks 1 --resolve-on-ranks | md5sum | cut -c1-32)
+            [ "$got" = "$want" ] || { echo "   $mode --ranks $k --resolve-on-ranks${spoil:+ (wrong starts)}: $got, want $want"; exit 1; }
+        done
+        echo "   --stats / --onlyaddr / --raw-net --ranks $k --resolve-on-ranks${spoil:+, wrong starts}: the one-process host's output"
+    done; done
+    wants=$($D/dump1090_amd_stub --ifile $D/ap.bin --stats | md5sum | cut -c1-32)
+    for k in 2 3; do for spoil in "" 1; do
+        got=$(env ${spoil:+MODES_RR_SPOIL=1} $D/dump1090_amd_stub --ifile $D/ap.bin --stats --ranks $k --batch-blocks 1 --resolve-on-ranks --timing 2> $D/rr_ap.err | md5sum | cut -c1-32)
+        re=$(grep -o '"reruns": [0-9]*' $D/rr_ap.err | cut -d' ' -f2)
+        echo "   --stats --resolve-on-ranks --ranks $k on AP-validated frames${spoil:+, wrong starts}: md5 $got, $re re-run(s)"
+        [ "$got" = "$wants" ] || { echo "   expected $wants (a repeated resolve must not count twice)"; exit 1; }
+        if [ -n "$spoil" ]; then [ "$re" -ge $((k - 1)) ] || { echo "   a wrong start went unnoticed"; exit 1; }; fi
+    done; done
+    got=$(cat tests/golden/modes1.bin | $D/dump1090_amd_stub --ifile - --stats --ranks 3 --batch-blocks 1 --resolve-on-ranks | md5sum | cut -c1-32)
+    [ "$got" = bc3d1c04b24f4989f0fc4a2d1f45abdd ] || { echo "   --ifile - --stats --ranks 3 --resolve-on-ranks: $got"; exit 1; }
+    echo "   --ifile - --stats --ranks 3 --resolve-on-ranks: md5 $got"
     mv $D/libmodes_gather.so.away $D/libmodes_gather.so
     # a rank whose GPU does not come up while its peers already wait in the gather: the job ends with status 1, it does not hang
     # (rank 0's watchdog kills the other ranks; a rank never outlives rank 0)
