@@ -373,6 +373,18 @@ def auto_resolve_threads(world, ranks_resolve):
     return max(1, min(32, spare // world if ranks_resolve else spare))
 
 
+def n1_reference(leg):
+    """The committed ONE-GPU rate of a leg (profiles/n1_reference.json, written from this round's `python bench.py` on the lease) - what an
+    N > 1 line's efficiency is priced against inside the record; the driver computes its own from its own N = 1 run."""
+    if leg is None:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "n1_reference.json")) as f:
+            return json.load(f).get(leg)
+    except (OSError, ValueError):
+        return None
+
+
 def visible_gpus():
     """GPUs this process can use: hipGetDeviceCount through torch (it honours the *_VISIBLE_DEVICES lists and what the container
     may open).  Called by the parent of a self-launched N-rank run only - the ranks are separate processes."""
@@ -554,7 +566,8 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=limit)
     ranks_resolve = dist_on and args.resolve_on == "ranks"
     # host memory for the ranks' whitelist exchanges (three small all_gathers a step), whatever the records' backend is
-    ctl_group = dist.new_group(backend="gloo", timeout=limit) if ranks_resolve else None
+    # (made whenever lists travel: the strong leg runs in BOTH resolve modes behind each other - one SCALE invocation, both answers)
+    ctl_group = dist.new_group(backend="gloo", timeout=limit) if dist_on else None
 
     def shard(total_bytes):
         """this rank's contiguous buffer range of the whole stream, and the bytes it needs (476-byte carry in front)"""
@@ -565,11 +578,13 @@ def main():
         lo, hi = shard_byte_range(first_block, nblocks, total_bytes)
         return first_block, nblocks, lo, hi
 
-    def leg(iq, lo, calls, flags, steps, warm, cap_records, nstreams, timing, time_every=None, regions=1):
+    def leg(iq, lo, calls, flags, steps, warm, cap_records, nstreams, timing, time_every=None, regions=1, resolve_on=None):
         """K timed steps over this rank's HBM-resident shard (dump1090_amd/pipeline.py).  timing: one call in --time-every
         carries HIP timing events around its kernels (one launch stream only: the times are then the kernels' own); without:
         no events at all - pure throughput."""
         works = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+        resolve_on = resolve_on or args.resolve_on
+        ranks_resolve = dist_on and resolve_on == "ranks"          # (this leg's: the strong leg runs once in each mode)
 
         class NoTiming:                                   # run_steps switches timing per call only on objects that have set_timing
             def __init__(self, d):
@@ -591,7 +606,7 @@ def main():
                          # (root: rank 0 resolves every rank's records on up to 32 threads; ranks: every rank its own, all at the same
                          #  time - half the hardware threads shared out among them)
                          resolve_threads=args.resolve_threads or auto_resolve_threads(world, ranks_resolve),
-                         gather=dist_on, resolve_on=args.resolve_on, ctl_group=ctl_group, regions=regions)
+                         gather=dist_on, resolve_on=resolve_on, ctl_group=ctl_group, regions=regions)
 
     def gathered(obj):
         """[obj of rank 0, of rank 1, ...] on rank 0 (None elsewhere)"""
@@ -616,7 +631,7 @@ def main():
                 "gather_ms": round(c["ms"] / max(1, c["calls"]), 4),        # GPU time of one call's two exchanges (communication stream)
                 "loopback": (world == 1) or None}
 
-    def frames_leg(kind, seed, total_bytes, flags, steps, kw, cap_records):
+    def frames_leg(kind, seed, total_bytes, flags, steps, kw, cap_records, both_modes=False):
         """A leg over the stream config3_stream(seed, total_bytes / 262144, **kw), sharded over the ranks: K timed steps, the
         last step's gathered listing checked (reference md5 where committed, analytic expectation otherwise)."""
         total_blocks = total_bytes // 262144
@@ -649,7 +664,16 @@ def main():
             res.update(scan_ms=kt["scan_ms"], demod_ms=kt["demod_ms"], order_ms=kt["order_ms"], scan_ms_median=kt["scan_ms_median"],
                        timed_calls=kt["timed_calls"], kernel_steps=tsteps,
                        kernel_timing="a region of %d steps of the same workload on ONE launch stream, HIP events on one call in 4" % tsteps)
-        res.update(total=total_bytes, span=hi - lo, per_gpu=total_bytes // world, settle_steps=settle_steps)
+        res.update(total=total_bytes, span=hi - lo, per_gpu=total_bytes // world, settle_steps=settle_steps, resolve_on=args.resolve_on if dist_on else None)
+        other = None
+        if both_modes and dist_on:
+            # the same steps over the same resident shard with the OTHER resolve mode (root: the lists travel to rank 0, which resolves them all;
+            # ranks: every rank resolves its own, the texts travel): a sub-linear point of the curve is attributed in the record itself
+            mode2 = "root" if args.resolve_on == "ranks" else "ranks"
+            other = leg(iq_f, lo, calls, flags, steps, settle_steps, cap_records, nls, nls == 1, resolve_on=mode2)
+            other.update(total=total_bytes, span=hi - lo, per_gpu=total_bytes // world, settle_steps=settle_steps, resolve_on=mode2,
+                         scan_ms=res["scan_ms"], demod_ms=res["demod_ms"], order_ms=res["order_ms"], scan_ms_median=res["scan_ms_median"],
+                         timed_calls=res["timed_calls"], kernel_timing="the first pass's (the same kernels on the same input)")
         if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "strong":     # (strong: the frames leg's stream at another seed)
             # the compiled reference on the first GiB of THIS leg's stream, with this leg's flags ("for >= 8 GiB
             # configs ... on the first 1 GiB with the extrapolation stated": the stream is statistically uniform - one frame
@@ -669,6 +693,12 @@ def main():
                     "the listing differs from the reference's: %s vs %s" % (chk, gold)
             chk["equals_reference_md5"] = True if gold is not None else None      # None: no committed listing for this size
             res["check"] = chk
+            if other is not None:
+                chk2 = check_listing(other["listing"], expected, weak=(kind == "lowsnr"))
+                assert (chk2["lines"], chk2["md5"]) == (chk["lines"], chk["md5"]), "resolve_on=%s prints another listing: %s vs %s" % (other["resolve_on"], chk2, chk)
+                chk2["equals_reference_md5"] = chk["equals_reference_md5"]
+                other["check"] = chk2
+        res["other_mode"] = other
         return res
 
     line = {}
@@ -721,7 +751,7 @@ def main():
     if want("frames"):
         fsteps = args.frames_steps if args.workload == "all" else args.steps
         frames = frames_leg("frames", 3 if world == 1 else 4, (args.frames_mib << 20) * world, dict(fix=True, aggressive=False),
-                            fsteps, {}, 1 << 17)
+                            fsteps, {}, 1 << 17, both_modes=(args.frames_mib << 20) * world == args.frames_total_mib << 20)
     if want("lowsnr"):
         lsteps = args.lowsnr_steps if args.workload == "all" else args.steps
         lowsnr = frames_leg("lowsnr", 5, (args.lowsnr_mib << 20) * world, dict(fix=True, aggressive=True), lsteps, LOWSNR, 1 << 16)
@@ -732,7 +762,7 @@ def main():
             strong, strong_is_frames = frames, True             # N = 8: the frames leg already is this stream on these shards
         else:
             ssteps = args.strong_steps if args.workload == "all" else args.steps
-            strong = frames_leg("strong", 4, total_strong, dict(fix=True, aggressive=False), ssteps, {}, 1 << 17)
+            strong = frames_leg("strong", 4, total_strong, dict(fix=True, aggressive=False), ssteps, {}, 1 << 17, both_modes=True)
 
     def leg_summary(leg, name, scaling):
         steps = leg["steps"]
@@ -784,6 +814,18 @@ def main():
                 d["rank_resolve"] = leg["rank_resolve"]     # rank 0's view: its own share of the resolve, the protocol's exchanges
             if dist_on:
                 d["rccl"] = comm_facts(leg, steps)
+                # where a step's time can go at N > 1, in one place: the slowest rank's kernels, rank 0's host half, the
+                # exchange - and the step itself; efficiency against the committed one-GPU rate of the same stream (profiles/n1_reference.json)
+                per_step = lambda r: leg["calls_per_step"] * (r["scan"] + r["demod"])
+                rr_facts = leg.get("rank_resolve") or {}
+                n1 = n1_reference("frames_strong" if scaling == "strong" else None)
+                d["scaling_breakdown"] = {"resolve_on": leg.get("resolve_on"), "n_gpus": world, "ms_per_step": d["ms_per_step"],
+                                "kernel_ms_max_rank": round(max(per_step(r) for r in per_rank), 4),
+                                "rank0_resolve_ms": rr_facts.get("work_ms_per_step", (leg.get("host_ms_per_call") or {}).get("resolve_per_step")),
+                                "exchange_ms": rr_facts.get("exchange_ms_per_step", round(d["rccl"]["gather_ms"] * leg["calls_per_step"], 4)),
+                                "Msamples_per_s": d["Msamples_per_s"],
+                                "efficiency_vs_committed_n1": round(d["Msamples_per_s"] / (world * n1["Msamples_per_s"]), 4) if n1 else None,
+                                "committed_n1": n1}
                 # a leg with records to gather whose gather moved nothing did not measure the N > 1 path
                 assert not (leg["lines"] > 0 and d["rccl"]["p2p_ops_per_step"] == 0 and (world > 1 or args.backend == "nccl")), \
                     "%s: %d messages per step but no point-to-point transfer was issued" % (name, leg["lines"])
@@ -797,11 +839,15 @@ def main():
         legs["lowsnr"] = leg_summary(lowsnr, "BASELINE.json configs[4]: %d MiB per GPU, sigma=3 noise + weak frames (amplitude 8-15, 20-40 %% leak, "
                                      "5 %% two-bit errors, 1 per 16,384 samples), --aggressive" % args.lowsnr_mib, "weak")
     if strong is not None:
+        sname = "BASELINE.json configs[3]'s stream (%d MiB, 1 frame per 65,536 samples) over %d GPU(s): the same stream at every N, --fix" % (
+            args.frames_total_mib, world)
         if strong_is_frames:
             legs["frames_strong"] = dict(legs["frames"], scaling="strong", same_run_as="frames")
         else:
-            legs["frames_strong"] = leg_summary(strong, "BASELINE.json configs[3]'s stream (%d MiB, 1 frame per 65,536 samples) over %d GPU(s): the "
-                                                "same stream at every N, --fix" % (args.frames_total_mib, world), "strong")
+            legs["frames_strong"] = leg_summary(strong, sname, "strong")
+        if strong.get("other_mode") is not None:                # the same steps with the other resolve mode, behind the first pass
+            o = strong["other_mode"]
+            legs["frames_strong_resolve_on_%s" % o["resolve_on"]] = leg_summary(o, sname + " - resolve_on=%s" % o["resolve_on"], "strong")
 
     names = {"noise": noise, "frames": frames, "lowsnr": lowsnr, "strong": strong}
     head = noise if noise is not None else next(v for k, v in names.items() if v is not None)

@@ -106,6 +106,10 @@ class Emitted(C.Structure):
     _fields_ = [("mm", ModesMessage), ("block", C.c_uint32), ("j", C.c_uint32)]
 
 
+class TextPiece(C.Structure):                      # modes_text_piece
+    _fields_ = [("base", C.c_void_p), ("len", C.c_uint64)]
+
+
 class Aircraft(C.Structure):
     """modes_aircraft (include/modes_host.h), the reference's struct aircraft without the list link."""
     _fields_ = [("addr", C.c_uint32), ("hexaddr", C.c_char * 7), ("flight", C.c_char * 9), ("altitude", C.c_int),
@@ -132,7 +136,7 @@ HOST_SYMBOLS = ("modes_host_create", "modes_host_destroy", "modes_host_set_time"
                 "modes_format_onlyaddr", "modes_format_verbose", "modes_format_stats", "modes_checksum", "modes_compute_crc", "modes_message_len_by_type",
                 "modes_block_count",
                 "modes_host_get_whitelist", "modes_host_set_whitelist", "modes_host_whitelist_guess", "modes_host_resolve_raw_spec",
-                "modes_host_whitelist_check", "modes_host_cpu_budget", "modes_host_classify", "modes_host_resolve_spec", "modes_host_set_stats",
+                "modes_host_whitelist_check", "modes_host_cpu_budget", "modes_host_classify", "modes_host_resolve_spec", "modes_host_set_stats", "modes_host_resolve_raw_pieces",
                 "modes_tracker_create", "modes_tracker_destroy", "modes_tracker_receive", "modes_tracker_expire",
                 "modes_tracker_count", "modes_tracker_get", "modes_tracker_reference", "modes_tracker_json", "modes_format_sbs")
 
@@ -275,6 +279,9 @@ def host_lib():
         L.modes_host_resolve_raw_spec.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_uint64,
                                                   C.POINTER(C.c_uint64), C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.modes_host_resolve_raw_spec.restype = C.c_uint64
+        L.modes_host_resolve_raw_pieces.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(TextPiece), C.c_uint32,
+                                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_int]
+        L.modes_host_resolve_raw_pieces.restype = C.c_uint64
         L.modes_host_resolve_spec.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, SINK_FN, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_uint64, C.POINTER(C.c_uint64)]
         L.modes_host_resolve_spec.restype = C.c_uint64

@@ -584,7 +584,6 @@ int run_ranks(const Options &opt, double t_start) {
     modes_host *probe = rr ? modes_host_create(&hcfg) : nullptr;              // (--resolve-on-ranks: checks logged answers against a rebuilt state)
     Sink sink{&opt, host, {}, (rank == 0 && opt.sbs) ? modes_tracker_create() : nullptr};
     const bool raw_fast = opt.raw && !opt.stats && !opt.sbs && !opt.raw_net && !opt.onlyaddr;
-    std::vector<char> rawbuf;
     uint64_t n_messages_out = 0;
     const double t_ready = now_s();
 
@@ -691,6 +690,9 @@ int run_ranks(const Options &opt, double t_start) {
         modes_host_whitelist_guess(host, &recs, &nrec, 1, me.guess, opt.resolve_threads);
         if (rank == 0) rr_head->now[l] = feed ? (int64_t)time(nullptr) : 0;   // one clock per round: rank 0's (a live stream: dump1090.c:913,924)
         me.guess_seq.store(qq + 1, std::memory_order_release);
+#ifdef MODES_TEST_HOOKS                                                          // (stub builds: a rank that dies between its guess and its final tables)
+        if (const char *die = getenv("MODES_RR_DIE"); die && atoi(die) == rank && strchr(die, ':') && (uint64_t)atoll(strchr(die, ':') + 1) == qq) raise(SIGKILL);
+#endif
         // the state the round starts from: every earlier round, final on every rank
         for (; rr_applied < qq; rr_applied++)
             for (int r = 0; r < N; r++) {
@@ -845,12 +847,12 @@ int run_ranks(const Options &opt, double t_start) {
         const uint64_t *cands = nullptr;
         uint64_t ncand = 0;
         if (opt.stats && G.candidates(g, (uint32_t)l, &cands, &ncand) != MODES_OK) { fail_rank("gather", G.last_error(g)); return; }
-        if (raw_fast) {
-            const uint64_t cap = nrec * 62 + 64;
-            if (rawbuf.size() < cap) rawbuf.resize(cap);
-            uint64_t nb = 0;
-            n_messages_out += modes_host_resolve_raw_mt(host, recs, nrec, rawbuf.data(), rawbuf.size(), &nb, opt.resolve_threads);
-            sink.out.assign(rawbuf.data(), (size_t)nb);
+        if (raw_fast) {                                                      // the listing goes out from where the resolve's threads wrote it
+            modes_text_piece pieces[80];
+            uint32_t np = 0;
+            n_messages_out += modes_host_resolve_raw_pieces(host, &recs, &nrec, 1, pieces, 80, &np, nullptr, opt.resolve_threads);
+            for (uint32_t i = 0; i < np; i++) fwrite(pieces[i].base, 1, (size_t)pieces[i].len, out);
+            if (np) fflush(out);
         } else
             n_messages_out += modes_host_resolve(host, recs, nrec, cands, ncand, on_message, &sink);
         if (!sink.out.empty()) {
@@ -1122,7 +1124,6 @@ int main(int argc, char **argv) {
     uint64_t n_messages_out = 0;
 
     const bool raw_fast = opt.raw && !opt.stats && !opt.sbs && !opt.raw_net && !opt.onlyaddr;
-    std::vector<char> rawbuf;
     std::thread resolver([&] {
         for (uint64_t b = 0;; b++) {
             {
@@ -1140,13 +1141,14 @@ int main(int argc, char **argv) {
                 return;
             }
             if (live) modes_host_set_time(host, (int64_t)time(nullptr));          // dump1090.c:913,924
-            if (raw_fast) {                                                       // the --raw listing of a long batch, several threads
-                const uint64_t cap = res.n_records * 62 + 64;
-                if (rawbuf.size() < cap) rawbuf.resize(cap);
-                uint64_t nb = 0;
-                n_messages_out += modes_host_resolve_raw_mt(host, res.records, res.n_records, rawbuf.data(), rawbuf.size(), &nb,
-                                                            opt.resolve_threads);
-                sink.out.assign(rawbuf.data(), (size_t)nb);
+            if (raw_fast) {                                                       // the --raw listing of a long batch, several threads;
+                modes_text_piece pieces[80];                                      // it goes out from where they wrote it
+                uint32_t np = 0;
+                const modes_record *recs = res.records;
+                const uint64_t nrec = res.n_records;
+                n_messages_out += modes_host_resolve_raw_pieces(host, &recs, &nrec, 1, pieces, 80, &np, nullptr, opt.resolve_threads);
+                for (uint32_t i = 0; i < np; i++) fwrite(pieces[i].base, 1, (size_t)pieces[i].len, stdout);
+                if (np) fflush(stdout);
             } else
             n_messages_out += modes_host_resolve(host, res.records, res.n_records, res.candidates, res.n_candidates, on_message, &sink);
             if (!sink.out.empty()) {

@@ -2658,10 +2658,11 @@ int modes_gpu_detect(modes_gpu *ctx, const modes_gpu_span *span, void *stream) {
 // to time so that a faulted kernel is an error, not a hang.
 static int wait_results(modes_gpu *ctx) {
     volatile uint32_t *seq = &ctx->h_hdr->seq;
-    // The word is polled hot for the length of a short call (~0.2 ms: the 1 GiB step), then politely: a host has one such
-    // thread per context in flight and per rank, next to its resolver's pool, and a container's CPU quota counts a spinning
-    // thread like a working one (the leases hold a 256-thread host to 16 CPUs) - a call that takes milliseconds
-    // is waited for in 20 us naps, which cost it nothing it could notice.
+    // The word is polled hot for as long as a call of the throughput workloads can take (2 ms: a nap oversleeps by 50 us and more,
+    // and with naps from 0.25 ms on the 1 GiB low-SNR step went from 0.236 to 0.269 ms), then politely: a host has one such thread
+    // per context in flight and per rank, next to its resolver's pool, and a container's CPU quota counts a spinning thread like
+    // a working one (the leases hold a 256-thread host to 16 CPUs) - a host that waits for a live stream's next
+    // buffer, or for a call of many GiB, does so in 20 us naps.
     using clk = std::chrono::steady_clock;
     clk::time_point t0{};
     uint32_t naps = 0;
@@ -2670,8 +2671,8 @@ static int wait_results(modes_gpu *ctx) {
         if ((spins & 0x3FF) == 0) {
             if (spins == 0x400) t0 = clk::now();
             const double waited_us = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
-            if (waited_us > 250.0) {
-                if ((++naps & 63) == 0) {                                   // every ~1.5 ms: has the stream failed, or ended without a word?
+            if (waited_us > 2000.0) {
+                if ((++naps & 15) == 0) {                                   // every ~1 ms: has the stream failed, or ended without a word?
                     const hipError_t q = hipStreamQuery(ctx->tail_stream);
                     if (q == hipSuccess) {                                  // everything on the stream has run
                         if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == ctx->seq) break;

@@ -85,6 +85,7 @@ struct modes_host {
     int64_t now_s = 0;                    // never advanced by a file run: nothing expires (the default)
     bool have_candidates = false;
     struct IcaoLog *log = nullptr;        // set while a piece of a batch is resolved speculatively (modes_host_resolve_raw_mt)
+    bool mt_guess = false;                // the multi-threaded resolve runs its guess pass (set by the first piece that had to be resolved again)
     bool lean = false;                    // set by the --raw resolvers: the sink reads msg / msgbits / crcok only, so the decode stops
                                           // when those (and the whitelist) are settled - no altitude, squawk, position, velocity fields
 };
@@ -743,11 +744,16 @@ struct Piece {
         return true;
     }
 };
-// The pieces of the process (grow-only; used under the pool's turn).
+// The pieces of the CALLING THREAD (grow-only): a resolver thread keeps its pieces' text buffers, logs and states from call to call,
+// and the listing modes_host_resolve_raw_pieces leaves in them stays put until that thread's next multi-threaded resolve.
 std::vector<std::unique_ptr<Piece>> &piece_store() {
-    static std::vector<std::unique_ptr<Piece>> store;
+    static thread_local std::vector<std::unique_ptr<Piece>> store;
     return store;
 }
+struct PieceList {                        // modes_host_resolve_raw_pieces: where the caller wants the pieces named
+    modes_text_piece *out;
+    uint32_t cap, n;
+};
 
 inline uint32_t attempt_class(const modes_attempt &a, uint32_t cfg_mask, uint32_t cfg_want, uint32_t fix, uint32_t aggressive) {
     if ((a.cls & cfg_mask) == cfg_want) return a.cls;
@@ -791,8 +797,9 @@ void run_piece(Piece &p) {
 
 // `outer` (modes_host_resolve_raw_spec; else null): the log of the CALL as a whole - the slots it wrote, and the lookups
 // that were answered from the state `h` had on entry.
+// `pl` (modes_host_resolve_raw_pieces; then out == nullptr): the listing stays in the pieces' own buffers, *pl names them.
 static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
-                                     char *out, uint64_t cap, uint64_t *nbytes, int threads, IcaoLog *outer) {
+                                     char *out, uint64_t cap, uint64_t *nbytes, int threads, IcaoLog *outer, PieceList *pl = nullptr) {
     uint64_t nrecs = 0;
     for (uint32_t g = 0; g < nsegs; g++) nrecs += seg_nrecs[g];
     // threads < 0: exactly -threads pieces however short the list and however few CPUs (tests); otherwise at least 2048 records
@@ -806,6 +813,21 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
         uint64_t msgs = 0, total = 0;
         struct Log { modes_host *h; IcaoLog *was; ~Log() { h->log = was; } } keep{h, h->log};
         if (outer) h->log = outer;                                                // (the log's `written` carries over from segment to segment)
+        if (pl) {                                                                 // the whole listing is one piece, in this thread's first buffer
+            std::vector<std::unique_ptr<Piece>> &store = piece_store();
+            if (store.empty()) store.emplace_back(new Piece);
+            Piece &p = *store[0];
+            pl->n = 0;
+            if (!p.own_text(nrecs * (h->cfg.check_crc ? 31 : 62) + 64)) { if (nbytes) *nbytes = 0; return 0; }
+            for (uint32_t g = 0; g < nsegs; g++) {
+                uint64_t nb = 0;
+                msgs += modes_host_resolve_raw(h, segs[g], seg_nrecs[g], nullptr, 0, p.text + total, p.cap - total, &nb);
+                total += nb;
+            }
+            if (total && pl->cap) { pl->out[0] = modes_text_piece{p.text, total}; pl->n = 1; }
+            if (nbytes) *nbytes = total;
+            return msgs;
+        }
         for (uint32_t g = 0; g < nsegs; g++) {
             uint64_t nb = 0;
             msgs += modes_host_resolve_raw(h, segs[g], seg_nrecs[g], nullptr, 0, out ? out + total : nullptr, cap > total ? cap - total : 0, &nb);
@@ -834,6 +856,7 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
         }
     }
     const size_t P = cuts.size();
+    if (P > 64 && pl) return one_thread();                                        // (pieces of several calls would share this thread's buffers)
     if (P > 64) {                                                                 // many short segments: fewer, longer pieces are not worth the code
         uint64_t msgs = 0, total = 0;
         for (uint32_t g = 0; g < nsegs; g++) {
@@ -845,8 +868,8 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
         return msgs;
     }
     WorkerPool &pool = WorkerPool::instance();
-    std::unique_lock<std::mutex> turn(pool.turn());                               // the pieces below belong to the process
-    std::vector<std::unique_ptr<Piece>> &pieces = piece_store();
+    std::unique_lock<std::mutex> turn(pool.turn());                               // one parallel loop at a time in the process
+    std::vector<std::unique_ptr<Piece>> &pieces = piece_store();                  // (this thread's)
     while (pieces.size() < P) pieces.emplace_back(new Piece);
     const bool dbg = getenv("MODES_HOST_MT_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -866,17 +889,22 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
     }
     // ONE parallel region: every piece lists what its clean frames would write; the state a piece starts from is the
     // batch's initial state with the lists of the pieces before it applied in order; then the speculative resolve
+    // The guess costs a pass over the records (a third of the call's memory traffic) and only pays where later pieces ASK the
+    // whitelist about addresses earlier pieces write: a host whose pieces have never been caught with a wrong answer starts every
+    // piece from the batch's own start state (streams of DF11 / DF17 squitters ask nothing); the first wrong answer - resolved
+    // again below, like any other - switches the guesses on for the rest of the host's life (traffic with DF0/4/5/20/21 replies).
+    const bool guessing = h->mt_guess || getenv("MODES_HOST_MT_GUESS") != nullptr;
     modes_host start = *h;
     start.log = nullptr;
     start.lean = false;
     pool.run(P, [&](size_t t) {
         Piece &p = *pieces[t];
         if (dbg) p.t_begin = now();
-        guess_piece(p, start.cfg);
+        if (guessing) guess_piece(p, start.cfg);
         p.guessed.store(1, std::memory_order_release);
         if (dbg) p.t_guessed = now();
         p.host = start;
-        for (size_t k = 0; k < t; k++) {
+        for (size_t k = 0; guessing && k < t; k++) {
             const Piece &q = *pieces[k];
             for (int spin = 0; !q.guessed.load(std::memory_order_acquire); spin++)
                 if (spin > 64) std::this_thread::yield();
@@ -903,6 +931,7 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
             p.host.cfg = cfg;
             run_piece(p);
             reruns++;
+            h->mt_guess = true;
         }
         // true state after the piece: its writes over the true state before it
         for (uint32_t s2 = 0; s2 < kIcaoSlots; s2++)
@@ -953,6 +982,11 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
     // step is 0.4 ms on one thread
     if (out) pool.run(P, [&](size_t t) { if (take[t] && pieces[t]->text != out + at[t]) memcpy(out + at[t], pieces[t]->text, (size_t)take[t]); });
     if (out && stored < cap) out[stored] = 0;
+    if (pl) {                                                                     // no copy at all: the pieces are the listing
+        pl->n = 0;
+        for (size_t t = 0; t < P; t++)
+            if (pieces[t]->nbytes && pl->n < pl->cap) pl->out[pl->n++] = modes_text_piece{pieces[t]->text, pieces[t]->nbytes};
+    }
     if (nbytes) *nbytes = total;
     if (dbg) {
         double wake = 0, guess = 0, wait = 0, run = 0;
@@ -976,6 +1010,16 @@ uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint
 uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
                                     char *out, uint64_t cap, uint64_t *nbytes, int threads) {
     return resolve_raw_mtv_impl(h, segs, seg_nrecs, nsegs, out, cap, nbytes, threads, nullptr);
+}
+
+// The listing where its pieces were written: nothing is gathered into one buffer (a third of the multi-threaded call's memory
+// traffic) - a host that prints hands the pieces to fwrite / writev in order.
+uint64_t modes_host_resolve_raw_pieces(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
+                                       modes_text_piece *pieces, uint32_t piece_cap, uint32_t *npieces, uint64_t *nbytes, int threads) {
+    PieceList pl{pieces, pieces ? piece_cap : 0, 0};
+    const uint64_t msgs = resolve_raw_mtv_impl(h, segs, seg_nrecs, nsegs, nullptr, 0, nbytes, threads, nullptr, &pl);
+    if (npieces) *npieces = pl.n;
+    return msgs;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -152,9 +152,11 @@ class HostResolver:
         if candidates is not None:
             candidates = np.ascontiguousarray(candidates, dtype=np.uint64)
             cptr, ncand = candidates.ctypes.data, candidates.size
+        if (threads > 1 or threads < 0) and candidates is None and not text:
+            return self._pieces([records], threads)[0], None        # nothing to hand back: the listing stays in the library's pieces
         buf = self._text_buffer(62 * records.size + 64)   # at most two 31-byte lines per record
         nbytes = C.c_uint64()
-        if threads > 1 and candidates is None:
+        if (threads > 1 or threads < 0) and candidates is None:
             n = self._lib.modes_host_resolve_raw_mt(self._h, records.ctypes.data, records.size, buf, len(buf),
                                                     C.byref(nbytes), threads)
         else:
@@ -168,13 +170,20 @@ class HostResolver:
         segs = [np.ascontiguousarray(a, dtype=N.RECORD_DTYPE) for a in segments if len(a)]
         if not segs:
             return 0, (b"" if text else None)
-        total = sum(a.size for a in segs)
-        buf = self._text_buffer(62 * total + 64)
+        n, pieces = self._pieces(segs, max(1, threads))
+        return n, (b"".join(C.string_at(b, ln) for b, ln in pieces) if text else None)
+
+    def _pieces(self, segs, threads):
+        """modes_host_resolve_raw_pieces: (lines, [(address, length) of the listing's pieces in stream order]) - the listing stays where
+        the resolve's threads wrote it (no gathering copy); valid until this thread's next multi-threaded listing call."""
         ptrs = (C.c_void_p * len(segs))(*[a.ctypes.data for a in segs])
         lens = (C.c_uint64 * len(segs))(*[a.size for a in segs])
-        nbytes = C.c_uint64()
-        n = self._lib.modes_host_resolve_raw_mtv(self._h, ptrs, lens, len(segs), buf, len(buf), C.byref(nbytes), max(1, threads))
-        return int(n), (C.string_at(buf, nbytes.value) if text else None)
+        out = (N.TextPiece * 80)()
+        npieces, nbytes = C.c_uint32(), C.c_uint64()
+        n = self._lib.modes_host_resolve_raw_pieces(self._h, ptrs, lens, len(segs), out, len(out), C.byref(npieces), C.byref(nbytes), threads)
+        pieces = [(out[i].base, out[i].len) for i in range(npieces.value)]
+        assert sum(ln for _, ln in pieces) == nbytes.value
+        return int(n), pieces
 
     # ---- resolve on the ranks that demodulated (include/modes_host.h; distributed.RankResolve is the protocol) ----
     @staticmethod

@@ -190,6 +190,16 @@ uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint
 uint64_t modes_host_resolve_raw_mtv(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
                                     char *out, uint64_t cap, uint64_t *nbytes, int threads);
 
+/* The same multi-threaded resolve WITHOUT the gathering copy: the listing stays where its pieces were written, pieces[0 .. *npieces)
+ * name them in stream order (at most 65; memory of the library, valid until the CALLING THREAD's next modes_host_resolve_raw_mt* /
+ * _pieces call) - for fwrite / writev in order.  *nbytes = length of the whole listing.  Returns the number of lines. */
+typedef struct {
+    const char *base;
+    uint64_t    len;
+} modes_text_piece;
+uint64_t modes_host_resolve_raw_pieces(modes_host *h, const modes_record *const *segs, const uint64_t *seg_nrecs, uint32_t nsegs,
+                                       modes_text_piece *pieces, uint32_t piece_cap, uint32_t *npieces, uint64_t *nbytes, int threads);
+
 /* ---- resolve on the ranks that demodulated ------------------------------------------------------
  * An N-GPU host whose rank 0 would otherwise resolve every rank's records (dump1090.c:896-925, :1183-1210: the
  * whitelist is the one piece of state that crosses buffers) can leave each list where it is: a rank resolves its

@@ -441,6 +441,9 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     assert p.stdout.count(b"--stats / --onlyaddr / --raw-net --ranks") == 8 and b"--ifile - --stats --ranks 3 --resolve-on-ranks: md5 bc3d1c04" in p.stdout
     assert p.stdout.count(b"--stats --resolve-on-ranks --ranks") == 4
     assert p.stdout.count(b"fails in its GPU call") == 2 and p.stdout.count(b": status 1") == 2       # a failing rank ends the job there too
+    # ... and a rank KILLED between publishing its guess and its final tables (nobody sets `failed`): the watchdog / the parent-death signal
+    # end the job within two seconds, whichever rank it is (the script checks status and time)
+    assert p.stdout.count(b"between guess and final: status") == 3
 
 
 def test_c_host_loop_replays_the_file_like_the_reference():
@@ -456,6 +459,8 @@ def test_c_host_loop_replays_the_file_like_the_reference():
     p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh"), "loop-host"], capture_output=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout[-800:], p.stderr[-800:])
     assert b"first lap = the plain listing" in p.stdout and b"--clean-exit: md5 4a81758c8bec5e45ffa8541c5622938a" in p.stdout
+    # --clean-exit where it matters: 1 GiB of mapping handed back batch by batch, six lanes allocated into the holes, under ASan
+    assert b"1 GiB sparse file + capture, 64 batches over six lanes, under ASan: 284 lines" in p.stdout
     if os.path.exists(os.path.join(root, "oracle", "_ref", "dump1090_ref")):
         assert b"--loop == oracle/_ref/dump1090_ref --loop" in p.stdout
 

@@ -38,6 +38,18 @@ def lean_listing(recs, flags, threads=1):
     return out
 
 
+def pieces_listing(recs, flags, threads):
+    """modes_host_resolve_raw_pieces: the listing left in the pieces' own buffers (no gathering copy), joined here; the list cut in
+    two segments at a buffer boundary where it has one."""
+    r = HostResolver(**flags)
+    cut = int(np.searchsorted(recs["block"], recs["block"][recs.size // 2])) if recs.size else 0
+    segs = [recs[:cut], recs[cut:]] if 0 < cut < recs.size else [recs]
+    n, text = r.raw_listing_segments(segs, threads=threads)
+    out = (n, text, r.stats(), r.whitelist())
+    r.close()
+    return out
+
+
 def same(a, b, ctx):
     assert a[0] == b[0] and a[1] == b[1], ctx
     assert a[2] == b[2], ctx
@@ -65,6 +77,15 @@ def test_lean_listing_equals_general_resolve(golden, streams, case):
             same(lean_listing(other, flags), want, (case, fs, "foreign class", fix, aggr))
         for th in (-2, -5):
             same(lean_listing(cls, flags, threads=th), want, (case, fs, "pieces", th))
+            same(pieces_listing(cls, flags, th), want, (case, fs, "pieces left in place", th))
+        # (a host starts every piece from the batch's own start state until one is caught with a wrong answer; MODES_HOST_MT_GUESS: the
+        #  guess pass from the first call on - both are exact)
+        os.environ["MODES_HOST_MT_GUESS"] = "1"
+        try:
+            same(lean_listing(cls, flags, threads=-4), want, (case, fs, "pieces, guessing"))
+            same(pieces_listing(recs, flags, -3), want, (case, fs, "pieces left in place, guessing, unclassified"))
+        finally:
+            del os.environ["MODES_HOST_MT_GUESS"]
 
 
 def test_class_byte_against_the_decoder(streams):
@@ -149,6 +170,17 @@ def test_iid_and_ap_frames_through_the_lean_resolve():
     same(lean_listing(recs, flags), want, "unclassified")
     same(lean_listing(cls, flags), want, "classified")
     same(lean_listing(cls, flags, threads=-3), want, "pieces")
+    same(pieces_listing(cls, flags, -3), want, "pieces left in place")
+    # one host, the same batch twice: the second piece of the first call starts without a guess, is caught with a wrong answer (aircraft A's
+    # DF17 lies in the piece before it) and resolved again; from then on the host guesses - both calls print the sequential listing
+    r = HostResolver(**flags)
+    first = r.raw_listing(cls, None, threads=-3)
+    r2 = HostResolver(**flags)
+    assert first == r2.raw_listing(cls, None, threads=1)
+    for _ in range(2):
+        a, b = r.raw_listing(cls, None, threads=-3), r2.raw_listing(cls, None, threads=1)      # (the whitelist now knows A from the start)
+        assert a == b and a[0] >= first[0]
+    r.close(), r2.close()
 
 
 def test_lean_listing_into_a_short_buffer(streams):

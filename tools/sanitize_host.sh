@@ -258,6 +258,18 @@ PY
         echo "   rank ${bad%%:*} fails in GPU call ${bad##*:}: exit status $rc"
         [ "$rc" = 1 ] || { cat $D/fail.err; exit 1; }
     done
+    # a rank KILLED between its guess and its final tables (round 6): its peers wait for final_seq in shared memory, nobody
+    # sets `failed` - rank 0's watchdog (or, rank 0 being the one, the parent-death signal) must end the job within a second
+    for die in 1:0 2:0 0:0; do
+        set +e
+        t0=$(date +%s.%N)
+        MODES_RR_DIE=$die timeout 20 $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw --ranks 3 --batch-blocks 1 --resolve-on-ranks > /dev/null 2> $D/fail.err
+        rc=$?
+        dt=$(python -c "import time,sys; print('%.2f' % (time.time() - float(sys.argv[1])))" $t0)
+        set -e
+        echo "   resolving on the ranks, rank ${die%%:*} killed in round ${die##*:} between guess and final: status $rc after $dt s"
+        [ "$rc" != 0 ] && [ "$rc" != 124 ] && python -c "import sys; sys.exit(0 if float(sys.argv[1]) < 2.0 else 1)" $dt || { cat $D/fail.err; exit 1; }
+    done
     # the same under --resolve-on-ranks: the peers wait for that rank's tables in shared memory - they must see the failure and end
     for bad in 0:1 1:0; do
         set +e
@@ -302,6 +314,27 @@ PY
         head -c $(wc -c < $D/one.txt) $D/many.txt | cmp - $D/one.txt || { echo "   --clean-exit, 48 laps in one file: the first lap differs"; exit 1; }
         echo "   --clean-exit, 48 laps as one file, --batch-blocks $bb: $many lines, status 0"
     done
+    # ... and at a size where it MATTERS: a 1 GiB sparse file (zeros: no preamble anywhere) with the capture at its end, under
+    # AddressSanitizer, 64 batches of 16 MiB over six lanes that are set up while the stream already runs - the unmapper has handed ~1 GiB of
+    # the mapping back by the time the last lanes' buffers, the output and the pools are allocated (some of them INTO the freed range), and the
+    # orderly teardown unmaps what is left.  Unmapping the whole original range there would pull memory from under its owners: ASan or a
+    # segfault says so.  The output must be that of the default exit path (which unmaps nothing).
+    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -fsanitize=address -fno-omit-frame-pointer -Iinclude -o $D/dump1090_amd_asan dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+        dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp $D/modes_oracle.o -lpthread -lm -ldl -rdynamic
+    python - <<'PY'
+import numpy as np
+pad = np.fromfile("/tmp/modes_loop_host/pad.bin", dtype=np.uint8)
+with open("/tmp/modes_loop_host/sparse.bin", "wb") as f:
+    f.truncate(1 << 30)
+    f.seek((1 << 30) - pad.size)
+    f.write(pad.tobytes())
+PY
+    $D/dump1090_amd_stub --ifile $D/sparse.bin --raw --batch-blocks 64 > $D/sparse_want.txt
+    ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 $D/dump1090_amd_asan --ifile $D/sparse.bin --raw --clean-exit --batch-blocks 64 --depth 3 --gpu-list 0,0 > $D/sparse_got.txt \
+        || { echo "   --clean-exit on a 1 GiB sparse file under ASan: status $?"; exit 1; }
+    cmp $D/sparse_want.txt $D/sparse_got.txt || { echo "   --clean-exit on a 1 GiB sparse file: the output differs from the default exit path's"; exit 1; }
+    echo "   --clean-exit, 1 GiB sparse file + capture, 64 batches over six lanes, under ASan: $(wc -l < $D/sparse_got.txt) lines = the default exit path's, status 0"
+    rm -f $D/sparse.bin
     n=$(( $(wc -c < $D/one.txt) * 5 / 2 ))
     set +e
     for bb in 1 3 512; do
