@@ -422,7 +422,7 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     assert p.stdout.count(b"fails in GPU call") == 2 and p.stdout.count(b": exit status 1") == 7      # (+ --resolve-on-ranks --sbs, refused)
     # --stats through the gather's second list (every rank's preamble positions on rank 0): the reference's nine lines for N = 1, 2, 3;
     # a list that outgrows its buffers fails the job
-    assert p.stdout.count(b"md5 bc3d1c04b24f4989f0fc4a2d1f45abdd") == 8        # N = 1, 2, 3 x two batch sizes, N = 8, and a pipe with N = 2
+    assert p.stdout.count(b"md5 bc3d1c04b24f4989f0fc4a2d1f45abdd") == 9        # N = 1, 2, 3 x two batch sizes, N = 8, a pipe with N = 2, and (round 6) a pipe with N = 3 resolving on the ranks
     assert b"--raw --ranks 8 --batch-blocks 1: md5 4a81758c" in p.stdout              # eight processes, five of them without a batch
     assert b"--stats with 8 positions of room: exit status 1" in p.stdout
     # round 5: a pipe and --loop through --ranks (rank 0 reads, shared-memory slots): the pipe's listing for N = 1, 2, 3 x two batch sizes
