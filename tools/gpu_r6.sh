@@ -24,6 +24,12 @@ for s in "$@"; do
     e2e)       run e2e_cli 900 python tools/e2e_cli.py 8 ;;
     pipe)      run pipe_cadence 600 python -m pytest tests/test_gpu_parity.py tests/test_dropin.py -m gpu -q -x -p no:cacheprovider -k "pipe or paced" ;;
     fuzz)      run fuzz_parity 900 python tools/fuzz_parity.py 5000 600 ;;
+    threads_ab) for rt in 2 4 8 15 2 4 8 15; do
+                 python bench.py --workload frames --steps 40 --no-end-to-end --no-live-traffic --no-cpu-baseline --no-ceiling --resolve-threads $rt 2>/dev/null | grep '^{' | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline())
+print('frames --resolve-threads $rt: ms_per_step %.4f resolve_per_step %.4f fetch %.4f' % (d['ms_per_step'], d['host_ms_per_call']['resolve_per_step'], d['host_ms_per_call']['fetch']))"
+               done > "$O/resolve_threads_ab.txt" 2>&1; cat "$O/resolve_threads_ab.txt" ;;
     *)         echo "unknown step $s" ;;
   esac
 done

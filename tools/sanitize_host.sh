@@ -10,6 +10,8 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd "$R"
 CLANG=/opt/rocm/lib/llvm/bin/clang++
+# the C host: the option parser and its three hosts (dump1090_amd/csrc/Makefile HOST_SRCS)
+HOST_SRCS="dump1090_amd/csrc/main.cpp dump1090_amd/csrc/host_single.cpp dump1090_amd/csrc/host_ranks.cpp dump1090_amd/csrc/host_ranks_rccl.cpp dump1090_amd/csrc/host_ranks_shared.cpp"
 RT=$(ls -d /opt/rocm/lib/llvm/lib/clang/*/lib/linux | head -1)
 # ubsan / asan replace dump1090_amd/libmodes_host.so and the core shim by sanitizer builds: the normal ones are put back
 # whatever happens - through a rename, never by writing into the file (a process that has the library mapped, e.g. the pytest
@@ -67,7 +69,7 @@ PY
 run_tsan_host() {
     echo "== tsan-host =="
     gcc -O1 -g -fsanitize=thread -c -o /tmp/modes_oracle_tsan.o oracle/modes_oracle.c
-    g++ -O1 -g -std=c++17 -fsanitize=thread -Iinclude -o /tmp/dump1090_amd_tsan dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+    g++ -O1 -g -std=c++17 -fsanitize=thread -Iinclude -o /tmp/dump1090_amd_tsan $HOST_SRCS tests/native/gpu_stub.cpp \
         dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp /tmp/modes_oracle_tsan.o -lpthread -lm -ldl
     # the reference's md5s of BASELINE.md section 4 (--raw, --stats, --onlyaddr)
     check() { want=$1; shift
@@ -91,7 +93,7 @@ run_ranks_host() {
     D=/tmp/modes_ranks_host
     mkdir -p $D
     gcc -O1 -g -c -o $D/modes_oracle.o oracle/modes_oracle.c
-    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -Iinclude -o $D/dump1090_amd_stub dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -Iinclude -o $D/dump1090_amd_stub $HOST_SRCS tests/native/gpu_stub.cpp \
         dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp $D/modes_oracle.o -lpthread -lm -ldl -rdynamic
     g++ -O1 -g -std=c++17 -fPIC -shared -Iinclude -o $D/libmodes_gather.so tests/native/gather_stub.cpp -lpthread -lrt
     for n in 1 2 3; do for bb in 1 2 5; do
@@ -289,7 +291,7 @@ run_loop_host() {
     D=/tmp/modes_loop_host
     mkdir -p $D
     gcc -O1 -g -c -o $D/modes_oracle.o oracle/modes_oracle.c
-    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -Iinclude -o $D/dump1090_amd_stub dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -Iinclude -o $D/dump1090_amd_stub $HOST_SRCS tests/native/gpu_stub.cpp \
         dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp $D/modes_oracle.o -lpthread -lm -ldl -rdynamic
     python - <<'PY'
 import sys
@@ -319,7 +321,7 @@ PY
     # the mapping back by the time the last lanes' buffers, the output and the pools are allocated (some of them INTO the freed range), and the
     # orderly teardown unmaps what is left.  Unmapping the whole original range there would pull memory from under its owners: ASan or a
     # segfault says so.  The output must be that of the default exit path (which unmaps nothing).
-    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -fsanitize=address -fno-omit-frame-pointer -Iinclude -o $D/dump1090_amd_asan dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -fsanitize=address -fno-omit-frame-pointer -Iinclude -o $D/dump1090_amd_asan $HOST_SRCS tests/native/gpu_stub.cpp \
         dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp $D/modes_oracle.o -lpthread -lm -ldl -rdynamic
     python - <<'PY'
 import numpy as np
@@ -363,7 +365,7 @@ run_pipe_host() {
     D=/tmp/modes_pipe_host
     mkdir -p $D
     gcc -O1 -g -c -o $D/modes_oracle.o oracle/modes_oracle.c
-    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -Iinclude -o $D/dump1090_amd_stub dump1090_amd/csrc/main.cpp tests/native/gpu_stub.cpp \
+    g++ -O1 -g -std=c++17 -DMODES_TEST_HOOKS -Iinclude -o $D/dump1090_amd_stub $HOST_SRCS tests/native/gpu_stub.cpp \
         dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp $D/modes_oracle.o -lpthread -lm -ldl -rdynamic
     g++ -O1 -g -std=c++17 -fPIC -shared -Iinclude -o $D/libmodes_gather.so tests/native/gather_stub.cpp -lpthread -lrt
     check() { what=$1; want=$2; shift 2
