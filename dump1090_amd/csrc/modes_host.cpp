@@ -802,9 +802,11 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
                                      char *out, uint64_t cap, uint64_t *nbytes, int threads, IcaoLog *outer, PieceList *pl = nullptr) {
     uint64_t nrecs = 0;
     for (uint32_t g = 0; g < nsegs; g++) nrecs += seg_nrecs[g];
-    // threads < 0: exactly -threads pieces however short the list and however few CPUs (tests); otherwise at least 2048 records
-    // per thread and no more threads than the process may run at once
-    const uint64_t kMinPiece = threads < 0 ? 1 : 2048;
+    // threads < 0: exactly -threads pieces however short the list and however few CPUs (tests); otherwise at least 16384 records
+    // per thread - 70 us of work at 4.3 ns a record, against the ~50 us it takes to get a sleeping worker going: with 2048 a
+    // 35,000-record list woke 15 threads for 10 us each, and the 8 GiB leg's step was 3-5 % slower with 8-15 resolver threads
+    // than with 2 (profiles/r09/resolve_threads_ab.txt) - and no more threads than the process may run at once
+    const uint64_t kMinPiece = threads < 0 ? 1 : 16384;
     int T = threads < 0 ? -threads : threads;
     if (threads >= 0 && T > modes_host_cpu_budget()) T = modes_host_cpu_budget();
     T = T < 1 ? 1 : (T > 64 ? 64 : T);
@@ -897,23 +899,30 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
     modes_host start = *h;
     start.log = nullptr;
     start.lean = false;
-    pool.run(P, [&](size_t t) {
-        Piece &p = *pieces[t];
-        if (dbg) p.t_begin = now();
-        if (guessing) guess_piece(p, start.cfg);
-        p.guessed.store(1, std::memory_order_release);
-        if (dbg) p.t_guessed = now();
-        p.host = start;
-        for (size_t k = 0; guessing && k < t; k++) {
-            const Piece &q = *pieces[k];
-            for (int spin = 0; !q.guessed.load(std::memory_order_acquire); spin++)
-                if (spin > 64) std::this_thread::yield();
-            for (uint32_t sl = 0; sl < kIcaoSlots; sl++)
-                if (q.guess_set[sl]) { p.host.icao[sl] = q.guess_addr[sl]; p.host.icao_seen[sl] = start.now_s; }
+    // (more pieces than threads - many segments: a worker takes pieces w, w + W, ...: never more than T threads at work)
+    const size_t W = std::min(P, (size_t)T);
+    pool.run(W, [&](size_t w) {
+        for (size_t t = w; t < P; t += W) {                                       // every guess of this worker first: nobody waits for a piece
+            Piece &p = *pieces[t];                                                // whose worker is still resolving an earlier one
+            if (dbg) p.t_begin = now();
+            if (guessing) guess_piece(p, start.cfg);
+            p.guessed.store(1, std::memory_order_release);
+            if (dbg) p.t_guessed = now();
         }
-        if (dbg) p.t_started = now();
-        run_piece(p);
-        if (dbg) p.t_done = now();
+        for (size_t t = w; t < P; t += W) {
+            Piece &p = *pieces[t];
+            p.host = start;
+            for (size_t k = 0; guessing && k < t; k++) {
+                const Piece &q = *pieces[k];
+                for (int spin = 0; !q.guessed.load(std::memory_order_acquire); spin++)
+                    if (spin > 64) std::this_thread::yield();
+                for (uint32_t sl = 0; sl < kIcaoSlots; sl++)
+                    if (q.guess_set[sl]) { p.host.icao[sl] = q.guess_addr[sl]; p.host.icao_seen[sl] = start.now_s; }
+            }
+            if (dbg) p.t_started = now();
+            run_piece(p);
+            if (dbg) p.t_done = now();
+        }
     });
     const double t2 = now();
     int reruns = 0;
@@ -980,7 +989,10 @@ static uint64_t resolve_raw_mtv_impl(modes_host *h, const modes_record *const *s
     }
     // the copies themselves on the workers (the first piece's text is in place): 12 MB for the 524,000 lines of a --gpus 8
     // step is 0.4 ms on one thread
-    if (out) pool.run(P, [&](size_t t) { if (take[t] && pieces[t]->text != out + at[t]) memcpy(out + at[t], pieces[t]->text, (size_t)take[t]); });
+    if (out) pool.run(W, [&](size_t w) {
+        for (size_t t = w; t < P; t += W)
+            if (take[t] && pieces[t]->text != out + at[t]) memcpy(out + at[t], pieces[t]->text, (size_t)take[t]);
+    });
     if (out && stored < cap) out[stored] = 0;
     if (pl) {                                                                     // no copy at all: the pieces are the listing
         pl->n = 0;

@@ -4,6 +4,7 @@ own thread.  bench.py drives it with the HIP Demodulator; tests/test_pipeline.py
 (gloo, world_size 2) with a stand-in detector fed by the oracle."""
 from __future__ import annotations
 
+import gc
 import queue
 import threading
 import time
@@ -385,6 +386,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     first_timed_call = warm * len(calls)
     timed_phase = (min(time_every, steps * len(calls)) - 1) % time_every
     t0_region = None
+    gc_was = False
     for step in range(warm + regions * steps):
         if step > warm and (step - warm) % steps == 0:          # a region ends here, the next one begins: the same bracket as at the very end
             for k in list(order):
@@ -405,6 +407,11 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                 e.wait()
             if resolver is not None:
                 resolver.drain()
+            # (no collector pauses inside the timed regions: a pass over the interpreter's objects is milliseconds - one region of five
+            #  read 0.2875 ms per step next to four at 0.214-0.217, profiles/r09/bench_line_gc.json; the loop allocates no cycles)
+            gc_was = gc.isenabled()
+            gc.collect()
+            gc.disable()
             sync_all()
             prof0 = [d.host_profile() for d in demods if hasattr(d, "host_profile")]
             if rr is not None:                                  # (its thread is idle: drained above)
@@ -481,6 +488,8 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     sync_all()
     t_end = time.perf_counter()
     region_elapsed.append(t_end - t0_region)
+    if gc_was:
+        gc.enable()
     # where the (last) region's final moments go (ms): the calls still in flight when the loop ends, the resolver, the final sync
     tail_ms = {"in_flight": round((t_adv - t_loop) * 1e3, 4), "resolver": round((t_drain - t_adv) * 1e3, 4),
                "sync": round((t_end - t_drain) * 1e3, 4)}

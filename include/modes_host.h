@@ -180,7 +180,8 @@ void modes_host_classify(const modes_host_config *cfg, modes_record *recs, uint6
  * buffer boundaries, the pieces are resolved speculatively and confirmed in order (modes_host.cpp) - byte-identical to
  * modes_host_resolve_raw without candidates.  For hosts whose one resolve thread would be the bottleneck: a
  * message-dense stream, or rank 0 of an N-GPU run that resolves N GPUs' records.  (threads < 0: exactly -threads
- * pieces however short the list is - for tests; otherwise a thread gets at least 2048 records.  The worker threads are created once per process.) */
+ * pieces however short the list is - for tests; otherwise a thread gets at least 16384 records and there are never more threads than
+ * modes_host_cpu_budget().  The worker threads are created once per process.) */
 uint64_t modes_host_resolve_raw_mt(modes_host *h, const modes_record *recs, uint64_t nrecs,
                                    char *out, uint64_t cap, uint64_t *nbytes, int threads);
 
