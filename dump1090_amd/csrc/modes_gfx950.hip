@@ -769,25 +769,48 @@ __device__ __forceinline__ AttemptFix wave_finish_attempt(modes_m128 bits, bool 
     return r;
 }
 
-// `maxfix` / `aggressive`: the context's repair policy - the class byte (include/modes_gfx950.h MODES_CLS_*, modes_classify) is the
-// part of decodeModesMessage's decisions that the wavefront holding the DF, the syndrome and the repair can make for the host.
-__device__ __forceinline__ void store_attempt(modes_attempt *out, modes_m128 bits, uint8_t errors, bool gate_ok, AttemptFix f,
-                                              int maxfix, int aggressive) {
-    uint8_t msg[14];
-    modes_bits_to_msg(bits, msg);
-#pragma unroll
-    for (int b = 0; b < 14; b++) out->msg[b] = msg[b];
-    out->errors = errors;
-    out->gate_ok = gate_ok ? 1 : 0;
-    out->nfix = f.nfix;
-    out->fixpos[0] = f.pos0;
-    out->fixpos[1] = f.pos1;
-    const uint32_t cls = modes_classify(df_of_bits(bits), errors, gate_ok ? 1u : 0u, f.syndrome, f.nfix, maxfix > 0 ? 1u : 0u,
-                                        aggressive ? 1u : 0u);
-    out->cls = (uint8_t)cls;
-    out->slot = (uint16_t)modes_class_slot(cls, msg[1], msg[2], msg[3], f.syndrome);
-    out->pad[0] = out->pad[1] = 0;
-    out->syndrome = f.syndrome;
+// The record, written by the whole wavefront: lane i computes BYTE i of the 64-byte modes_record from the wave-uniform results (lanes
+// 0-7 block and j; 8-35 attempt 0; 36-63 attempt 1 - msg by one shift and v_bfrev per byte, the class byte and whitelist slot of
+// include/modes_gfx950.h MODES_CLS_* / modes_classify once for BOTH attempts, each on the lanes of its own half), three quad
+// permutes pack the four bytes of a dword into every lane of their quad, and lanes 4k store dword k: one coalesced 64-byte store
+// (lanes 4k + 1: the same dword to the host's pinned copy).  Round 6: one lane used to write the record field by field - 14 byte
+// reversals, a classification and 30 stores per attempt, twice -, and the class byte had made record_kernel 14 % slower on the
+// frames stream (43.9 -> 50.1 us per 4 GiB call).  `maxfix` / `aggressive`: the context's repair policy.
+__device__ __forceinline__ void store_record(modes_record *dev, modes_record *host, int lane, uint32_t block, uint32_t j,
+                                             modes_m128 bits0, uint32_t err0, AttemptFix f0, modes_m128 bits1, uint32_t err1, bool gate1,
+                                             AttemptFix f1, int maxfix, int aggressive) {
+    const bool second = lane >= 36;                                          // this lane's attempt
+    const int o = lane - (second ? 36 : 8);                                  // its byte's offset in the attempt (negative: the header)
+    const uint64_t lo = second ? bits1.lo : bits0.lo, hi = second ? bits1.hi : bits0.hi;
+    const uint32_t err = second ? err1 : err0, gate = second ? (gate1 ? 1u : 0u) : 1u;
+    const uint32_t syn = second ? f1.syndrome : f0.syndrome, nfix = second ? f1.nfix : f0.nfix;
+    const uint32_t pos0 = second ? f1.pos0 : f0.pos0, pos1 = second ? f1.pos1 : f0.pos1;
+    // message byte b: pairs 8b .. 8b + 7 are bits 8b .. of the mask, pair 8b + t is bit 7 - t of the byte (modes_bits_to_msg)
+    auto msg_byte = [&](int b) -> uint32_t {
+        const uint32_t v = (uint32_t)((b < 8 ? lo >> (8 * b) : hi >> (8 * (b - 8))) & 0xFF);
+        return __builtin_bitreverse32(v) >> 24;
+    };
+    const uint32_t m0 = msg_byte(0), m1 = msg_byte(1), m2 = msg_byte(2), m3 = msg_byte(3);
+    const uint32_t cls = modes_classify((int)(m0 >> 3), err, gate, syn, nfix, maxfix > 0 ? 1u : 0u, aggressive ? 1u : 0u);
+    const uint32_t wslot = modes_class_slot(cls, m1, m2, m3, syn);
+    uint32_t byte;
+    if (lane < 4) byte = block >> (8 * lane);
+    else if (lane < 8) byte = j >> (8 * (lane - 4));
+    else if (o < 14) byte = msg_byte(o);
+    else if (o < 24) {
+        const uint32_t low = err | (gate << 8) | (nfix << 16) | (pos0 << 24);                // bytes 14 .. 17
+        const uint64_t mid = (uint64_t)low | ((uint64_t)(pos1 | ((cls & 0xFF) << 8) | ((wslot & 0xFFFF) << 16)) << 32);   // .. 21; 22, 23: 0
+        byte = (uint32_t)(mid >> (8 * (o - 14)));
+    } else byte = syn >> (8 * (o - 24));
+    byte &= 0xFF;
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte, 0x00, 0xf, 0xf, true);   // quad_perm [0,0,0,0]
+    const uint32_t b1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte, 0x55, 0xf, 0xf, true);   // [1,1,1,1]
+    const uint32_t b2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte, 0xAA, 0xf, 0xf, true);   // [2,2,2,2]
+    const uint32_t b3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)byte, 0xFF, 0xf, 0xf, true);   // [3,3,3,3]
+    const uint32_t dword = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    const int q = lane & 3;
+    uint32_t *dst = q == 0 ? reinterpret_cast<uint32_t *>(dev) : reinterpret_cast<uint32_t *>(host);
+    if (q < (host ? 2 : 1)) dst[lane >> 2] = dword;
 }
 
 // The delta sums of dump1090.c:1713-1717 over the first 56 and over all 112 pairs (lane L: pairs L, L + 64).
@@ -1011,13 +1034,10 @@ __device__ __forceinline__ bool demod_rest(const DemodParams &P, const Lut lut, 
     // syndromes and repair positions: the whole wavefront, both attempts (wave-uniform results)
     const AttemptFix f0 = wave_finish_attempt(bits0, true, P.maxfix, lane, s_esyn);
     const AttemptFix f1 = wave_finish_attempt(bits1, gate1, P.maxfix, lane, s_esyn);
-    // lane 0 writes the record; with a host copy to fill (record_kernel, short lists) lane 1 writes the same values there
-    if (lane < (host_rec ? 2 : 1) && slot < P.max_records) {
-        modes_record *rec = lane == 0 ? &P.staging[slot] : host_rec;
-        rec->block = (uint32_t)(g / MODES_BLOCK_STRIDE);
-        rec->j = j;
-        store_attempt(&rec->att[0], bits0, err0, true, f0, P.maxfix, P.aggressive);
-        store_attempt(&rec->att[1], bits1, err1, gate1, f1, P.maxfix, P.aggressive);
+    // the whole wavefront writes the record (store_record); with a host copy to fill (record_kernel, short lists) the same dwords there
+    if (slot < P.max_records) {                                              // (wave-uniform)
+        store_record(&P.staging[slot], host_rec, lane, (uint32_t)(g / MODES_BLOCK_STRIDE), j, bits0, err0, f0, bits1, err1, gate1, f1,
+                     P.maxfix, P.aggressive);
         if (KEYED && lane == 0) P.keys[slot] = key;
     }
     return true;

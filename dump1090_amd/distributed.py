@@ -405,12 +405,29 @@ class RankResolve:
             self._dev = torch.empty(self._cap, dtype=torch.uint8, device=self.device)
             self._pin = torch.empty(self._cap, dtype=torch.uint8).pin_memory()
 
-    def _gather(self, arr):
+    # Every gather of the protocol travels in ONE fixed shape - word 0 = "this rank is well", word 1 = the payload's length, the payload
+    # padded to the longest one: a rank whose own work fails between two exchanges (a ModesError in its resolve, an assertion) still
+    # takes part in the next gather, with word 0 = 0, and EVERY rank raises there and then - instead of the peers sitting in an
+    # all_gather the failed rank never joins until the group's timeout.
+    _WORDS = 2 + _HDR + N.ICAO_SLOTS
+
+    def _gather(self, arr, failed=None):
         torch, dist = self.torch, self.dist
-        mine = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64))
-        out = torch.empty(self.world * mine.numel(), dtype=torch.int64)
+        mine = torch.zeros(self._WORDS, dtype=torch.int64)
+        if failed is None:
+            a = np.ascontiguousarray(arr, dtype=np.int64)
+            assert a.size <= self._WORDS - 2
+            mine[0], mine[1] = 1, a.size
+            mine[2: 2 + a.size] = torch.from_numpy(a)
+        out = torch.empty(self.world * self._WORDS, dtype=torch.int64)
         dist.all_gather_into_tensor(out, mine, group=self.ctl)
-        return list(out.numpy().reshape(self.world, -1))
+        rows = out.numpy().reshape(self.world, -1)
+        bad = [r for r in range(self.world) if not int(rows[r][0])]
+        if bad:
+            if failed is not None:
+                raise failed
+            raise N.ModesError(-5, "resolve on the ranks: rank(s) %s failed inside the step; every rank stops here" % bad)
+        return [rows[r][2: 2 + int(rows[r][1])] for r in range(self.world)]
 
     def _texts(self, view, sizes):
         """-> rank 0: [uint8 array per rank] (views of buffers that live until the next step), others None"""
@@ -432,18 +449,19 @@ class RankResolve:
                 dist.send(torch.from_numpy(view), dist.get_global_rank(self.ctl, 0), group=self.ctl)
                 self.p2p_ops += 1
             return None
-        # device memory: the default group is RCCL
+        # device memory: the default group is RCCL; its peers are GLOBAL ranks - `ctl` may number the ranks its own way
+        g = lambda r: dist.get_global_rank(self.ctl, r)
         with torch.cuda.stream(self.stream):
             if me == 0:
                 self._grow(moved + (n if self.world == 1 else 0))
                 ops, offs, where = [], 0, {}
                 for r in peers:
                     where[r] = (offs, sizes[r])
-                    ops.append(dist.P2POp(dist.irecv, self._dev[offs: offs + sizes[r]], r))
+                    ops.append(dist.P2POp(dist.irecv, self._dev[offs: offs + sizes[r]], g(r)))
                     offs += sizes[r]
                 if self.world == 1 and n:                   # a group of one: the text goes through isend / irecv to itself (the calls of
                     src = torch.from_numpy(view).to(self.device, non_blocking=False)        # the N > 1 path on the hardware at hand)
-                    ops += [dist.P2POp(dist.irecv, self._dev[:n], 0), dist.P2POp(dist.isend, src, 0)]
+                    ops += [dist.P2POp(dist.irecv, self._dev[:n], g(0)), dist.P2POp(dist.isend, src, g(0))]
                     offs = n
                 if ops:
                     for w in dist.batch_isend_irecv(ops):
@@ -463,7 +481,7 @@ class RankResolve:
                 self._grow(n)
                 self._pin[:n].copy_(torch.from_numpy(view))
                 self._dev[:n].copy_(self._pin[:n], non_blocking=True)
-                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, self._dev[:n], 0)]):
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, self._dev[:n], g(0))]):
                     w.wait()
                 self.p2p_ops += 1
             self.stream.synchronize()
@@ -482,7 +500,11 @@ class RankResolve:
             self._prev = None
         gen = rank_resolve_step(self.make, self.rank, self.world, self.state, segments, self.threads, now, spoil, buf)
         t = time.perf_counter()
-        ask = next(gen)
+        try:
+            ask = next(gen)
+        except Exception as e:                              # noqa: BLE001 - this rank's own work failed before the first exchange:
+            self._gather(None, failed=e)                    # the peers are told in it (raises e here, ModesError there)
+            raise
         ph = 0
         while True:
             t1 = time.perf_counter()
@@ -497,6 +519,13 @@ class RankResolve:
             except StopIteration as e:
                 out = e.value
                 break
+            except Exception as e:                          # noqa: BLE001 - ... or between two exchanges: the next one is a gather
+                # (behind the text exchange nothing is left to exchange; behind the round's last gather - every rank's check came
+                #  back good - the peers' next exchange is the texts, not a gather: nothing but two array copies lies in between)
+                last_check = ask[0] == "gather" and ask[1].size == 1 and all(int(x[0]) for x in reply)
+                if ask[0] == "gather" and not last_check:
+                    self._gather(None, failed=e)
+                raise
         self.work_s += time.perf_counter() - t
         self.phase_s[min(ph, 7)] += time.perf_counter() - t
         self.state = out["whitelist"]

@@ -183,7 +183,17 @@ def split_calls(first_block, nblocks, ncalls, lo, total_bytes):
     return out
 
 
-def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, rank=0, dist=None, coll_device=None,
+def run_steps(*args, **kwargs):
+    """_run_steps with the garbage collector's state restored afterwards (it is switched off for the timed regions)."""
+    was = gc.isenabled()
+    try:
+        return _run_steps(*args, **kwargs)
+    finally:
+        if was:
+            gc.enable()
+
+
+def _run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, rank=0, dist=None, coll_device=None,
               cap_records=1 << 16, streams=(None,), device_sync=lambda: None, time_every=8, resolve_threads=1,
               gather=None, oplog=None, lag=None, resolve_on="root", ctl_group=None, regions=1):
     """`warm` untimed + `steps` timed steps of the hot path over this rank's shard `iq` (stream bytes from `lo`;
@@ -386,7 +396,12 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     first_timed_call = warm * len(calls)
     timed_phase = (min(time_every, steps * len(calls)) - 1) % time_every
     t0_region = None
-    gc_was = False
+    # No collector pauses inside the timed regions: a pass over the interpreter's objects is milliseconds - one region of five read 0.2875 ms
+    # per step next to four at 0.214-0.217 (profiles/r09/bench_line_gc.json); the loop allocates no cycles.  Collected HERE, in front of the
+    # warm-up: a pause between the warm-up and the first region idles the chip and restarts its clock transient (that region then read
+    # 0.245 next to 0.216-0.219).
+    gc.collect()
+    gc.disable()                                               # (run_steps puts it back, whatever happens in here)
     for step in range(warm + regions * steps):
         if step > warm and (step - warm) % steps == 0:          # a region ends here, the next one begins: the same bracket as at the very end
             for k in list(order):
@@ -407,11 +422,6 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
                 e.wait()
             if resolver is not None:
                 resolver.drain()
-            # (no collector pauses inside the timed regions: a pass over the interpreter's objects is milliseconds - one region of five
-            #  read 0.2875 ms per step next to four at 0.214-0.217, profiles/r09/bench_line_gc.json; the loop allocates no cycles)
-            gc_was = gc.isenabled()
-            gc.collect()
-            gc.disable()
             sync_all()
             prof0 = [d.host_profile() for d in demods if hasattr(d, "host_profile")]
             if rr is not None:                                  # (its thread is idle: drained above)
@@ -488,8 +498,7 @@ def run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ran
     sync_all()
     t_end = time.perf_counter()
     region_elapsed.append(t_end - t0_region)
-    if gc_was:
-        gc.enable()
+
     # where the (last) region's final moments go (ms): the calls still in flight when the loop ends, the resolver, the final sync
     tail_ms = {"in_flight": round((t_adv - t_loop) * 1e3, 4), "resolver": round((t_drain - t_adv) * 1e3, 4),
                "sync": round((t_end - t_drain) * 1e3, 4)}

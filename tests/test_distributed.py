@@ -158,3 +158,59 @@ def test_resolve_on_the_ranks_over_gloo(tmp_path, golden, world, case, fs):
     assert open(tmp_path / "out.txt").read() == golden[case]["raw"][fs]["text"]
     steps, rounds, p2p = [int(v) for v in open(tmp_path / "facts.txt").read().split()]
     assert steps == 2 and rounds >= 2 and p2p >= 1
+
+
+def _failing_rank_worker(rank, world, port, where, outdir):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import time
+    import torch.distributed as dist
+    import oracle as orc
+    import synth
+    from dump1090_amd import block_count, shard_blocks
+    from dump1090_amd import demod
+    from dump1090_amd._native import ModesError
+    from dump1090_amd.distributed import RankResolve
+    from helpers import oracle_records
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    ctl = dist.new_group(backend="gloo")
+    data = synth.case_frames()
+    flags = orc.FLAGSETS["default"]
+    first, n = shard_blocks(block_count(data.size), world, rank)
+    recs, _ = oracle_records(data, 1, blocks=range(first, first + n))
+    if rank == 1:                                         # this rank's own work fails: before the first exchange / between two of them
+        def boom(self, *a, **k):
+            raise RuntimeError("rank 1's resolve failed on purpose")
+        if where == "guess":
+            demod.HostResolver.whitelist_guess = boom
+        else:
+            demod.HostResolver.raw_listing_spec = boom
+    rr = RankResolve(flags, threads=1, ctl=ctl, fresh=True)
+    t0 = time.time()
+    try:
+        rr.step([recs])
+        verdict = "no error"
+    except RuntimeError as e:                             # (ModesError is a RuntimeError)
+        verdict = "%s: %s" % ("ModesError" if isinstance(e, ModesError) else "RuntimeError", str(e)[:60])
+    with open(os.path.join(outdir, "rank%d.txt" % rank), "w") as f:
+        f.write("%.1f %s" % (time.time() - t0, verdict))
+    # (no barrier: a rank that failed is not expected to take part in anything else)
+
+
+@pytest.mark.parametrize("where", ["guess", "resolve"])
+def test_a_rank_that_fails_inside_the_step_stops_every_rank_at_the_next_exchange(tmp_path, where):
+    """an exception on one rank's resolver inside RankResolve.step used to leave its peers in an all_gather it never joined
+    until the group's 300 s timeout.  Every gather carries a "this rank is well" word now: the failing rank still takes part in the next
+    one, with the word down, raises its own error, and every other rank raises a ModesError there and then - within seconds."""
+    ctx = mp.spawn(_failing_rank_worker, args=(3, _free_port(), where, str(tmp_path)), nprocs=3, join=False)
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=2.0):
+        assert time.time() - t0 < 60, "the ranks hung"
+    out = [open(tmp_path / ("rank%d.txt" % r)).read() for r in range(3)]
+    assert out[1].split(" ", 1)[1].startswith("RuntimeError: rank 1's resolve failed on purpose"), out
+    for r in (0, 2):
+        secs, verdict = out[r].split(" ", 1)
+        assert float(secs) < 20 and verdict.startswith("ModesError") and "rank(s) [1] failed" in verdict, out

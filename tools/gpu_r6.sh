@@ -24,6 +24,13 @@ for s in "$@"; do
     e2e)       run e2e_cli 900 python tools/e2e_cli.py 8 ;;
     pipe)      run pipe_cadence 600 python -m pytest tests/test_gpu_parity.py tests/test_dropin.py -m gpu -q -x -p no:cacheprovider -k "pipe or paced" ;;
     fuzz)      run fuzz_parity 900 python tools/fuzz_parity.py 5000 600 ;;
+    forced)    run pytest_gpu_forced_and_fuzz 1500 python -m pytest tests/test_gpu_forced.py -m gpu -q -x -p no:cacheprovider ;;
+    legs)      for wl in frames lowsnr frames lowsnr; do
+                 python bench.py --workload $wl --steps 40 --no-end-to-end --no-live-traffic --no-cpu-baseline --no-ceiling 2>/dev/null | grep '^{' | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline())
+print('$wl: ms_per_step %.4f kernel_ms %s' % (d['ms_per_step'], {k: d['kernel_ms'][k] for k in ('scan', 'demod', 'order')}))"
+               done > "$O/legs.txt" 2>&1; cat "$O/legs.txt" ;;
     threads_ab) for rt in 2 4 8 15 2 4 8 15; do
                  python bench.py --workload frames --steps 40 --no-end-to-end --no-live-traffic --no-cpu-baseline --no-ceiling --resolve-threads $rt 2>/dev/null | grep '^{' | python -c "
 import sys, json
