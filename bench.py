@@ -670,7 +670,22 @@ def main():
             # the same steps over the same resident shard with the OTHER resolve mode (root: the lists travel to rank 0, which resolves them all;
             # ranks: every rank resolves its own, the texts travel): a sub-linear point of the curve is attributed in the record itself
             mode2 = "root" if args.resolve_on == "ranks" else "ranks"
-            other = leg(iq_f, lo, calls, flags, steps, settle_steps, cap_records, nls, nls == 1, resolve_on=mode2)
+            # (the first pass is the line's; a second pass that raises - on every rank or on one - is reported, not fatal: the ranks
+            #  agree on the outcome before anything else is exchanged)
+            err2 = None
+            try:
+                other = leg(iq_f, lo, calls, flags, steps, settle_steps, cap_records, nls, nls == 1, resolve_on=mode2)
+            except Exception as e:                               # noqa: BLE001
+                other, err2 = None, "%s: %s" % (type(e).__name__, str(e)[:300])
+            verdicts = [None] * world
+            if world > 1:
+                dist.all_gather_object(verdicts, err2)
+            else:
+                verdicts = [err2]
+            if any(v is not None for v in verdicts):
+                other = None
+                res["other_mode_error"] = {"resolve_on": mode2, "errors": {r: v for r, v in enumerate(verdicts) if v is not None}}
+        if other is not None:
             other.update(total=total_bytes, span=hi - lo, per_gpu=total_bytes // world, settle_steps=settle_steps, resolve_on=mode2,
                          scan_ms=res["scan_ms"], demod_ms=res["demod_ms"], order_ms=res["order_ms"], scan_ms_median=res["scan_ms_median"],
                          timed_calls=res["timed_calls"], kernel_timing="the first pass's (the same kernels on the same input)")
@@ -845,6 +860,8 @@ def main():
             legs["frames_strong"] = dict(legs["frames"], scaling="strong", same_run_as="frames")
         else:
             legs["frames_strong"] = leg_summary(strong, sname, "strong")
+        if strong.get("other_mode_error"):
+            legs["frames_strong_other_mode_error"] = strong["other_mode_error"]
         if strong.get("other_mode") is not None:                # the same steps with the other resolve mode, behind the first pass
             o = strong["other_mode"]
             legs["frames_strong_resolve_on_%s" % o["resolve_on"]] = leg_summary(o, sname + " - resolve_on=%s" % o["resolve_on"], "strong")

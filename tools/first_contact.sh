@@ -39,6 +39,11 @@ record rr${N}_small $([ $RC = 0 ] && [ "$md5" = $REF_RAW ] && echo true || echo 
 means "$N PROCESSES, one device each, NO communicator (--resolve-on-ranks): every rank resolves its own batches, rank 0 prints the texts." \
       "A failure here is a device that does not come up or a context that cannot be made on it - nothing RCCL could be blamed for."
 
+run rr${N}_stats 200 $EXE --ifile tests/golden/modes1.bin --stats --ranks $N --batch-blocks 1 --resolve-on-ranks
+md5=$(md5sum < "$O/rr${N}_stats.out" | cut -c1-32)
+record rr${N}_stats $([ $RC = 0 ] && [ "$md5" = $REF_STATS ] && echo true || echo false) $SECS "status $RC, --stats md5 $md5 (reference $REF_STATS)"
+means "the same mode for --stats (round 6): every rank counts its own batches, rank 0 adds the nine counters up - still no communicator."
+
 run ranks${NR}_small 1200 $EXE --ifile tests/golden/modes1.bin --raw --ranks $NR --batch-blocks 1 --timing
 md5=$(md5sum < "$O/ranks${NR}_small.out" | cut -c1-32)
 record ranks${NR}_small $([ $RC = 0 ] && [ "$md5" = $REF_RAW ] && echo true || echo false) $SECS "status $RC, listing md5 $md5 (reference $REF_RAW)"
@@ -75,6 +80,12 @@ run bench${N}_all 1500 python bench.py --gpus $N --steps 20 --warmup 5
 ok=$(jget "$O/bench${N}_all.out" "all(d[k]['listing_check'].get('equals_reference_md5') in (True, None) for k in ('frames', 'lowsnr', 'frames_strong')) and d['n_gpus'] == $N")
 record bench${N}_all $([ $RC = 0 ] && [ "$ok" = True ] && echo true || echo false) $SECS "status $RC, $(jget "$O/bench${N}_all.out" "'value %.0f Msamples/s over %d GPU(s); frames %.0f, low SNR %.0f, 64 GiB strong %.0f' % (d['value'], d['n_gpus'], d['frames']['Msamples_per_s'], d['lowsnr']['Msamples_per_s'], d['frames_strong']['Msamples_per_s'])")"
 means "the driver's command: every leg (noise, frames, low SNR, the 64 GiB stream at every N)."
+# round 6: that ONE invocation carries both answers - the strong leg's steps in the given resolve mode and, over the same resident shards, in
+# the other, each with its listing check and its scaling_breakdown {slowest rank's kernels, rank 0's resolve, exchange, step, efficiency}
+ok=$(jget "$O/bench${N}_all.out" "$N == 1 or ('frames_strong_resolve_on_ranks' in d and d['frames_strong_resolve_on_ranks']['listing_check']['md5'] == d['frames_strong']['listing_check']['md5'])")
+record bench${N}_all_both_modes $([ "$ok" = True ] && echo true || echo false) 0 "$(jget "$O/bench${N}_all.out" "'root: %s | ranks: %s | second-pass error: %s' % (d['frames_strong'].get('scaling_breakdown'), d.get('frames_strong_resolve_on_ranks', {}).get('scaling_breakdown'), d.get('frames_strong_other_mode_error'))")"
+means "the second pass (resolve_on = ranks) of the strong leg: a failure there is reported in the line (frames_strong_other_mode_error), not fatal;" \
+      "the two scaling_breakdown objects say where a sub-linear step went - kernels, rank 0's host half, or the exchange."
 
 if [ -w /dev/shm ]; then
   python - <<'PY'
