@@ -440,7 +440,7 @@ def test_c_host_one_process_per_gpu_with_two_and_three_processes():
     # on the ranks: N = 1, 2, 3, 8 with right and wrong starts, and a pipe
     assert p.stdout.count(b"--stats / --onlyaddr / --raw-net --ranks") == 8 and b"--ifile - --stats --ranks 3 --resolve-on-ranks: md5 bc3d1c04" in p.stdout
     assert p.stdout.count(b"--stats --resolve-on-ranks --ranks") == 4
-    assert p.stdout.count(b"fails in its GPU call") == 2 and p.stdout.count(b": status 1") == 2       # a failing rank ends the job there too
+    assert p.stdout.count(b"fails in its GPU call") == 2 and p.stdout.count(b": status 1\n") == 2       # a failing rank ends the job there too
     # ... and a rank KILLED between publishing its guess and its final tables (nobody sets `failed`): the watchdog / the parent-death signal
     # end the job within two seconds, whichever rank it is (the script checks status and time)
     assert p.stdout.count(b"between guess and final: status") == 3
