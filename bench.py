@@ -452,6 +452,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-mib", type=int, default=1024, help="MiB of the workload timed on the CPU baseline")
     ap.add_argument("--run-chunks", type=int, default=0)
     ap.add_argument("--demod-variant", type=int, default=0, help="modes_gpu_config.demod_variant (include/modes_gfx950.h)")
+    ap.add_argument("--direct-records", type=int, default=0,
+                    help="modes_gpu_config.direct_records: lists of up to this many records are written to the host's pinned copy by the "
+                         "kernels themselves (0 = the library's default, 4096); longer lists follow as one device-to-host copy")
     ap.add_argument("--depth", type=int, default=0, help="detect calls in flight (contexts used in rotation); default 4, and 6 when "
                                                         "the record lists are gathered (N > 1): that pipeline has two more stages")
     ap.add_argument("--settle", type=int, default=240,
@@ -598,7 +601,7 @@ def main():
 
         def make():
             d = Demodulator(device=local, run_chunks=args.run_chunks, overlap=args.overlap,
-                            demod_variant=args.demod_variant, max_records=cap_records if dist_on and not ranks_resolve else 0, **flags)
+                            demod_variant=args.demod_variant, direct_records=args.direct_records, max_records=cap_records if dist_on and not ranks_resolve else 0, **flags)
             return d if timing else NoTiming(d)
         return run_steps(make, iq, lo, calls, flags, steps, warm, args.depth, world=world, rank=rank, dist=dist,
                          coll_device=coll_dev, cap_records=cap_records, streams=works,

@@ -279,7 +279,14 @@ MODES_HD void modes_power8_sat(const uint32_t w[4], uint32_t out[4]) {
 MODES_HD void modes_order8_swar(const uint32_t E[12], uint32_t r[4]) {
     uint32_t O[11];
 #pragma unroll
+#if defined(SCAN_ABL_NOPERM)
+    /* ablation build (timing only; tools/ab_scan.py): the odd-aligned pairs cost nothing - some other dword of the window stands in
+     * (ten distinct samples per position still, so noise survives at the same rate): what the scan would gain if the eight v_perm
+     * per chunk were not needed */
+    for (int t = 0; t < 11; t++) O[t] = E[(t + 6) % 12];
+#else
     for (int t = 0; t < 11; t++) O[t] = (E[t] >> 16) | (E[t + 1] << 16);
+#endif
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t x0 = E[q], x1 = O[q], x2 = E[q + 1], x3 = O[q + 1], x4 = E[q + 2], x5 = O[q + 2],
