@@ -239,16 +239,17 @@ def test_paced_pipe_through_both_hosts_on_the_gpu(tmp_path):
     """GPU box: the C++ host and the batched drop-in on a pipe at the radio's cadence (one buffer per 66 ms) with their default batch
     sizes - first output before the writer is done, stdout byte-identical to the file run; an unpaced pipe too."""
     raw = os.path.join(ROOT, "tests", "golden", "modes1.bin")
-    four = tmp_path / "ten.bin"
-    four.write_bytes(open(raw, "rb").read() * 10)
+    four = tmp_path / "thirty.bin"
+    four.write_bytes(open(raw, "rb").read() * 30)
     exe = os.path.join(ROOT, "dump1090_amd", "bin", "dump1090_amd")
     want = run_md5(exe, ["--ifile", str(four), "--raw"])
-    assert want[0] > 2500
+    assert want[0] > 7500
     for cmd in ([exe, "--ifile", "-", "--raw"], [BATCHED, "--ifile", "-", "--raw"], [exe, "--ifile", "-", "--raw", "--ranks", "1", "--resolve-on-ranks"]):
-        d = _paced(cmd, raw, ms=66, repeat=10)
+        d = _paced(cmd, raw, ms=66, repeat=30)
         assert (d["lines"], d["md5"]) == want, (cmd, d)
         # (the process starts the HIP runtime, a second context and two pinned buffers while the first buffers arrive: 0.3-0.5 s of the
-        #  writer's 1.8 s; the drop-in prints a hand-off when the next one is submitted)
+        #  writer's 5.9 s - seconds on a box whose libraries are not in the page cache yet; the drop-in prints a hand-off when the next
+        #  one is submitted)
         assert d["first_output_s"] is not None and d["first_output_s"] < d["writer_done_s"] - 0.5, (cmd, d)
         with open(four, "rb") as f:
             assert run_md5(cmd[0], cmd[1:], stdin=f) == want, cmd
