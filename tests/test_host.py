@@ -380,7 +380,7 @@ def test_a_listing_that_outgrows_its_buffer_is_cut_at_a_line(streams):
 
 
 def test_c_host_under_thread_sanitizer():
-    """tools/sanitize_host.sh tsan-host: dump1090_amd/csrc/main.cpp - reader thread, resolver thread, lanes of two and three
+    """tools/sanitize_host.sh tsan-host: dump1090_amd/csrc/host_single.cpp - reader thread, resolver thread, lanes of two and three
     "devices" handed between them - built under -fsanitize=thread with the GPU library replaced by tests/native/gpu_stub.cpp
     (the oracle's stateless functions behind the same entry points).  No race, and the reference's md5s for --raw, --stats
     and --onlyaddr (the script checks both)."""

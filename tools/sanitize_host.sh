@@ -63,7 +63,7 @@ PY
         dump1090_amd/csrc/modes_host.cpp dump1090_amd/csrc/modes_track.cpp -lpthread -lm
     TSAN_OPTIONS=halt_on_error=1 /tmp/modes_mt_harness /tmp/modes_mt_records.bin
 }
-# tsan-host: the C host itself (dump1090_amd/csrc/main.cpp: reader thread, resolver thread, lanes of two "devices" handed
+# tsan-host: the C host itself (dump1090_amd/csrc/host_single.cpp: reader thread, resolver thread, lanes of two "devices" handed
 # between them) under ThreadSanitizer, the GPU library replaced by tests/native/gpu_stub.cpp (the oracle's stateless
 # functions behind the same entry points) - listing and --stats must be the reference's, and no race may be reported.
 run_tsan_host() {
@@ -251,7 +251,7 @@ PY
         [ "$got" = 4a81758c8bec5e45ffa8541c5622938a ] && [ "$(grep -c 'starting over with' $D/probe.err)" = 1 ] || { cat $D/probe.err; exit 1; }
     done
     # a rank that fails MID-STREAM (two ranks, three batches: rank 0's second GPU call / rank 1's only one): the peer is already
-    # in that round's exchange, nobody tears an RCCL communicator down on that path (main.cpp run_ranks) - status 1, promptly
+    # in that round's exchange, nobody tears an RCCL communicator down on that path (host_ranks.cpp run_ranks) - status 1, promptly
     for bad in 0:1 1:0; do
         set +e
         MODES_STUB_FAIL_SUBMIT=$bad timeout 20 $D/dump1090_amd_stub --ifile tests/golden/modes1.bin --raw --ranks 2 --batch-blocks 1 --depth 4 > /dev/null 2> $D/fail.err
@@ -354,7 +354,7 @@ PY
         echo "   --loop == oracle/_ref/dump1090_ref --loop over the same 2.5 laps"
     fi
 }
-# pipe-host: a pipe is served at the pace it delivers (main.cpp read_paced; dump1090.c:460-512, :2969-2990 print a buffer's messages
+# pipe-host: a pipe is served at the pace it delivers (host_common.h read_paced; dump1090.c:460-512, :2969-2990 print a buffer's messages
 # within that buffer): the reference's capture written one 256 KiB buffer every 150 ms into `dump1090_amd --ifile -` with the DEFAULT
 # batch size (512 buffers: a host that waits for a full batch prints nothing before the writer is done) - the first line must be out
 # before the writer has finished, the listing must be the file run's; the same through --ranks 2 (rank 0's reader deals the batches
