@@ -15,7 +15,7 @@ REF_STATS=bc3d1c04b24f4989f0fc4a2d1f45abdd      # ... --stats
 EXE=dump1090_amd/bin/dump1090_amd
 STEPS=()
 FAILED=0
-record() { STEPS+=("{\"step\": \"$1\", \"pass\": $2, \"seconds\": $3, \"detail\": \"$4\"}"); [ "$2" = true ] && echo "   PASS  $1 ($3 s) $4" || { echo "   FAIL  $1 ($3 s) $4"; FAILED=$((FAILED + 1)); }; }
+record() { local d=${4//\\/\\\\}; d=${d//\"/\\\"}; STEPS+=("{\"step\": \"$1\", \"pass\": $2, \"seconds\": $3, \"detail\": \"$d\"}"); [ "$2" = true ] && echo "   PASS  $1 ($3 s) $4" || { echo "   FAIL  $1 ($3 s) $4"; FAILED=$((FAILED + 1)); }; }
 means() { echo "         if this fails: $*"; }
 # run <name> <timeout> <command...>: log, wall seconds in $SECS, status in $RC
 run() { name=$1; limit=$2; shift 2; echo "== $name: $*"; t0=$(date +%s.%N); timeout $limit "$@" > "$O/$name.out" 2> "$O/$name.err"; RC=$?; SECS=$(python -c "import time; print('%.1f' % (time.time() - $t0))"); }
