@@ -59,6 +59,14 @@ class OracleDetector:
         pass
 
 
+def _sparse():
+    """Buffers without a single record around three buffers of frames: calls of one buffer each - the step's first, its last and
+    some in between hand the resolver an EMPTY list."""
+    import synth
+    quiet = np.full(synth.DATA_LEN, 127, dtype=np.uint8)
+    return np.concatenate([quiet, synth.case_frames(), quiet, quiet])
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -78,7 +86,7 @@ def _run(rank, world, port, case, ncalls, depth, outdir, inplace=False, slow_res
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    data = {"frames": synth.case_frames, "edges": synth.case_edges}[case]()
+    data = {"frames": synth.case_frames, "edges": synth.case_edges, "sparse": _sparse}[case]()
     total = block_count(data.size)
     first, n = shard_blocks(total - 1, world, rank)            # bench.py's sharding: the EOF buffer goes to the last rank
     if rank == world - 1:
@@ -158,6 +166,27 @@ def _spawn2(args, deadline=180.0, nprocs=2):
 def test_single_rank_pipeline(tmp_path, golden, case, ncalls, depth):
     _run(0, 1, 0, case, ncalls, depth, str(tmp_path))
     assert open(tmp_path / "out.txt").read() == golden[case]["raw"]["default"]["text"]
+
+
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_calls_without_a_record_are_taken_by_the_launching_thread(tmp_path, depth):
+    """Resolver.take_empty: a call whose list is empty never goes through the resolver thread when that thread has nothing queued
+    (bench.py's record-free headline workload: no hand-over at all) - and goes through it like any other call when it has, so that
+    the step's first / last bookkeeping keeps its order.  Seven calls of one buffer, the first, the last and one in the middle empty:
+    the listing is the oracle's for the whole stream, on every depth (depth 1: the resolver is always idle when a call ends)."""
+    sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+    import oracle as orc
+    from dump1090_amd import pipeline
+    taken = []
+    orig = pipeline.Resolver.take_empty
+    pipeline.Resolver.take_empty = lambda self, *a, **k: (taken.append(orig(self, *a, **k)), taken[-1])[1]
+    try:
+        _run(0, 1, 0, "sparse", 7, depth, str(tmp_path))
+    finally:
+        pipeline.Resolver.take_empty = orig
+    msgs, _ = orc.run_stream(_sparse(), fix=True)
+    assert open(tmp_path / "out.txt").read() == orc.raw_text(msgs) and len(msgs) >= 100
+    assert len(taken) >= 3 * 3 and any(taken)                  # three steps x (at least) three empty calls; some taken inline
 
 
 def test_several_timed_regions_behind_one_warm_up(tmp_path, golden):
