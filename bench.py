@@ -99,6 +99,19 @@ def measured_traffic(mib):
         return None, "unreadable"
 
 
+def committed_demod_traffic(mib):
+    """HBM bytes the demodulation kernel reads per launch of the headline workload (the committed PMC pass of these kernel sources), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if mib != 1024 or t.get("kernel_source_sha256_16") != kernel_source_hash():
+            return None
+        return int(t["demod_kernel"]["hbm_read_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def leg_traffic(kind):
     """Committed PMC pass of a record-bearing leg (profiles/traffic_latest.json["legs"][kind], written by tools/profile.sh <tag>
     lowsnr | frames + tools/merge_traffic.py): {kernel: HBM read bytes per launch}, or None when there is none for these kernel
@@ -889,6 +902,10 @@ def main():
         if live is not None:
             traffic, traffic_note = live
     per_rank_kernels = gathered({"scan": round(kern["scan_ms"], 4), "demod": round(kern["demod_ms"], 4)})
+    # the step in the lines it really moves: the scan's traffic (live or committed counter pass) + the demodulation kernel's (committed)
+    demod_traffic = committed_demod_traffic(args.mib) if noise is not None else None
+    step_traffic = traffic + demod_traffic if (traffic and demod_traffic and head["calls_per_step"] == 1) else None
+    step_traffic_gbs = step_traffic / (head["elapsed"] / head_steps) / 1e9 if step_traffic else None
     line = {
         "metric": "IQ Msamples/s demodulated", "value": round(value, 1), "unit": "Msamples/s",
         "n_gpus": world, "steps": head_steps, "warmup": args.warmup,
@@ -938,8 +955,13 @@ def main():
                      # the same bytes over the WHOLE step (every kernel, the fetch and the resolve behind it: the clock `value` is on)
                      "achieved_step": round(head["per_gpu"] / (head["elapsed"] / head_steps) / 1e9, 1),
                      "frac_step": round(head["per_gpu"] / (head["elapsed"] / head_steps) / 1e9 / HBM_PEAK_GBS, 4),
+                     # ... and the HBM lines the step's kernels really read (scan + demodulation, FETCH_SIZE) over the same clock
+                     "traffic_step": step_traffic,
+                     "achieved_traffic_step": round(step_traffic_gbs, 1) if step_traffic_gbs else None,
+                     "frac_traffic_step": round(step_traffic_gbs / HBM_PEAK_GBS, 4) if step_traffic_gbs else None,
                      # the box's own read-only streaming rate next to the specification
                      "measured_ceiling": ceiling,
+                     "frac_traffic_step_of_measured_ceiling": round(step_traffic_gbs / ceiling["GB_per_s"], 4) if (step_traffic_gbs and ceiling) else None,
                      "frac_of_measured_ceiling": round(achieved / ceiling["GB_per_s"], 4) if ceiling else None,
                      # `achieved` is from the HIP events of THIS run; the committed rocprofv3 trace of the same sources
                      # (profiles/): its events read ~3 % above its own kernel durations (the dispatch's ~5 us lead-in)
