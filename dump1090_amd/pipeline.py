@@ -396,7 +396,8 @@ def _run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ra
             host["fetch"] += time.perf_counter() - t_a
             note(info, timed)
         if resolver is not None:
-            if counts is None and len(recs) == 0 and resolver.take_empty(tag[0], tag[1], keep_text=tag[2]):
+            # (gathered lists: only a step of ONE call - then the resolver would resolve the list where it stands, like a rank's own)
+            if len(recs) == 0 and (counts is None or (tag[0] and tag[1])) and resolver.take_empty(tag[0], tag[1], keep_text=tag[2]):
                 return                                          # nothing to resolve, nothing to print: the buffer stays free
             free[k].clear()
             resolver.submit(recs, counts, tag[0], tag[1], timed, free[k], keep_text=tag[2])
@@ -421,6 +422,15 @@ def _run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ra
             stage.pop(k)
             order.remove(k)
 
+    def flush():
+        """Everything in flight to the resolver.  Phase by phase over all calls, not call by call: the count all_gathers of all of them
+        are queued before the first list transfer is, so the exchanges of the last calls overlap instead of standing behind one another at
+        the end of a timed region (a 20-step region of the headline leg ends with up to three calls in flight; every rank flushes at the
+        same step with the same calls in flight, so the order of the communication calls stays the same everywhere)."""
+        for upto in (1, 2, 3):
+            for k in list(order):
+                advance(k, upto)
+
     t0 = None
     prof0 = []
     ncall = 0
@@ -435,8 +445,7 @@ def _run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ra
     gc.disable()                                               # (run_steps puts it back, whatever happens in here)
     for step in range(warm + regions * steps):
         if step > warm and (step - warm) % steps == 0:          # a region ends here, the next one begins: the same bracket as at the very end
-            for k in list(order):
-                advance(k, 3)
+            flush()
             for e in free:
                 e.wait()
             if resolver is not None:
@@ -447,8 +456,7 @@ def _run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ra
             t0_region = t_now
             cur_region[0] += 1
         if step == warm:
-            for k in list(order):
-                advance(k, 3)
+            flush()
             for e in free:
                 e.wait()
             if resolver is not None:
@@ -518,8 +526,7 @@ def _run_steps(make_demod, iq, lo, calls, flags, steps, warm, depth, world=1, ra
             elif len(order) >= 3:
                 advance(order[0], 3)
     t_loop = time.perf_counter()
-    for k in list(order):
-        advance(k, 3)
+    flush()
     t_adv = time.perf_counter()
     for e in free:
         e.wait()
